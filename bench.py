@@ -1,0 +1,276 @@
+#!/usr/bin/env python3
+"""Benchmark of the VAE training hot path (fwd + bwd ELBO) on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg2|cfg3|cfg4|cfg1]
+
+One "step" = one fused forward+backward ELBO pass over one batch of synthetic cells that is
+already resident in HBM (plus, for N > 1, the gradient all-reduce).  The default workload is
+BASELINE.json configs[1]: 20k genes, ZINB, hidden 256, latent 30, batch 512, fp32.
+Rank 0 prints ONE JSON line (metric: cells/sec, whole job) with `roofline` for the dominant
+kernel (measured with HIP events on the launch stream) and `cpu_baseline` (the oracle's
+plain-PyTorch step timed on the host cores, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CONFIGS = {
+    # name: G, H, Hd, Hl, L, n_layers, likelihood, per-GPU batch, precision, resident cells per GPU
+    "cfg1": dict(G=2000, H=128, Hd=128, Hl=128, L=10, n_layers=1, likelihood="nb", B=512, precision="fp32", cells=10_000,
+                 desc="10k cells x 2k genes, NB, hidden 128, latent 10"),
+    "cfg2": dict(G=20000, H=256, Hd=256, Hl=128, L=30, n_layers=1, likelihood="zinb", B=512, precision="fp32",
+                 cells=100_000, desc="100k cells x 20k genes, ZINB, hidden 256, latent 30, batch 512, fp32"),
+    "cfg3": dict(G=20000, H=256, Hd=256, Hl=128, L=30, n_layers=1, likelihood="zinb", B=4096, precision="bf16",
+                 cells=100_000, desc="20k-gene ZINB, bf16 MFMA GEMMs + fp32 likelihood, batch 4096"),
+    "cfg4": dict(G=20000, H=256, Hd=256, Hl=128, L=30, n_layers=2, likelihood="zinb", B=4096, precision="bf16",
+                 cells=131_072, desc="20k genes, 2-layer encoder/decoder, batch 4096 per GPU, data parallel"),
+}
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s
+MFMA_PEAK = {"fp32": 157.3, "bf16": 2500.0}  # dense TFLOP/s
+
+
+def synth_counts_device(n, G, device, seed, zero_inflate):
+    """SURVEY.md §8(d) synthetic counts generated on the device in chunks: Poisson(lambda_g * s_c),
+    optional zero inflation, no all-zero rows.  Stored fp32 (the boundary hands fp32 counts)."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    lam = torch.exp(torch.randn(G, generator=g, device=device) * 1.5 - 1.5).clamp(0, 50)
+    out = torch.empty(n, G, dtype=torch.float32, device=device)
+    for i in range(0, n, 8192):
+        m = min(8192, n - i)
+        s = torch.exp(torch.randn(m, 1, generator=g, device=device) * 0.25)
+        x = torch.poisson(lam.unsqueeze(0) * s, generator=g)
+        if zero_inflate > 0:
+            x = x * (torch.rand(m, G, generator=g, device=device) >= zero_inflate)
+        x[:, 0] += (x.sum(dim=1) == 0).float()
+        out[i:i + m] = x
+    return out
+
+
+def time_kernel(fn, iters=5):
+    """Average device time (ms) of fn() measured with HIP events on the current stream."""
+    fn()
+    torch.cuda.synchronize()
+    st, en = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    st.record()
+    for _ in range(iters):
+        fn()
+    en.record()
+    torch.cuda.synchronize()
+    return st.elapsed_time(en) / iters
+
+
+def kernel_breakdown(arena, cfg, x, precision):
+    """Per-kernel timings of the big stages at the bench shapes, on the launch stream."""
+    from vae_amd import ops
+    from vae_amd.arena import _enc
+    B, G, H, Hl, Hd = x.shape[0], cfg["G"], cfg["H"], cfg["Hl"], cfg["Hd"]
+    zinb = cfg["likelihood"] == "zinb"
+    dev = x.device
+    w_enc = arena.pcat(_enc("z_encoder", 0, "w"), _enc("l_encoder", 0, "w"))
+    if zinb:
+        w_heads = arena.pcat("decoder.px_scale_decoder.0.weight", "decoder.px_dropout_decoder.weight")
+    else:
+        w_heads = arena.p("decoder.px_scale_decoder.0.weight")
+    NH = w_heads.shape[0]
+    mean = ops.row_mean(x)
+    px = torch.randn(B, Hd, device=dev)
+    dpre = torch.randn(B, H + Hl, device=dev) * 1e-3
+    logits = torch.randn(B, NH, device=dev)
+    lib = torch.full((B,), 9.0, device=dev)
+    table = ops.gene_table(arena.p("px_r"))
+    ll, rmax, rsum, S = ops.nbzinb_fwd(zinb, logits[:, :G], logits[:, G:] if zinb else None, x, lib, table)
+    dl = torch.empty_like(logits)
+    dlib, dpxr = torch.empty(B, device=dev), torch.zeros(G, device=dev)
+    dbs, dbp = torch.zeros(G, device=dev), torch.zeros(G, device=dev)
+    gw_heads, gw_enc = torch.empty_like(w_heads), torch.empty_like(w_enc)
+    P = precision
+    ks = {}
+    fl = lambda m, n, k: 2.0 * m * n * k  # noqa: E731
+    ks["gemm_enc_fwd"] = (time_kernel(lambda: ops.gemm(ops.NT, x, w_enc, x_mean=mean, precision=P)), "mfma", fl(B, H + Hl, G))
+    ks["gemm_dec_fwd"] = (time_kernel(lambda: ops.gemm(ops.NT, px, w_heads, out=logits, precision=P)), "mfma", fl(B, NH, Hd))
+    ks["gemm_dec_wgrad"] = (time_kernel(lambda: ops.gemm(ops.TN, logits, px, out=gw_heads, precision=P)), "mfma", fl(NH, Hd, B))
+    ks["gemm_dec_dgrad"] = (time_kernel(lambda: ops.gemm(ops.NN, logits, w_heads, precision=P)), "mfma", fl(B, Hd, NH))
+    ks["gemm_enc_wgrad"] = (time_kernel(lambda: ops.gemm(ops.TN, dpre, x, out=gw_enc, x_mean=mean, precision=P)), "mfma", fl(H + Hl, G, B))
+    logits.normal_()
+    per = 12 if zinb else 8
+    ks["nbzinb_fwd"] = (time_kernel(lambda: ops.nbzinb_fwd(zinb, logits[:, :G], logits[:, G:] if zinb else None, x, lib, table)),
+                        "hbm", float(per) * B * G)
+    per_b = 20 if zinb else 12
+    ks["nbzinb_bwd"] = (time_kernel(lambda: ops.nbzinb_bwd(zinb, logits[:, :G], logits[:, G:] if zinb else None, x, lib, table,
+                                                           rmax, rsum, S, None, -1e-5, dl[:, :G], dl[:, G:] if zinb else None,
+                                                           dlib, dpxr, dbs, dbp if zinb else None)),
+                        "hbm", float(per_b) * B * G)
+    return ks
+
+
+def cpu_baseline(cfg, threads):
+    """The oracle's plain-PyTorch fwd+bwd step on the host cores (bounded: ~10-30 s)."""
+    from oracle import vae_oracle as O
+    torch.set_num_threads(threads)
+    B = 512 if cfg["G"] >= 20000 else 256
+    p = O.init_params(cfg["G"], cfg["H"], cfg["Hd"], cfg["Hl"], cfg["L"], cfg["n_layers"], seed=43)
+    x = O.synthetic_counts(B, cfg["G"], seed=43, zero_inflate=0.3 if cfg["likelihood"] == "zinb" else 0.0)
+    g = torch.Generator().manual_seed(44)
+    ez, el = torch.randn(B, cfg["L"], generator=g), torch.randn(B, 1, generator=g)
+    lm, lv = O.library_prior(x)
+    leaves = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+
+    def one():
+        for v in leaves.values():
+            v.grad = None
+        out = O.training_step(leaves, x, ez, el, n_layers=cfg["n_layers"], likelihood=cfg["likelihood"], l_mean=lm, l_var=lv)
+        out["loss"].backward()
+
+    for _ in range(2):
+        one()
+    times = []
+    t_end = time.time() + 20.0
+    while len(times) < 10 and (time.time() < t_end or len(times) < 3):
+        t0 = time.perf_counter()
+        one()
+        times.append(time.perf_counter() - t0)
+    times.sort()
+    med = times[len(times) // 2]
+    return dict(value=B / med, unit="cells/s", cores=threads, kind="port",
+                sample=f"{len(times)} fwd+bwd steps of batch {B} of the same config (oracle/vae_oracle.py, fp32, "
+                       f"median {med * 1e3:.1f} ms/step)")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the config's)")
+    ap.add_argument("--precision", default="", choices=["", "fp32", "bf16"])
+    ap.add_argument("--grad-payload", default="fp32", choices=["fp32", "bf16"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-breakdown", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py: --gpus N > 1 must be launched through torch.distributed.run (one rank per GPU)")
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from vae_amd import ops
+    from vae_amd.arena import ParamArena
+    from vae_amd.networks import VAE
+    from vae_amd.parallel import GradAllReducer, broadcast_parameters
+    from vae_amd.step import ElboStep
+
+    cfg = dict(CONFIGS[args.config])
+    if args.batch:
+        cfg["B"] = args.batch
+    if args.precision:
+        cfg["precision"] = args.precision
+    B, G, L = cfg["B"], cfg["G"], cfg["L"]
+    precision = ops.BF16 if cfg["precision"] == "bf16" else ops.FP32
+
+    # model: the reference architecture with torch default init under seed 43 (train.py:20)
+    torch.manual_seed(43)
+    net = VAE(G, n_hidden=cfg["H"], n_hidden_decoder=cfg["Hd"], n_hidden_library=cfg["Hl"], n_latent=L,
+              n_latent_cell_decoder=L, n_layers=cfg["n_layers"], dropout_rate=0.0, input_dropout_rate=0.0,
+              cell_properties={"Dementia": {"discrete": True, "values": [0, 1], "stop_grad": False}},
+              grad_reverse_dict={}, reconstruction_loss=cfg["likelihood"])
+    arena = ParamArena(dict(net.named_parameters()), cfg["n_layers"], cfg["likelihood"], dev)
+    del net
+    broadcast_parameters(arena)
+
+    # data: this rank's shard of the synthetic matrix, resident in HBM
+    n_cells = max(B, (cfg["cells"] // B) * B)
+    n_cells = min(n_cells, 64 * B)  # bounded resident pool: 64 distinct batches per rank are plenty
+    x_all = synth_counts_device(n_cells, G, dev, seed=43 + rank, zero_inflate=0.3 if cfg["likelihood"] == "zinb" else 0.0)
+    lib = torch.log1p(x_all.sum(dim=1).double())
+    l_mean, l_var = float(lib.mean()), float(lib.var(unbiased=False))
+    n_batches = n_cells // B
+    gen = torch.Generator(device=dev).manual_seed(43 + rank)
+    eps_z = torch.randn(B, L, generator=gen, device=dev)
+    eps_l = torch.randn(B, 1, generator=gen, device=dev)
+
+    step = ElboStep(arena, l_mean=l_mean, l_var=l_var, kl_weight=1.0, gene_loss_coeff=5e-3, precision=precision)
+    reducer = GradAllReducer(arena, payload=args.grad_payload) if world > 1 else None
+
+    def one_step(i):
+        xb = x_all[(i % n_batches) * B:(i % n_batches + 1) * B]
+        out = step.run(xb, eps_z, eps_l, reducer=reducer)
+        if reducer is not None:
+            reducer.finish()
+        return out
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        one_step(i)
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out = one_step(args.warmup + i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    loss = float(out["loss"])
+
+    result = None
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        value = world * B * args.steps / elapsed
+        result = {
+            "metric": "training cells/sec (fwd+bwd ELBO, 20k genes)" if G == 20000 else f"training cells/sec (fwd+bwd ELBO, {G} genes)",
+            "value": value, "unit": "cells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if cfg["precision"] == "fp32" else "bf16 GEMM operands, f32 accumulate and likelihood",
+            "data": "synthetic",
+            "config": {"workload": f"{args.config}: {cfg['desc']}", "batch_per_gpu": B, "global_batch": B * world,
+                       "genes": G, "likelihood": cfg["likelihood"], "n_layers": cfg["n_layers"],
+                       "parallelism": f"dp{world}", "grad_payload": args.grad_payload if world > 1 else None},
+            "final_loss": loss,
+        }
+    if rank == 0 and not args.no_breakdown:
+        xb = x_all[:B]
+        ks = kernel_breakdown(arena, cfg, xb, precision)
+        name, (t_ms, bound, work) = max(ks.items(), key=lambda kv: kv[1][0])
+        if bound == "hbm":
+            ach, peak, unit = work / (t_ms * 1e-3) / 1e9, HBM_PEAK_GBS, "GB/s"
+        else:
+            ach, peak, unit = work / (t_ms * 1e-3) / 1e12, MFMA_PEAK[cfg["precision"]], "TFLOP/s"
+        result["roofline"] = {"kernel": name, "bound": bound, "achieved": ach, "peak": peak, "unit": unit,
+                              "frac": ach / peak, "traffic": None, "avg_launch_ms": t_ms}
+        result["kernels"] = {
+            k: {"ms": v[0], "bound": v[1],
+                "achieved": (v[2] / (v[0] * 1e-3) / (1e9 if v[1] == "hbm" else 1e12)),
+                "unit": "GB/s" if v[1] == "hbm" else "TFLOP/s"} for k, v in ks.items()}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        threads = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16") or 16))
+        result["cpu_baseline"] = cpu_baseline(cfg, threads)
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

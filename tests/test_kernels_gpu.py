@@ -1,0 +1,189 @@
+"""GPU parity tests of the individual HIP kernels, called through the C ABI (vae_amd.ops),
+against fp64 CPU computations and the reference-generated likelihood grid."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import load_golden, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from vae_amd import ops as o
+    return o
+
+
+def _rand(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand(*shape, generator=g, dtype=torch.float64) * 2 - 1) * scale
+
+
+GEMM_SHAPES = [
+    # (M, N, K)  -- ragged on purpose, plus split-K shapes (skinny M,N with long K)
+    (8, 16, 64), (5, 31, 30), (129, 130, 33), (512, 384, 2000), (96, 257, 4101), (300, 40, 7), (1, 1, 1),
+]
+
+
+@pytest.mark.parametrize("layout", [0, 1, 2])
+@pytest.mark.parametrize("shape", GEMM_SHAPES)
+def test_gemm_fp32(ops, layout, shape):
+    M, N, K = shape
+    a64 = _rand((M, K), 1)
+    b64 = _rand((K, N), 2)
+    bias64 = _rand((N,), 3)
+    ref = a64 @ b64 + bias64
+    A = (a64 if layout != ops.TN else a64.t().contiguous()).float().cuda()
+    Bm = (b64.t().contiguous() if layout == ops.NT else b64).float().cuda()
+    out = ops.gemm(layout, A, Bm, bias=bias64.float().cuda())
+    torch.cuda.synchronize()
+    assert rel_err(out.cpu().numpy(), ref.numpy()) < 2e-6 * max(1, np.sqrt(K) / 8)
+    # accumulate=True adds on top
+    out2 = ops.gemm(layout, A, Bm, out=out.clone(), accumulate=True)
+    assert rel_err(out2.cpu().numpy(), (2 * ref - bias64).numpy()) < 4e-6 * max(1, np.sqrt(K) / 8)
+
+
+@pytest.mark.parametrize("layout", [0, 1, 2])
+def test_gemm_bf16(ops, layout):
+    M, N, K = 130, 200, 1000
+    a64, b64 = _rand((M, K), 4), _rand((K, N), 5)
+    ar, br = a64.float().bfloat16().double(), b64.float().bfloat16().double()
+    ref = ar @ br
+    A = (a64 if layout != ops.TN else a64.t().contiguous()).float().cuda()
+    Bm = (b64.t().contiguous() if layout == ops.NT else b64).float().cuda()
+    out = ops.gemm(layout, A, Bm, precision=ops.BF16)
+    assert rel_err(out.cpu().numpy(), ref.numpy()) < 1e-5  # operands rounded identically; fp32 accumulate
+
+
+@pytest.mark.parametrize("layout", [0, 2])
+def test_gemm_normalised_counts(ops, layout):
+    """x/mean - 1 applied on the fly to the count operand (modules.py:264)."""
+    Bc, G, H = 37, 1003, 24
+    g = torch.Generator().manual_seed(7)
+    x = torch.poisson(torch.rand(Bc, G, generator=g) * 3, generator=g)
+    x[:, 0] += 1
+    mean = ops.row_mean(x.cuda())
+    assert torch.equal(mean.cpu(), x.mean(dim=-1))
+    xn = (x.double() / x.double().mean(-1, keepdim=True)) - 1
+    if layout == ops.NT:
+        w = _rand((H, G), 8, 0.05)
+        ref = xn @ w.t()
+        out = ops.gemm(ops.NT, x.cuda(), w.float().cuda(), x_mean=mean)
+    else:
+        dy = _rand((Bc, H), 9)
+        ref = dy.t() @ xn
+        out = ops.gemm(ops.TN, dy.float().cuda(), x.cuda(), x_mean=mean)
+    assert rel_err(out.cpu().numpy(), ref.numpy()) < 5e-6
+
+
+def test_gemm_rejects_bad_arguments(ops):
+    a = torch.zeros(4, 8, device="cuda")
+    with pytest.raises(ValueError):
+        ops.gemm(ops.NT, a, torch.zeros(4, 9, device="cuda"))
+    with pytest.raises(RuntimeError):
+        ops.gemm(ops.NT, torch.zeros(4, 8), torch.zeros(4, 8))
+    with pytest.raises(TypeError):
+        ops.gemm(ops.NT, a.double(), a.double())
+
+
+@pytest.mark.parametrize("B,W", [(7, 12), (64, 128), (33, 256), (5, 1000)])
+def test_gelu_ln_fwd_bwd(ops, B, W):
+    pre = _rand((B, W), 11, 2.0).requires_grad_(True)
+    gamma = (1 + _rand((W,), 12, 0.3)).requires_grad_(True)
+    beta = _rand((W,), 13, 0.3).requires_grad_(True)
+    dout = _rand((B, W), 14)
+    y = torch.nn.functional.layer_norm(torch.nn.functional.gelu(pre), (W,), gamma, beta, 1e-5)
+    y.backward(dout)
+    out, mean, rstd = ops.gelu_ln_fwd(pre.detach().float().cuda(), gamma.detach().float().cuda(), beta.detach().float().cuda())
+    assert rel_err(out.cpu().numpy(), y.detach().numpy()) < 3e-6
+    dg = torch.zeros(W, device="cuda"); db = torch.zeros(W, device="cuda"); dbias = torch.zeros(W, device="cuda")
+    dpre = ops.gelu_ln_bwd(dout.float().cuda(), pre.detach().float().cuda(), mean, rstd, gamma.detach().float().cuda(), dg, db, dbias)
+    assert rel_err(dpre.cpu().numpy(), pre.grad.numpy()) < 1e-5
+    assert rel_err(dg.cpu().numpy(), gamma.grad.numpy()) < 1e-5
+    assert rel_err(db.cpu().numpy(), beta.grad.numpy()) < 1e-5
+    assert rel_err(dbias.cpu().numpy(), pre.grad.sum(0).numpy()) < 1e-5
+
+
+@pytest.mark.parametrize("B,L,pm,pv", [(9, 4, 0.0, 1.0), (130, 30, 0.0, 1.0), (17, 1, 7.3, 0.21)])
+def test_reparam_kl_fwd_bwd(ops, B, L, pm, pv):
+    from torch.distributions import Normal, kl_divergence
+    heads = _rand((B, L + 1), 21, 3.0)
+    heads[0, L] = 25.0  # softplus threshold branch
+    heads.requires_grad_(True)
+    eps = _rand((B, L), 22, 2.0)
+    qm, qv = heads[:, :L], torch.nn.functional.softplus(heads[:, L:]) + 1e-4
+    z = qm + eps * qv.sqrt()
+    kl = kl_divergence(Normal(qm, qv.sqrt()), Normal(torch.tensor(pm, dtype=torch.float64),
+                                                     torch.tensor(pv, dtype=torch.float64).sqrt())).sum(1)
+    dz = _rand((B, L), 23)
+    gk = _rand((B,), 24)
+    (z * dz).sum().backward(retain_graph=True)
+    (0.37 * (kl * gk).sum()).backward()
+    hq = heads.detach().float().cuda()
+    qv_g, z_g, kl_g = ops.reparam_kl_fwd(hq, eps.float().cuda(), pm, pv)
+    assert rel_err(qv_g.cpu().numpy(), qv.detach().numpy()[:, 0]) < 2e-6
+    assert rel_err(z_g.cpu().numpy(), z.detach().numpy()) < 2e-6
+    assert rel_err(kl_g.cpu().numpy(), kl.detach().numpy()) < 5e-6
+    dh = ops.reparam_kl_bwd(dz.float().cuda(), gk.float().cuda(), 0.37, hq, eps.float().cuda(), qv_g, pm, pv)
+    assert rel_err(dh.cpu().numpy(), heads.grad.numpy()) < 1e-5
+
+
+def test_colsum_and_elbo_reduce(ops):
+    m = _rand((301, 77), 31)
+    out = torch.zeros(77, device="cuda")
+    ops.colsum_into(m.float().cuda(), out)
+    assert rel_err(out.cpu().numpy(), m.sum(0).numpy()) < 1e-5
+    ll, kz, kl_ = -_rand((1000,), 32, 500).abs(), _rand((1000,), 33).abs(), _rand((1000,), 34).abs()
+    s = ops.elbo_reduce(ll.float().cuda(), kz.float().cuda(), kl_.float().cuda(), 0.7, 5e-3).cpu().double()
+    gl = (-ll).mean() + 0.7 * (kz + kl_).mean()
+    ref = torch.stack([(-ll).mean(), kz.mean(), kl_.mean(), gl, 5e-3 * gl])
+    assert rel_err(s.numpy(), ref.numpy()) < 1e-6
+
+
+def _grid_condition_scales(gold):
+    """Magnitudes of the terms each quantity is a sum/difference of: an fp32 evaluation of
+    the reference formulas (the reference itself included: its own fp32 run sits at <= 2.7
+    eps*T on this grid) cannot be closer to the fp64 truth than a few eps32 * these."""
+    from scipy.special import gammaln, digamma
+    x, mu, th, pi = gold["x"], gold["mu"], gold["theta"], gold["pi"]
+    e = 1e-8
+    T = (np.abs(gammaln(x + th)) + np.abs(gammaln(th)) + np.abs(gammaln(x + 1)) + np.abs(x * np.log(mu + e))
+         + np.abs((x + th) * np.log(th + mu + e)) + np.abs(th * np.log(th + e)) + np.abs(pi) + 1)
+    Tm = x / (mu + e) + (x + th) / (th + mu + e) + 1e-3
+    Tt = (np.abs(digamma(x + th)) + np.abs(digamma(th)) + np.abs(np.log((th + e) / (th + mu + e))) + 2
+          + x / (th + mu + e))
+    lr = np.abs(np.log((th + e) / (th + mu + e)))
+    Tp = 0.25 * (th * (np.abs(np.log(th + e)) + np.abs(np.log(th + mu + e))) + np.abs(pi)) + 1
+    # zero branch of ZINB: sigmoid(pi_theta_log) carries the rounding of theta*log-ratio into dmu / dtheta
+    Tm = Tm + Tp * th / (th + mu + e)
+    Tt = Tt + Tp * (lr + 2)
+    return T, Tm, Tt, Tp
+
+
+@pytest.mark.parametrize("zinb", [True, False])
+def test_likelihood_grid_elementwise(ops, zinb):
+    """log_zinb_positive / log_nb_positive and their gradients on the reference-made grid
+    (x up to 5e4, mu 1e-8..1e4, theta 1e-3..1e4, softplus-threshold edges at |pi| ~ 20).
+    Truth = the reference run in fp64; bound = 6 eps32 x the condition scale of each quantity."""
+    gold = load_golden("likelihood_grid.npz")
+    n = gold["x"].size
+    cols = 512
+    rows = n // cols
+    assert rows * cols == n
+
+    def dev(a):
+        return torch.tensor(a, dtype=torch.float32).view(rows, cols).cuda()
+
+    x, mu, th, pi = dev(gold["x"]), dev(gold["mu"]), dev(gold["theta"]), dev(gold["pi"])
+    key = "zinb" if zinb else "nb"
+    T, Tm, Tt, Tp = _grid_condition_scales(gold)
+    eps32 = 2.0 ** -24
+    out = ops.loglik_elem_fwd(zinb, x, mu, th, pi).cpu().numpy().ravel().astype(np.float64)
+    assert np.all(np.isfinite(out))
+    assert np.max(np.abs(out - gold[f"f64/{key}"]) / (eps32 * T)) < 6.0
+    dmu, dth, dpi = ops.loglik_elem_bwd(zinb, torch.ones_like(x), x, mu, th, pi)
+    for got, name, sc in ((dmu, "dmu", Tm), (dth, "dtheta", Tt)) + (((dpi, "dpi", Tp),) if zinb else ()):
+        g_ = got.cpu().numpy().ravel().astype(np.float64)
+        assert np.all(np.isfinite(g_)), name
+        assert np.max(np.abs(g_ - gold[f"f64/{key}_{name}"]) / (eps32 * sc)) < 8.0, name

@@ -1,0 +1,68 @@
+"""ctypes binding of the C-ABI HIP library ``vae_amd/lib/libvae_amd.so`` (include/vae_amd.h).
+
+The product path has NO fallback: if the library is missing or fails to load, every op
+raises.  Build it with ``python -c "import __graft_entry__ as g; g.build()"`` or
+``make -C vae_amd/csrc``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libvae_amd.so")
+
+_i64, _i32, _f32, _ptr = C.c_int64, C.c_int, C.c_float, C.c_void_p
+
+# name -> (restype, argtypes); mirrors include/vae_amd.h one to one
+SIGNATURES = {
+    "vae_version": (_i32, []),
+    "vae_arch": (C.c_char_p, []),
+    "vae_last_error": (C.c_char_p, []),
+    "vae_device_count": (_i32, []),
+    "vae_gemm_workspace_bytes": (_i64, [_i64, _i64, _i64]),
+    "vae_gemm": (_i32, [_i32, _i32, _i64, _i64, _i64, _ptr, _i64, _ptr, _i64, _ptr, _i64, _ptr, _ptr, _i32, _ptr, _i64, _ptr]),
+    "vae_row_mean": (_i32, [_ptr, _i64, _i64, _i64, _ptr, _ptr]),
+    "vae_gelu_ln_fwd": (_i32, [_ptr, _i64, _ptr, _ptr, _i64, _i64, _ptr, _i64, _ptr, _ptr, _ptr]),
+    "vae_gelu_ln_bwd": (_i32, [_ptr, _i64, _ptr, _i64, _ptr, _ptr, _ptr, _i64, _i64, _ptr, _i64, _ptr, _ptr, _ptr, _ptr]),
+    "vae_reparam_kl_fwd": (_i32, [_ptr, _i64, _ptr, _i64, _i64, _i64, _f32, _f32, _ptr, _ptr, _i64, _ptr, _ptr]),
+    "vae_reparam_kl_bwd": (_i32, [_ptr, _i64, _ptr, _f32, _ptr, _i64, _ptr, _i64, _ptr, _i64, _i64, _f32, _f32, _ptr, _i64, _ptr]),
+    "vae_colsum": (_i32, [_ptr, _i64, _i64, _i64, _ptr, _ptr]),
+    "vae_elbo_reduce": (_i32, [_ptr, _ptr, _ptr, _i64, _f32, _f32, _ptr, _ptr]),
+    "vae_gene_table": (_i32, [_ptr, _i64, _ptr, _ptr]),
+    "vae_nbzinb_max_genes": (_i64, []),
+    "vae_nbzinb_fwd": (_i32, [_i32, _ptr, _i64, _ptr, _i64, _ptr, _i64, _ptr, _ptr, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _ptr]),
+    "vae_nbzinb_bwd": (_i32, [_i32, _ptr, _i64, _ptr, _i64, _ptr, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _f32, _i64, _i64,
+                              _ptr, _i64, _ptr, _i64, _ptr, _ptr, _ptr, _ptr, _ptr]),
+    "vae_softmax_rate_fwd": (_i32, [_ptr, _i64, _ptr, _i64, _i64, _ptr, _ptr, _ptr]),
+    "vae_softmax_rate_bwd": (_i32, [_ptr, _ptr, _ptr, _ptr, _i64, _i64, _ptr, _i64, _ptr, _ptr]),
+    "vae_loglik_elem_fwd": (_i32, [_i32, _ptr, _i64, _ptr, _i64, _ptr, _i64, _ptr, _i64, _i64, _i64, _ptr, _i64, _ptr]),
+    "vae_loglik_elem_bwd": (_i32, [_i32, _ptr, _i64, _ptr, _i64, _ptr, _i64, _ptr, _i64, _ptr, _i64, _i64, _i64, _ptr, _ptr, _ptr, _ptr]),
+}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load the library once; raise loudly (no CPU fallback) when it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"vae_amd: HIP library not found at {LIB_PATH}. Build it (make -C vae_amd/csrc); "
+            "there is no CPU fallback for the product path."
+        )
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here = header / library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = load().vae_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"vae_amd {what} failed (status {rc}): {msg}")

@@ -1,0 +1,136 @@
+"""Flat parameter / gradient arena for the VAE hot path.
+
+All parameters of the model live in ONE contiguous fp32 buffer in HBM, ordered so that
+  * the first-layer weights of the z- and library-encoders are adjacent: one (H+Hl, G) matrix,
+    so the counts are streamed through ONE genes->hidden GEMM;
+  * the px_scale / px_dropout head weights are adjacent: one (2G, Hd) matrix -> one
+    hidden->genes GEMM producing both logit arrays;
+  * every small tensor whose gradient is accumulated with float atomics (biases, LayerNorm
+    affine, px_r, cell heads) sits in one "small" region that is zeroed with a single fill
+    per step; the big weight gradients are overwritten by the wgrad GEMMs and never zeroed.
+The gradient arena mirrors the layout, which makes the data-parallel all-reduce a handful
+of large contiguous buckets (vae_amd/parallel.py).  State-dict key names are the
+reference's (networks.py:162-231).
+"""
+from __future__ import annotations
+
+from collections import OrderedDict
+from typing import Dict, Iterable, List, Optional, Tuple
+
+import torch
+
+
+def _enc(prefix: str, n: int, what: str) -> str:
+    return f"{prefix}.encoder.fc_layers.{4 * n + (0 if what in ('w', 'b') else 2)}." + (
+        "weight" if what in ("w", "g") else "bias")
+
+
+def _dec(n: int, what: str) -> str:
+    return f"decoder.px_decoder.fc_layers.{4 * n + (0 if what in ('w', 'b') else 2)}." + (
+        "weight" if what in ("w", "g") else "bias")
+
+
+class ParamArena:
+    """Owns the flat parameter and gradient buffers and hands out views."""
+
+    def __init__(self, params: Dict[str, torch.Tensor], n_layers: int, likelihood: str, device):
+        self.n_layers = n_layers
+        self.likelihood = likelihood
+        self.device = torch.device(device)
+        names = set(params.keys())
+        cell = sorted(k for k in names if k.startswith("cell_decoder."))
+        # groups = runs of parameters that the kernels address as ONE stacked matrix / vector;
+        # only group starts are aligned to 16 bytes so that members stay adjacent
+        big = [[_enc("z_encoder", 0, "w"), _enc("l_encoder", 0, "w")],
+               ["decoder.px_scale_decoder.0.weight", "decoder.px_dropout_decoder.weight"]]
+        mid: List[List[str]] = [[_enc("z_encoder", n, "w")] for n in range(1, n_layers)]
+        mid += [["z_encoder.mean_encoder.weight", "z_encoder.var_encoder.weight"],
+                ["l_encoder.mean_encoder.weight", "l_encoder.var_encoder.weight"]]
+        mid += [[_dec(n, "w")] for n in range(n_layers)]
+        small: List[List[str]] = [["px_r"], [_enc("z_encoder", 0, "b"), _enc("l_encoder", 0, "b")],
+                                  ["decoder.px_scale_decoder.0.bias", "decoder.px_dropout_decoder.bias"],
+                                  ["z_encoder.mean_encoder.bias", "z_encoder.var_encoder.bias"],
+                                  ["l_encoder.mean_encoder.bias", "l_encoder.var_encoder.bias"]]
+        for n in range(n_layers):
+            small += [[_enc("z_encoder", n, "g")], [_enc("z_encoder", n, "beta")]]
+            if n > 0:
+                small.append([_enc("z_encoder", n, "b")])
+            small += [[_dec(n, "b")], [_dec(n, "g")], [_dec(n, "beta")]]
+        small += [[_enc("l_encoder", 0, "g")], [_enc("l_encoder", 0, "beta")]]
+        small += [[k] for k in cell]
+        unused = [["decoder.px_r_decoder.weight"], ["decoder.px_r_decoder.bias"]]
+        groups = big + mid + small + unused
+        order = [k for grp in groups for k in grp]
+        missing = [k for k in order if k not in names]
+        extra = names - set(order)
+        if missing or extra:
+            raise KeyError(f"ParamArena: parameter set mismatch; missing {missing}, unexpected {sorted(extra)}")
+
+        self.offsets: "OrderedDict[str, Tuple[int, torch.Size]]" = OrderedDict()
+        off = 0
+        for grp in groups:
+            off = (off + 3) & ~3  # 16-byte alignment of every group start (vector loads)
+            if grp is small[0]:
+                self.small_begin = off
+            if grp is unused[0]:
+                self.small_end = off
+            for k in grp:
+                self.offsets[k] = (off, params[k].shape)
+                off += params[k].numel()
+        self.used_end = self.small_end
+        self.total = (off + 3) & ~3
+        self.flat = torch.zeros(self.total, dtype=torch.float32, device=self.device)
+        self.flat_grad = torch.zeros(self.total, dtype=torch.float32, device=self.device)
+        for k in order:
+            self.p(k).copy_(params[k].detach().to(device=self.device, dtype=torch.float32))
+        # parameters the loss never reaches (grad None in the reference): SURVEY quirk 6
+        self.no_grad = {k for grp in unused for k in grp}
+        if likelihood == "nb":
+            self.no_grad |= {"decoder.px_dropout_decoder.weight", "decoder.px_dropout_decoder.bias"}
+
+    # -- views ---------------------------------------------------------------------------
+    def _view(self, buf: torch.Tensor, k: str) -> torch.Tensor:
+        off, shape = self.offsets[k]
+        n = 1
+        for s in shape:
+            n *= s
+        return buf[off:off + n].view(shape)
+
+    def p(self, k: str) -> torch.Tensor:
+        return self._view(self.flat, k)
+
+    def g(self, k: str) -> torch.Tensor:
+        return self._view(self.flat_grad, k)
+
+    def _cat(self, buf: torch.Tensor, keys: Iterable[str]) -> torch.Tensor:
+        """One tensor spanning adjacent parameters stacked along dim 0."""
+        keys = list(keys)
+        off0, shape0 = self.offsets[keys[0]]
+        cols = shape0[1:] if len(shape0) > 1 else torch.Size([])
+        rows, expect = 0, off0
+        for k in keys:
+            off, shape = self.offsets[k]
+            tail = shape[1:] if len(shape) > 1 else torch.Size([])
+            if off != expect or tail != cols:
+                raise RuntimeError(f"ParamArena: {keys} are not adjacent / compatible in the arena")
+            n = 1
+            for s in shape:
+                n *= s
+            expect = off + n
+            rows += shape[0]
+        return buf[off0:expect].view((rows,) + tuple(cols))
+
+    def pcat(self, *keys: str) -> torch.Tensor:
+        return self._cat(self.flat, keys)
+
+    def gcat(self, *keys: str) -> torch.Tensor:
+        return self._cat(self.flat_grad, keys)
+
+    def zero_small_grads(self) -> None:
+        self.flat_grad[self.small_begin:self.small_end].zero_()
+
+    def grads(self) -> Dict[str, Optional[torch.Tensor]]:
+        return {k: (None if k in self.no_grad else self.g(k)) for k in self.offsets}
+
+    def state_dict(self) -> Dict[str, torch.Tensor]:
+        return {k: self.p(k) for k in self.offsets}

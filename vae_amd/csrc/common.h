@@ -1,0 +1,76 @@
+// Shared device/host helpers for the vae_amd HIP library (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define VAE_OK 0
+#define VAE_ERR_ARG 1
+#define VAE_ERR_LAUNCH 2
+#define VAE_ERR_UNSUPPORTED 3
+
+// Records a message retrievable through vae_last_error(); returns `code`.
+int vae_set_error(int code, const char* fmt, ...);
+
+#define VAE_REQUIRE(cond, ...)                                  \
+  do {                                                          \
+    if (!(cond)) return vae_set_error(VAE_ERR_ARG, __VA_ARGS__); \
+  } while (0)
+
+#define VAE_CHECK_LAUNCH(name)                                                            \
+  do {                                                                                    \
+    hipError_t e__ = hipGetLastError();                                                   \
+    if (e__ != hipSuccess)                                                                \
+      return vae_set_error(VAE_ERR_LAUNCH, "%s: launch failed: %s", name, hipGetErrorString(e__)); \
+  } while (0)
+
+static inline bool vae_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+#ifdef __HIPCC__
+constexpr int WAVE = 64;
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, WAVE));
+  return v;
+}
+
+// Block-wide sum over NW waves; `scratch` holds >= NW floats of LDS. Every thread gets the result.
+template <int NW>
+__device__ __forceinline__ float block_sum(float v, float* scratch) {
+  v = wave_sum(v);
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  __syncthreads();
+  if (l == 0) scratch[w] = v;
+  __syncthreads();
+  float t = 0.f;
+#pragma unroll
+  for (int i = 0; i < NW; ++i) t += scratch[i];
+  return t;
+}
+template <int NW>
+__device__ __forceinline__ float block_max(float v, float* scratch) {
+  v = wave_max(v);
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  __syncthreads();
+  if (l == 0) scratch[w] = v;
+  __syncthreads();
+  float t = scratch[0];
+#pragma unroll
+  for (int i = 1; i < NW; ++i) t = fmaxf(t, scratch[i]);
+  return t;
+}
+
+// torch.nn.functional.softplus with beta=1, threshold=20 (distributions.py:42,47; modules.py:269)
+__device__ __forceinline__ float softplus20(float v) { return v > 20.f ? v : log1pf(expf(v)); }
+// its derivative as torch's softplus_backward evaluates it: z/(z+1), z = exp(v)
+__device__ __forceinline__ float softplus20_grad(float v) {
+  if (v > 20.f) return 1.f;
+  const float z = expf(v);
+  return z / (z + 1.f);
+}
+#endif

@@ -1,0 +1,344 @@
+// Row-wise kernels of the VAE hot path (gfx950): per-cell mean of the count row, the
+// GELU -> LayerNorm half of an FCLayers layer (forward + backward), the fused
+// reparameterisation-sample + Gaussian-KL kernel (forward + backward), column sums for bias
+// gradients and the ELBO reduction.
+//
+// Layout rule: one 64-lane wavefront owns one cell (row); the hidden width (<= 1024) lives in
+// registers, row reductions are wavefront shuffles, per-column reductions over cells are
+// accumulated in registers across the rows a wave visits, combined through LDS and flushed
+// with one float atomic per column per workgroup.
+#include "common.h"
+
+namespace {
+
+constexpr int MAXW = 1024;           // widest hidden layer a wave keeps in registers
+constexpr int NPL = MAXW / WAVE;     // elements per lane
+
+// ---------------------------------------------------------------------------------------
+// per-cell mean of x (Encoder.forward: x.mean(dim=-1), modules.py:264).  Counts are integers
+// whose row sums stay below 2^24, so any summation order gives torch's result exactly.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void row_mean_kernel(const float* __restrict__ x, int64_t ld, int B, int G, int vec,
+                                                       float* __restrict__ mean) {
+  __shared__ float red[4];
+  const int b = blockIdx.x;
+  const float* row = x + (int64_t)b * ld;
+  float s = 0.f;
+  if (vec) {
+    const int n4 = G >> 2;
+    for (int i = threadIdx.x; i < n4; i += 256) {
+      const float4 v = reinterpret_cast<const float4*>(row)[i];
+      s += (v.x + v.y) + (v.z + v.w);
+    }
+    for (int i = (n4 << 2) + threadIdx.x; i < G; i += 256) s += row[i];
+  } else {
+    for (int i = threadIdx.x; i < G; i += 256) s += row[i];
+  }
+  s = block_sum<4>(s, red);
+  if (threadIdx.x == 0) mean[b] = s / (float)G;
+}
+
+// ---------------------------------------------------------------------------------------
+// GELU(erf) -> LayerNorm(eps 1e-5, affine) forward (FCLayers, modules.py:112-114).
+// `pre` = Linear output incl. bias.  Saves mean / rstd of the GELU output per row.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ float gelu_f(float v) { return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_grad(float v) {
+  const float cdf = 0.5f * (1.f + erff(v * 0.70710678118654752440f));
+  const float pdf = 0.39894228040143267794f * expf(-0.5f * v * v);
+  return cdf + v * pdf;
+}
+
+__global__ __launch_bounds__(256) void gelu_ln_fwd_kernel(const float* __restrict__ pre, int64_t ld_pre,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          int B, int W, float* __restrict__ out, int64_t ld_out,
+                                                          float* __restrict__ mean, float* __restrict__ rstd) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= B) return;
+  const float* p = pre + (int64_t)row * ld_pre;
+  float g[NPL];
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < NPL; ++j) {
+    const int c = lane + j * WAVE;
+    g[j] = c < W ? gelu_f(p[c]) : 0.f;
+    s += g[j];
+  }
+  const float mu = wave_sum(s) / (float)W;
+  float q = 0.f;
+#pragma unroll
+  for (int j = 0; j < NPL; ++j) {
+    const int c = lane + j * WAVE;
+    const float d = c < W ? g[j] - mu : 0.f;
+    q += d * d;
+  }
+  const float rs = 1.f / sqrtf(wave_sum(q) / (float)W + 1e-5f);
+  float* o = out + (int64_t)row * ld_out;
+#pragma unroll
+  for (int j = 0; j < NPL; ++j) {
+    const int c = lane + j * WAVE;
+    if (c < W) o[c] = (g[j] - mu) * rs * gamma[c] + beta[c];
+  }
+  if (lane == 0) {
+    mean[row] = mu;
+    rstd[row] = rs;
+  }
+}
+
+// Backward of the above plus the three per-column reductions over cells that sit on it:
+// dgamma += sum_b dout*xhat, dbeta += sum_b dout, dbias += sum_b dpre (bias of the Linear
+// that produced `pre`).  dpre may alias dout.
+__global__ __launch_bounds__(256) void gelu_ln_bwd_kernel(const float* dout, int64_t ld_dout,
+                                                          const float* __restrict__ pre, int64_t ld_pre,
+                                                          const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                          const float* __restrict__ gamma, int B, int W, float* dpre,
+                                                          int64_t ld_dpre, float* __restrict__ dgamma,
+                                                          float* __restrict__ dbeta, float* __restrict__ dbias) {
+  __shared__ float comb[3][4][WAVE];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float ag[NPL], ab[NPL], ap[NPL], gam[NPL];
+#pragma unroll
+  for (int j = 0; j < NPL; ++j) {
+    ag[j] = ab[j] = ap[j] = 0.f;
+    const int c = lane + j * WAVE;
+    gam[j] = c < W ? gamma[c] : 0.f;
+  }
+  for (int row = blockIdx.x * 4 + wave; row < B; row += gridDim.x * 4) {
+    const float* p = pre + (int64_t)row * ld_pre;
+    const float* d = dout + (int64_t)row * ld_dout;
+    const float mu = mean[row], rs = rstd[row];
+    float xh[NPL], dx[NPL], pv[NPL];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < NPL; ++j) {
+      const int c = lane + j * WAVE;
+      const bool ok = c < W;
+      pv[j] = ok ? p[c] : 0.f;
+      const float dy = ok ? d[c] : 0.f;
+      xh[j] = ok ? (gelu_f(pv[j]) - mu) * rs : 0.f;
+      dx[j] = dy * gam[j];
+      s1 += dx[j];
+      s2 += dx[j] * xh[j];
+      ag[j] += dy * xh[j];
+      ab[j] += dy;
+    }
+    s1 = wave_sum(s1) / (float)W;
+    s2 = wave_sum(s2) / (float)W;
+    float* o = dpre + (int64_t)row * ld_dpre;
+#pragma unroll
+    for (int j = 0; j < NPL; ++j) {
+      const int c = lane + j * WAVE;
+      if (c < W) {
+        const float dg = rs * (dx[j] - s1 - xh[j] * s2);
+        const float v = dg * gelu_grad(pv[j]);
+        o[c] = v;
+        ap[j] += v;
+      }
+    }
+  }
+  // combine the 4 waves of the workgroup, then one atomic per column per workgroup
+#pragma unroll
+  for (int j = 0; j < NPL; ++j) {
+    if (j * WAVE >= W) break;
+    __syncthreads();
+    comb[0][wave][lane] = ag[j];
+    comb[1][wave][lane] = ab[j];
+    comb[2][wave][lane] = ap[j];
+    __syncthreads();
+    if (wave < 3) {
+      const int c = lane + j * WAVE;
+      if (c < W) {
+        const float v = comb[wave][0][lane] + comb[wave][1][lane] + comb[wave][2][lane] + comb[wave][3][lane];
+        float* dst = wave == 0 ? dgamma : (wave == 1 ? dbeta : dbias);
+        if (dst) atomicAdd(dst + c, v);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// reparameterisation sample + Gaussian KL (Encoder.forward modules.py:268-270 with
+// reparameterize_gaussian :11-12, and LitVAE.gene_loss task.py:188-198).
+// heads[b, 0:L] = q_m, heads[b, L] = pre-activation of the ONE shared variance (modules.py:249).
+//   q_v = softplus(.) + 1e-4 ; z = q_m + eps * sqrt(q_v)
+//   kl  = sum_j 0.5 * (r + ((q_m_j - pm)/sp)^2 - 1 - log r),  r = (sqrt(q_v)/sp)^2
+// One thread per cell: L <= 64 and the arrays are tiny (B x L).
+// ---------------------------------------------------------------------------------------
+__global__ void reparam_kl_fwd_kernel(const float* __restrict__ heads, int64_t ld_h, const float* __restrict__ eps,
+                                      int64_t ld_e, int B, int L, float prior_mean, float prior_var,
+                                      float* __restrict__ qv, float* __restrict__ z, int64_t ld_z,
+                                      float* __restrict__ kl) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const float* hrow = heads + (int64_t)b * ld_h;
+  const float v = softplus20(hrow[L]) + 1e-4f;
+  const float sq = sqrtf(v), sp = sqrtf(prior_var);
+  const float r0 = sq / sp;
+  const float r = r0 * r0;
+  const float base = r - 1.f - logf(r);
+  float acc = 0.f;
+  for (int j = 0; j < L; ++j) {
+    const float m = hrow[j];
+    const float t = (m - prior_mean) / sp;
+    acc += 0.5f * (r + t * t - 1.f - logf(r));
+    z[(int64_t)b * ld_z + j] = m + eps[(int64_t)b * ld_e + j] * sq;
+  }
+  (void)base;
+  qv[b] = v;
+  kl[b] = acc;
+}
+
+// Backward: dheads from dz (gradient reaching the sample) and the upstream gradient on kl[b]
+// (g_kl_scalar * g_kl[b], g_kl may be null).  dz_extra (nullable) is added to dz first: it
+// carries the cell-property heads' contribution to the latent.
+__global__ void reparam_kl_bwd_kernel(const float* __restrict__ dz, int64_t ld_dz, const float* __restrict__ g_kl,
+                                      float g_kl_scalar, const float* __restrict__ heads, int64_t ld_h,
+                                      const float* __restrict__ eps, int64_t ld_e, const float* __restrict__ qv, int B,
+                                      int L, float prior_mean, float prior_var, float* __restrict__ dheads,
+                                      int64_t ld_dh) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const float gk = g_kl_scalar * (g_kl ? g_kl[b] : 1.f);
+  const float* hrow = heads + (int64_t)b * ld_h;
+  const float v = qv[b];
+  const float sq = sqrtf(v);
+  float dv = 0.f;
+  for (int j = 0; j < L; ++j) {
+    const float d = dz[(int64_t)b * ld_dz + j];
+    const float m = hrow[j];
+    dheads[(int64_t)b * ld_dh + j] = d + gk * (m - prior_mean) / prior_var;
+    dv += d * eps[(int64_t)b * ld_e + j];
+  }
+  // d z_j / d v = eps_j / (2 sqrt v);  d kl / d v = L * 0.5 * (1/pv - 1/v)
+  dv = dv * 0.5f / sq + gk * (float)L * 0.5f * (1.f / prior_var - 1.f / v);
+  dheads[(int64_t)b * ld_dh + L] = dv * softplus20_grad(hrow[L]);
+}
+
+// ---------------------------------------------------------------------------------------
+// column sums over cells: out[n] += sum_m in[m, n]   (bias gradients of small Linears)
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ in, int64_t ld, int M, int N,
+                                                     int rows_per_block, float* __restrict__ out) {
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= N) return;
+  const int r0 = blockIdx.y * rows_per_block;
+  const int r1 = min(M, r0 + rows_per_block);
+  float s = 0.f;
+  for (int r = r0; r < r1; ++r) s += in[(int64_t)r * ld + n];
+  atomicAdd(out + n, s);
+}
+
+// ---------------------------------------------------------------------------------------
+// ELBO reduction (LitVAE.gene_loss task.py:202 and training_step :489):
+//   out[0] = mean(recon) = -mean(ll), out[1] = mean(kl_z), out[2] = mean(kl_l),
+//   out[3] = gene_loss = out[0] + kl_weight*(mean(kl_l + kl_z)), out[4] = coeff*gene_loss
+// single workgroup, fixed summation order (deterministic).
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void elbo_reduce_kernel(const float* __restrict__ ll, const float* __restrict__ kl_z,
+                                                          const float* __restrict__ kl_l, int B, float kl_weight,
+                                                          float coeff, float* __restrict__ out) {
+  __shared__ float red[4];
+  float a = 0.f, b = 0.f, c = 0.f, d = 0.f;
+  for (int i = threadIdx.x; i < B; i += 256) {
+    a -= ll[i];
+    b += kl_z[i];
+    c += kl_l[i];
+    d += kl_l[i] + kl_z[i];
+  }
+  a = block_sum<4>(a, red);
+  b = block_sum<4>(b, red);
+  c = block_sum<4>(c, red);
+  d = block_sum<4>(d, red);
+  if (threadIdx.x == 0) {
+    const float n = (float)B;
+    const float gl = a / n + kl_weight * (d / n);
+    out[0] = a / n;
+    out[1] = b / n;
+    out[2] = c / n;
+    out[3] = gl;
+    out[4] = coeff * gl;
+  }
+}
+
+}  // namespace
+
+extern "C" int vae_row_mean(const float* x, int64_t ldx, int64_t B, int64_t G, float* mean, void* stream) {
+  VAE_REQUIRE(x && mean && B > 0 && G > 0 && ldx >= G, "vae_row_mean: bad arguments");
+  const int vec = (ldx % 4 == 0) && vae_aligned16(x);
+  hipLaunchKernelGGL(row_mean_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, x, ldx, (int)B, (int)G, vec,
+                     mean);
+  VAE_CHECK_LAUNCH("vae_row_mean");
+  return VAE_OK;
+}
+
+extern "C" int vae_gelu_ln_fwd(const float* pre, int64_t ld_pre, const float* gamma, const float* beta, int64_t B,
+                               int64_t W, float* out, int64_t ld_out, float* mean, float* rstd, void* stream) {
+  VAE_REQUIRE(pre && gamma && beta && out && mean && rstd, "vae_gelu_ln_fwd: null pointer");
+  VAE_REQUIRE(B > 0 && W > 0 && W <= MAXW, "vae_gelu_ln_fwd: width %lld not in [1, %d]", (long long)W, MAXW);
+  VAE_REQUIRE(ld_pre >= W && ld_out >= W, "vae_gelu_ln_fwd: leading dimension too small");
+  hipLaunchKernelGGL(gelu_ln_fwd_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, (hipStream_t)stream, pre, ld_pre,
+                     gamma, beta, (int)B, (int)W, out, ld_out, mean, rstd);
+  VAE_CHECK_LAUNCH("vae_gelu_ln_fwd");
+  return VAE_OK;
+}
+
+extern "C" int vae_gelu_ln_bwd(const float* dout, int64_t ld_dout, const float* pre, int64_t ld_pre, const float* mean,
+                               const float* rstd, const float* gamma, int64_t B, int64_t W, float* dpre, int64_t ld_dpre,
+                               float* dgamma, float* dbeta, float* dbias, void* stream) {
+  VAE_REQUIRE(dout && pre && mean && rstd && gamma && dpre, "vae_gelu_ln_bwd: null pointer");
+  VAE_REQUIRE(B > 0 && W > 0 && W <= MAXW, "vae_gelu_ln_bwd: width %lld not in [1, %d]", (long long)W, MAXW);
+  VAE_REQUIRE(ld_dout >= W && ld_pre >= W && ld_dpre >= W, "vae_gelu_ln_bwd: leading dimension too small");
+  int blocks = (int)((B + 3) / 4);
+  if (blocks > 256) blocks = 256;
+  hipLaunchKernelGGL(gelu_ln_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dout, ld_dout, pre, ld_pre,
+                     mean, rstd, gamma, (int)B, (int)W, dpre, ld_dpre, dgamma, dbeta, dbias);
+  VAE_CHECK_LAUNCH("vae_gelu_ln_bwd");
+  return VAE_OK;
+}
+
+extern "C" int vae_reparam_kl_fwd(const float* heads, int64_t ld_heads, const float* eps, int64_t ld_eps, int64_t B,
+                                  int64_t L, float prior_mean, float prior_var, float* qv, float* z, int64_t ld_z,
+                                  float* kl, void* stream) {
+  VAE_REQUIRE(heads && eps && qv && z && kl, "vae_reparam_kl_fwd: null pointer");
+  VAE_REQUIRE(B > 0 && L > 0 && ld_heads >= L + 1 && ld_eps >= L && ld_z >= L, "vae_reparam_kl_fwd: bad shape");
+  VAE_REQUIRE(prior_var > 0.f, "vae_reparam_kl_fwd: prior variance must be positive");
+  hipLaunchKernelGGL(reparam_kl_fwd_kernel, dim3((unsigned)((B + 127) / 128)), dim3(128), 0, (hipStream_t)stream, heads,
+                     ld_heads, eps, ld_eps, (int)B, (int)L, prior_mean, prior_var, qv, z, ld_z, kl);
+  VAE_CHECK_LAUNCH("vae_reparam_kl_fwd");
+  return VAE_OK;
+}
+
+extern "C" int vae_reparam_kl_bwd(const float* dz, int64_t ld_dz, const float* g_kl, float g_kl_scalar,
+                                  const float* heads, int64_t ld_heads, const float* eps, int64_t ld_eps,
+                                  const float* qv, int64_t B, int64_t L, float prior_mean, float prior_var,
+                                  float* dheads, int64_t ld_dheads, void* stream) {
+  VAE_REQUIRE(dz && heads && eps && qv && dheads, "vae_reparam_kl_bwd: null pointer");
+  VAE_REQUIRE(B > 0 && L > 0 && ld_heads >= L + 1 && ld_eps >= L && ld_dz >= L && ld_dheads >= L + 1,
+              "vae_reparam_kl_bwd: bad shape");
+  hipLaunchKernelGGL(reparam_kl_bwd_kernel, dim3((unsigned)((B + 127) / 128)), dim3(128), 0, (hipStream_t)stream, dz,
+                     ld_dz, g_kl, g_kl_scalar, heads, ld_heads, eps, ld_eps, qv, (int)B, (int)L, prior_mean, prior_var,
+                     dheads, ld_dheads);
+  VAE_CHECK_LAUNCH("vae_reparam_kl_bwd");
+  return VAE_OK;
+}
+
+extern "C" int vae_colsum(const float* in, int64_t ld, int64_t M, int64_t N, float* out, void* stream) {
+  VAE_REQUIRE(in && out && M > 0 && N > 0 && ld >= N, "vae_colsum: bad arguments");
+  int row_blocks = (int)((M + 63) / 64);
+  if (row_blocks > 64) row_blocks = 64;
+  const int rows_per_block = (int)((M + row_blocks - 1) / row_blocks);
+  hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((N + 255) / 256), row_blocks), dim3(256), 0, (hipStream_t)stream, in,
+                     ld, (int)M, (int)N, rows_per_block, out);
+  VAE_CHECK_LAUNCH("vae_colsum");
+  return VAE_OK;
+}
+
+extern "C" int vae_elbo_reduce(const float* ll, const float* kl_z, const float* kl_l, int64_t B, float kl_weight,
+                               float gene_loss_coeff, float* out5, void* stream) {
+  VAE_REQUIRE(ll && kl_z && kl_l && out5 && B > 0, "vae_elbo_reduce: bad arguments");
+  hipLaunchKernelGGL(elbo_reduce_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, ll, kl_z, kl_l, (int)B, kl_weight,
+                     gene_loss_coeff, out5);
+  VAE_CHECK_LAUNCH("vae_elbo_reduce");
+  return VAE_OK;
+}

@@ -1,0 +1,239 @@
+"""The reference's nn.Module API (src/modules.py) on the HIP kernels.
+
+Constructor signatures, sub-module names (hence state_dict keys) and forward signatures are
+the reference's; the forwards run the GEMMs, GELU+LayerNorm, softmax/library scaling on the
+hand-written gfx950 kernels through vae_amd.autograd.  Tiny (B, latent) element-wise steps
+(softplus of the one variance column, the rsample affine) stay torch ops on the GPU.
+"""
+from __future__ import annotations
+
+from typing import Any, Dict, Optional
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from . import ops
+from .autograd import CountLinearFn, GeluLayerNormFn, LinearFn, SoftmaxRateFn
+from .functional import GradReverseLayer
+
+
+def reparameterize_gaussian(mu, var):
+    """Normal(mu, sqrt(var)).rsample() (modules.py:11-12): mu + eps*sqrt(var), eps drawn with
+    ``empty(shape).normal_()`` exactly as torch's rsample does (same generator consumption)."""
+    scale = var.sqrt()
+    shape = torch.broadcast_shapes(mu.shape, scale.shape)
+    eps = torch.empty(shape, dtype=mu.dtype, device=mu.device).normal_()
+    return mu + eps * scale
+
+
+def identity(x):
+    return x
+
+
+def one_hot(index, n_cat):
+    onehot = torch.zeros(index.size(0), n_cat, device=index.device)
+    onehot.scatter_(1, index.type(torch.long), 1)
+    return onehot.type(torch.float32)
+
+
+def hip_linear(lin: nn.Linear, x: torch.Tensor, precision: int = ops.FP32) -> torch.Tensor:
+    return LinearFn.apply(x, lin.weight, lin.bias, precision)
+
+
+class LinearWithMask(nn.Module):
+    """Masked linear layer of the pathways model (modules.py:25-42)."""
+
+    def __init__(self, n_input: int, n_output: int, mask: torch.Tensor):
+        super().__init__()
+        self.W = nn.parameter.Parameter(data=torch.randn(n_input, n_output), requires_grad=True)
+        self.b = nn.parameter.Parameter(data=torch.zeros((1, n_output), dtype=torch.float32), requires_grad=True)
+        self.mask = mask
+
+    def forward(self, x):
+        W = (self.W * self.mask.to(x.device)).t().contiguous()
+        return LinearFn.apply(x, W, self.b.view(-1), ops.FP32)
+
+
+class FCLayers(nn.Module):
+    """Per layer: Linear -> GELU(erf) -> LayerNorm(affine, eps 1e-5) -> Dropout (modules.py:74-132);
+    optional masked one-hot batch covariates concatenated to the input (:123-130)."""
+
+    def __init__(self, n_in: int, n_layers: int = 1, n_hidden: int = 128, dropout_rate: float = 0.1,
+                 batch_properties: Optional[Dict[str, Any]] = None, layer_norm: bool = True):
+        super().__init__()
+        self.batch_dims = 0 if batch_properties is None else [
+            len(batch_properties[k]["values"]) for k in batch_properties.keys()]
+        self.act = nn.GELU()
+        self.layer_norm = layer_norm
+        self.n_layers = n_layers
+        self.precision = ops.FP32
+        layers_dim = [n_in + int(np.sum(self.batch_dims))] + n_layers * [n_hidden]
+        layers = []
+        for n in range(n_layers):
+            layers.append(nn.Linear(layers_dim[n], layers_dim[n + 1]))
+            layers.append(nn.GELU())
+            if layer_norm:
+                layers.append(nn.LayerNorm(n_hidden, elementwise_affine=True))
+            layers.append(nn.Dropout(p=float(dropout_rate)))
+        self.fc_layers = nn.Sequential(*layers)
+
+    def _run(self, x: torch.Tensor, count_input: bool) -> torch.Tensor:
+        mods = list(self.fc_layers)
+        per = 4 if self.layer_norm else 3
+        for n in range(self.n_layers):
+            lin = mods[per * n]
+            if n == 0 and count_input:
+                pre = CountLinearFn.apply(x, lin.weight, lin.bias, self.precision)
+            else:
+                pre = LinearFn.apply(x, lin.weight, lin.bias, self.precision)
+            if self.layer_norm:
+                ln = mods[per * n + 2]
+                x = GeluLayerNormFn.apply(pre, ln.weight, ln.bias)
+            else:
+                x = F.gelu(pre)
+            x = mods[per * n + per - 1](x)  # Dropout (identity in eval or at p = 0)
+        return x
+
+    def forward(self, x: torch.Tensor, batch_vals: torch.Tensor, batch_mask: torch.Tensor, _count_input: bool = False):
+        if np.sum(self.batch_dims) > 0:
+            if _count_input:
+                raise NotImplementedError("vae_amd: batch covariates on the count input are not on the HIP path yet")
+            batch_vals[batch_vals < 0] = 0
+            batch_vars = []
+            for n in range(len(self.batch_dims)):
+                b = F.one_hot(batch_vals[:, n], num_classes=self.batch_dims[n])
+                batch_vars.append(b * batch_mask[:, n: n + 1])
+            x = torch.cat((x, *batch_vars), dim=-1)
+        return self._run(x, _count_input)
+
+
+class GeneDropout(nn.Module):
+    """Expression-frequency-weighted input dropout (modules.py:190-209); identity when not
+    training or p < 1e-6 (all benchmark configurations)."""
+
+    def __init__(self, p: float = 0.5, alpha: float = 0.95):
+        super().__init__()
+        self.p = p
+        self.alpha = alpha
+        self.running_non_zero_means = 0.0
+
+    def forward(self, input: torch.Tensor) -> torch.Tensor:
+        if not self.training or self.p < 1e-6:
+            return input
+        non_zero_means = (input > 0).to(torch.float32).mean(dim=0, keepdim=True)
+        self.running_non_zero_means = self.alpha * self.running_non_zero_means + (1 - self.alpha) * non_zero_means
+        p = self.p * self.running_non_zero_means / self.running_non_zero_means.mean()
+        p = torch.clip(p, 0.0, 0.9)
+        rand = torch.rand(*input.size()).to(device=input.device)
+        mask = (rand < p).to(torch.float32)
+        return (input * mask) / p.mean()
+
+
+class Encoder(nn.Module):
+    """genes -> latent encoder (modules.py:213-271): x/mean-1 -> FCLayers -> mean / ONE shared
+    variance head -> softplus + 1e-4 -> reparameterised sample."""
+
+    def __init__(self, n_input: int, n_output: int, batch_properties: Optional[Dict[str, Any]] = None, n_layers: int = 1,
+                 n_hidden: int = 128, dropout_rate: float = 0.1, input_dropout_rate: float = 0.0,
+                 distribution: str = "normal", shared_variance: bool = True):
+        super().__init__()
+        self.distribution = distribution
+        self.encoder = FCLayers(n_in=n_input, n_layers=n_layers, n_hidden=n_hidden, dropout_rate=dropout_rate,
+                                batch_properties=batch_properties)
+        self.mean_encoder = nn.Linear(n_hidden, n_output)
+        self.var_encoder = nn.Linear(n_hidden, 1) if shared_variance else nn.Linear(n_hidden, n_output)
+        self.ln = nn.LayerNorm(n_input, elementwise_affine=False)  # parameter-free; unused on the live path
+        self.z_transformation = nn.Softmax(dim=-1) if distribution == "ln" else identity
+        self.drop = GeneDropout(p=input_dropout_rate)
+        self.softplus = nn.Softplus()
+
+    def forward(self, x: torch.Tensor, batch_labels: torch.Tensor, batch_mask: torch.Tensor):
+        x = self.drop(x)
+        q = self.encoder(x, batch_labels, batch_mask, _count_input=True)  # normalisation fused into the GEMM
+        q_m = hip_linear(self.mean_encoder, q, self.encoder.precision)
+        q_v = self.softplus(hip_linear(self.var_encoder, q, self.encoder.precision)) + 1e-4
+        latent = self.z_transformation(reparameterize_gaussian(q_m, q_v))
+        return q_m, q_v, latent
+
+
+class GroupedEncoder(nn.Module):
+    """One Encoder per cell property, outputs concatenated (modules.py:134-188)."""
+
+    def __init__(self, n_input: int, n_latent: int, cell_properties: Optional[Dict[str, Any]] = None,
+                 batch_properties: Optional[Dict[str, Any]] = None, n_layers: int = 1, n_hidden: int = 128,
+                 dropout_rate: float = 0.1, input_dropout_rate: float = 0.0, latent_distribution: str = "normal"):
+        super().__init__()
+        self.z_enc = nn.ModuleDict()
+        self.cell_properties = cell_properties
+        self.cell_predict = nn.ModuleDict()
+        for k in cell_properties.keys():
+            self.z_enc[k] = Encoder(n_input, n_latent, batch_properties=batch_properties, n_layers=n_layers,
+                                    n_hidden=n_hidden, dropout_rate=dropout_rate,
+                                    input_dropout_rate=input_dropout_rate, distribution=latent_distribution)
+
+    def forward(self, x: torch.Tensor, batch_labels: torch.Tensor, batch_mask: torch.Tensor):
+        q_m, q_v, latent = [], [], []
+        for k in self.cell_properties.keys():
+            a, b, c = self.z_enc[k](x, batch_labels, batch_mask)
+            q_m.append(a); q_v.append(b); latent.append(c)
+        return torch.cat(q_m, dim=-1), torch.cat(q_v, dim=-1), torch.cat(latent, dim=-1)
+
+
+class CellDecoder(nn.Module):
+    """Cell-property heads on the latent (modules.py:274-324): gradient reversal for keys in
+    ``grad_reverse_dict``, ``detach`` for stop_grad properties.  Tiny (B x L x n_targets)."""
+
+    def __init__(self, latent_dim: int, cell_properties: Dict[str, Any], grad_reverse_dict: Optional[Dict] = None,
+                 use_hidden_layer: bool = True):
+        super().__init__()
+        self.latent_dim = latent_dim
+        self.cell_properties = cell_properties
+        self.cell_mlp = nn.ModuleDict()
+        self.grad_reverse_dict = grad_reverse_dict
+        if grad_reverse_dict is not None:
+            self.grad_reverse = nn.ModuleDict()
+            for k, v in grad_reverse_dict.items():
+                self.grad_reverse[k] = GradReverseLayer(v)
+        for k, cell_prop in cell_properties.items():
+            n_targets = 1 if not cell_prop["discrete"] else len(cell_prop["values"])
+            if use_hidden_layer:
+                self.cell_mlp[k] = nn.Sequential(nn.Linear(latent_dim, 2 * latent_dim), nn.GELU(),
+                                                 nn.Linear(2 * latent_dim, n_targets))
+            else:
+                self.cell_mlp[k] = nn.Linear(latent_dim, n_targets, bias=True)
+
+    def forward(self, latent: torch.Tensor):
+        output = {}
+        for n, (k, cell_prop) in enumerate(self.cell_properties.items()):
+            if k in self.grad_reverse_dict.keys():  # raises on None exactly as the reference does (:317)
+                x = self.grad_reverse[k](latent)
+            else:
+                x = latent.detach() if cell_prop["stop_grad"] else latent
+            output[k] = self.cell_mlp[k](x)
+        return output
+
+
+class DecoderSCVI(nn.Module):
+    """latent -> genes decoder (modules.py:328-406): FCLayers, then the px_scale (softmax over
+    genes), px_dropout and (gene-cell only) px_r heads; px_rate = exp(library) * px_scale."""
+
+    def __init__(self, n_input: int, n_output: int, n_layers: int = 1, n_hidden: int = 128, dropout_rate: float = 0.1,
+                 batch_properties: Optional[Dict[str, Any]] = None):
+        super().__init__()
+        self.px_decoder = FCLayers(n_in=n_input, n_layers=n_layers, n_hidden=n_hidden, dropout_rate=dropout_rate,
+                                   batch_properties=batch_properties)
+        self.px_scale_decoder = nn.Sequential(nn.Linear(n_hidden, n_output), nn.Softmax(dim=-1))
+        self.px_r_decoder = nn.Linear(n_hidden, n_output)
+        self.px_dropout_decoder = nn.Linear(n_hidden, n_output)
+
+    def forward(self, dispersion: str, z: torch.Tensor, library: torch.Tensor, batch_labels: torch.Tensor,
+                batch_mask: torch.Tensor):
+        P = self.px_decoder.precision
+        px = self.px_decoder(z, batch_labels, batch_mask)
+        logits = hip_linear(self.px_scale_decoder[0], px, P)
+        px_scale, px_rate = SoftmaxRateFn.apply(logits, library)
+        px_dropout = hip_linear(self.px_dropout_decoder, px, P)
+        px_r = hip_linear(self.px_r_decoder, px, P) if dispersion == "gene-cell" else None
+        return px_scale, px_r, px_rate, px_dropout

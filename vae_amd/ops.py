@@ -1,0 +1,310 @@
+"""Tensor-level wrappers over the C-ABI HIP kernels (include/vae_amd.h).
+
+torch is used for device memory and the current stream only; every computation below is a
+hand-written gfx950 kernel.  All tensors must be fp32 CUDA (ROCm) tensors whose last
+dimension is contiguous; there is no CPU fallback -- CPU tensors raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+
+NT, NN, TN = 0, 1, 2
+FP32, BF16 = 0, 1
+
+_workspaces = {}
+
+
+def _stream() -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t: Optional[torch.Tensor]) -> C.c_void_p:
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _chk2d(t: torch.Tensor, name: str) -> None:
+    if not t.is_cuda:
+        raise RuntimeError(f"vae_amd.ops: {name} must live on the GPU (no CPU fallback)")
+    if t.dtype != torch.float32:
+        raise TypeError(f"vae_amd.ops: {name} must be float32, got {t.dtype}")
+    if t.dim() != 2 or t.stride(1) != 1:
+        raise ValueError(f"vae_amd.ops: {name} must be 2-D with a contiguous last dim, got {tuple(t.shape)} / {t.stride()}")
+
+
+def _chk1d(t: Optional[torch.Tensor], n: int, name: str) -> None:
+    if t is None:
+        return
+    if not t.is_cuda or t.dtype != torch.float32 or t.numel() != n or not t.is_contiguous():
+        raise ValueError(f"vae_amd.ops: {name} must be a contiguous float32 GPU tensor of {n} elements")
+
+
+def _ld(t: torch.Tensor) -> int:
+    return t.stride(0) if t.shape[0] > 1 else max(t.shape[1], t.stride(0))
+
+
+def workspace(nbytes: int, device) -> torch.Tensor:
+    """Per-device scratch for split-K slabs, grown on demand (torch = allocator only)."""
+    key = torch.device(device).index
+    ws = _workspaces.get(key)
+    if ws is None or ws.numel() * 4 < nbytes:
+        ws = torch.empty(max(nbytes // 4 + 4, 1 << 20), dtype=torch.float32, device=device)
+        _workspaces[key] = ws
+    return ws
+
+
+def gemm(layout: int, a: torch.Tensor, b: torch.Tensor, *, out: Optional[torch.Tensor] = None,
+         bias: Optional[torch.Tensor] = None, x_mean: Optional[torch.Tensor] = None,
+         accumulate: bool = False, precision: int = FP32) -> torch.Tensor:
+    """NT: a(M,K) b(N,K) | NN: a(M,K) b(K,N) | TN: a(K,M) b(K,N)  ->  out(M,N).
+
+    ``x_mean`` normalises the count operand on the fly (a in NT, b in TN): x/mean - 1.
+    """
+    lib = _lib.load()
+    _chk2d(a, "a")
+    _chk2d(b, "b")
+    if layout == NT:
+        M, K = a.shape
+        N, K2 = b.shape
+    elif layout == NN:
+        M, K = a.shape
+        K2, N = b.shape
+    elif layout == TN:
+        K, M = a.shape
+        K2, N = b.shape
+    else:
+        raise ValueError("layout")
+    if K != K2:
+        raise ValueError(f"vae_amd.ops.gemm: contraction mismatch {tuple(a.shape)} vs {tuple(b.shape)} (layout {layout})")
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.float32, device=a.device)
+    _chk2d(out, "out")
+    if tuple(out.shape) != (M, N):
+        raise ValueError(f"vae_amd.ops.gemm: out must be {(M, N)}, got {tuple(out.shape)}")
+    _chk1d(bias, N, "bias")
+    if x_mean is not None:
+        _chk1d(x_mean, M if layout == NT else K, "x_mean")
+    nbytes = lib.vae_gemm_workspace_bytes(M, N, K)
+    ws = workspace(nbytes, a.device) if nbytes else None
+    rc = lib.vae_gemm(layout, precision, M, N, K, _p(a), _ld(a), _p(b), _ld(b), _p(out), _ld(out), _p(bias), _p(x_mean),
+                      int(accumulate), _p(ws), nbytes, _stream())
+    _lib.check(rc, "gemm")
+    return out
+
+
+def row_mean(x: torch.Tensor) -> torch.Tensor:
+    lib = _lib.load()
+    _chk2d(x, "x")
+    out = torch.empty(x.shape[0], dtype=torch.float32, device=x.device)
+    _lib.check(lib.vae_row_mean(_p(x), _ld(x), x.shape[0], x.shape[1], _p(out), _stream()), "row_mean")
+    return out
+
+
+def gelu_ln_fwd(pre: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor,
+                out: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    lib = _lib.load()
+    _chk2d(pre, "pre")
+    B, W = pre.shape
+    _chk1d(gamma, W, "gamma")
+    _chk1d(beta, W, "beta")
+    if out is None:
+        out = torch.empty(B, W, dtype=torch.float32, device=pre.device)
+    _chk2d(out, "out")
+    mean = torch.empty(B, dtype=torch.float32, device=pre.device)
+    rstd = torch.empty(B, dtype=torch.float32, device=pre.device)
+    _lib.check(lib.vae_gelu_ln_fwd(_p(pre), _ld(pre), _p(gamma), _p(beta), B, W, _p(out), _ld(out), _p(mean), _p(rstd),
+                                   _stream()), "gelu_ln_fwd")
+    return out, mean, rstd
+
+
+def gelu_ln_bwd(dout: torch.Tensor, pre: torch.Tensor, mean: torch.Tensor, rstd: torch.Tensor, gamma: torch.Tensor,
+                dgamma: Optional[torch.Tensor], dbeta: Optional[torch.Tensor], dbias: Optional[torch.Tensor],
+                dpre: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """dgamma / dbeta / dbias are ACCUMULATED into (float atomics): zero them beforehand."""
+    lib = _lib.load()
+    _chk2d(dout, "dout")
+    _chk2d(pre, "pre")
+    B, W = pre.shape
+    if tuple(dout.shape) != (B, W):
+        raise ValueError("vae_amd.ops.gelu_ln_bwd: dout shape mismatch")
+    _chk1d(mean, B, "mean"); _chk1d(rstd, B, "rstd"); _chk1d(gamma, W, "gamma")
+    _chk1d(dgamma, W, "dgamma"); _chk1d(dbeta, W, "dbeta"); _chk1d(dbias, W, "dbias")
+    if dpre is None:
+        dpre = torch.empty(B, W, dtype=torch.float32, device=pre.device)
+    _chk2d(dpre, "dpre")
+    _lib.check(lib.vae_gelu_ln_bwd(_p(dout), _ld(dout), _p(pre), _ld(pre), _p(mean), _p(rstd), _p(gamma), B, W, _p(dpre),
+                                   _ld(dpre), _p(dgamma), _p(dbeta), _p(dbias), _stream()), "gelu_ln_bwd")
+    return dpre
+
+
+def reparam_kl_fwd(heads: torch.Tensor, eps: torch.Tensor, prior_mean: float, prior_var: float):
+    """heads (B, L+1) = [q_m | variance pre-activation]; eps (B, L) -> q_v (B,), z (B,L), kl (B,)."""
+    lib = _lib.load()
+    _chk2d(heads, "heads")
+    _chk2d(eps, "eps")
+    B, L = eps.shape
+    if heads.shape != (B, L + 1):
+        raise ValueError(f"vae_amd.ops.reparam_kl_fwd: heads must be {(B, L + 1)}, got {tuple(heads.shape)}")
+    qv = torch.empty(B, dtype=torch.float32, device=heads.device)
+    z = torch.empty(B, L, dtype=torch.float32, device=heads.device)
+    kl = torch.empty(B, dtype=torch.float32, device=heads.device)
+    _lib.check(lib.vae_reparam_kl_fwd(_p(heads), _ld(heads), _p(eps), _ld(eps), B, L, float(prior_mean), float(prior_var),
+                                      _p(qv), _p(z), _ld(z), _p(kl), _stream()), "reparam_kl_fwd")
+    return qv, z, kl
+
+
+def reparam_kl_bwd(dz: torch.Tensor, g_kl: Optional[torch.Tensor], g_kl_scalar: float, heads: torch.Tensor,
+                   eps: torch.Tensor, qv: torch.Tensor, prior_mean: float, prior_var: float) -> torch.Tensor:
+    lib = _lib.load()
+    _chk2d(dz, "dz"); _chk2d(heads, "heads"); _chk2d(eps, "eps")
+    B, L = eps.shape
+    if dz.shape != (B, L) or heads.shape != (B, L + 1):
+        raise ValueError("vae_amd.ops.reparam_kl_bwd: shape mismatch")
+    _chk1d(qv, B, "qv"); _chk1d(g_kl, B, "g_kl")
+    dheads = torch.empty(B, L + 1, dtype=torch.float32, device=heads.device)
+    _lib.check(lib.vae_reparam_kl_bwd(_p(dz), _ld(dz), _p(g_kl), float(g_kl_scalar), _p(heads), _ld(heads), _p(eps),
+                                      _ld(eps), _p(qv), B, L, float(prior_mean), float(prior_var), _p(dheads),
+                                      _ld(dheads), _stream()), "reparam_kl_bwd")
+    return dheads
+
+
+def colsum_into(inp: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+    """out[n] += sum_m inp[m, n] (float atomics; zero ``out`` beforehand for a plain sum)."""
+    lib = _lib.load()
+    _chk2d(inp, "inp")
+    _chk1d(out, inp.shape[1], "out")
+    _lib.check(lib.vae_colsum(_p(inp), _ld(inp), inp.shape[0], inp.shape[1], _p(out), _stream()), "colsum")
+    return out
+
+
+def elbo_reduce(ll: torch.Tensor, kl_z: torch.Tensor, kl_l: torch.Tensor, kl_weight: float, coeff: float) -> torch.Tensor:
+    """-> [mean(recon), mean(kl_z), mean(kl_l), gene_loss, coeff*gene_loss]."""
+    lib = _lib.load()
+    B = ll.numel()
+    _chk1d(ll, B, "ll"); _chk1d(kl_z, B, "kl_z"); _chk1d(kl_l, B, "kl_l")
+    out = torch.empty(5, dtype=torch.float32, device=ll.device)
+    _lib.check(lib.vae_elbo_reduce(_p(ll), _p(kl_z), _p(kl_l), B, float(kl_weight), float(coeff), _p(out), _stream()),
+               "elbo_reduce")
+    return out
+
+
+def gene_table(px_r: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """(4, G): theta = exp(px_r), log(theta + 1e-8), lgamma(theta), digamma(theta)."""
+    lib = _lib.load()
+    G = px_r.numel()
+    _chk1d(px_r, G, "px_r")
+    if out is None:
+        out = torch.empty(4, G, dtype=torch.float32, device=px_r.device)
+    _lib.check(lib.vae_gene_table(_p(px_r), G, _p(out), _stream()), "gene_table")
+    return out
+
+
+def nbzinb_fwd(zinb: bool, logit_scale: torch.Tensor, logit_dropout: Optional[torch.Tensor], x: torch.Tensor,
+               library: torch.Tensor, table: torch.Tensor):
+    """Fused softmax + library scale + NB/ZINB log-likelihood + row sum.
+
+    -> (ll (B,), rowmax (B,), rowsum (B,), S (B,)); recon = -ll.  The last three are what
+    ``nbzinb_bwd`` needs."""
+    lib = _lib.load()
+    _chk2d(logit_scale, "logit_scale"); _chk2d(x, "x")
+    B, G = x.shape
+    if logit_scale.shape != (B, G):
+        raise ValueError("vae_amd.ops.nbzinb_fwd: logit_scale shape mismatch")
+    if zinb:
+        _chk2d(logit_dropout, "logit_dropout")
+        if logit_dropout.shape != (B, G):
+            raise ValueError("vae_amd.ops.nbzinb_fwd: logit_dropout shape mismatch")
+    _chk1d(library, B, "library")
+    if table.shape != (4, G) or not table.is_contiguous():
+        raise ValueError("vae_amd.ops.nbzinb_fwd: table must be the (4, G) gene table")
+    o = torch.empty(4, B, dtype=torch.float32, device=x.device)
+    _lib.check(lib.vae_nbzinb_fwd(int(zinb), _p(logit_scale), _ld(logit_scale), _p(logit_dropout if zinb else None),
+                                  _ld(logit_dropout) if zinb else 0, _p(x), _ld(x), _p(library), _p(table), B, G,
+                                  _p(o[0]), _p(o[1]), _p(o[2]), _p(o[3]), _stream()), "nbzinb_fwd")
+    return o[0], o[1], o[2], o[3]
+
+
+def nbzinb_bwd(zinb: bool, logit_scale: torch.Tensor, logit_dropout: Optional[torch.Tensor], x: torch.Tensor,
+               library: torch.Tensor, table: torch.Tensor, rowmax, rowsum, S, g_ll: Optional[torch.Tensor],
+               g_scalar: float, dlogit_scale: torch.Tensor, dlogit_dropout: Optional[torch.Tensor],
+               dlibrary: Optional[torch.Tensor], dpx_r: torch.Tensor, dbias_scale: Optional[torch.Tensor],
+               dbias_dropout: Optional[torch.Tensor]) -> None:
+    """Gradient of sum_b g_scalar*g_ll[b]*ll[b].  dlogit_* may alias logit_* (in place).
+    dpx_r / dbias_* are ACCUMULATED into (float atomics)."""
+    lib = _lib.load()
+    B, G = x.shape
+    _chk2d(dlogit_scale, "dlogit_scale")
+    if zinb:
+        _chk2d(dlogit_dropout, "dlogit_dropout")
+    _chk1d(g_ll, B, "g_ll"); _chk1d(dlibrary, B, "dlibrary"); _chk1d(dpx_r, G, "dpx_r")
+    _chk1d(dbias_scale, G, "dbias_scale"); _chk1d(dbias_dropout, G, "dbias_dropout")
+    _lib.check(lib.vae_nbzinb_bwd(int(zinb), _p(logit_scale), _ld(logit_scale), _p(logit_dropout if zinb else None),
+                                  _ld(logit_dropout) if zinb else 0, _p(x), _ld(x), _p(library), _p(table), _p(rowmax),
+                                  _p(rowsum), _p(S), _p(g_ll), float(g_scalar), B, G, _p(dlogit_scale), _ld(dlogit_scale),
+                                  _p(dlogit_dropout if zinb else None), _ld(dlogit_dropout) if zinb else 0, _p(dlibrary),
+                                  _p(dpx_r), _p(dbias_scale), _p(dbias_dropout if zinb else None), _stream()),
+               "nbzinb_bwd")
+
+
+def loglik_elem_fwd(zinb: bool, x, mu, theta, pi) -> torch.Tensor:
+    """Element-wise log_nb_positive / log_zinb_positive; theta is (G,) or (B,G)."""
+    lib = _lib.load()
+    _chk2d(x, "x"); _chk2d(mu, "mu")
+    B, G = x.shape
+    th2 = theta if theta.dim() == 2 else theta.view(1, -1)
+    _chk2d(th2, "theta")
+    ld_th = 0 if th2.shape[0] == 1 and B > 1 or theta.dim() == 1 else _ld(th2)
+    if zinb:
+        _chk2d(pi, "pi")
+    out = torch.empty(B, G, dtype=torch.float32, device=x.device)
+    _lib.check(lib.vae_loglik_elem_fwd(int(zinb), _p(x), _ld(x), _p(mu), _ld(mu), _p(th2), ld_th, _p(pi if zinb else None),
+                                       _ld(pi) if zinb else 0, B, G, _p(out), G, _stream()), "loglik_elem_fwd")
+    return out
+
+
+def loglik_elem_bwd(zinb: bool, gout, x, mu, theta, pi):
+    """-> (dmu, dtheta_full (B,G), dpi|None): gradients of sum(gout * loglik)."""
+    lib = _lib.load()
+    B, G = x.shape
+    _chk2d(gout, "gout")
+    th2 = theta if theta.dim() == 2 else theta.view(1, -1)
+    ld_th = 0 if th2.shape[0] == 1 and B > 1 or theta.dim() == 1 else _ld(th2)
+    dmu = torch.empty(B, G, dtype=torch.float32, device=x.device)
+    dth = torch.empty(B, G, dtype=torch.float32, device=x.device)
+    dpi = torch.empty(B, G, dtype=torch.float32, device=x.device) if zinb else None
+    _lib.check(lib.vae_loglik_elem_bwd(int(zinb), _p(gout), _ld(gout), _p(x), _ld(x), _p(mu), _ld(mu), _p(th2), ld_th,
+                                       _p(pi if zinb else None), _ld(pi) if zinb else 0, B, G, _p(dmu), _p(dth), _p(dpi),
+                                       _stream()), "loglik_elem_bwd")
+    return dmu, dth, dpi
+
+
+def softmax_rate_fwd(logit_scale: torch.Tensor, library: torch.Tensor):
+    """-> (px_scale, px_rate) = (softmax(logits), exp(library) * softmax(logits)), both (B, G)."""
+    lib = _lib.load()
+    _chk2d(logit_scale, "logit_scale")
+    B, G = logit_scale.shape
+    _chk1d(library, B, "library")
+    ps = torch.empty(B, G, dtype=torch.float32, device=logit_scale.device)
+    pr = torch.empty(B, G, dtype=torch.float32, device=logit_scale.device)
+    _lib.check(lib.vae_softmax_rate_fwd(_p(logit_scale), _ld(logit_scale), _p(library), B, G, _p(ps), _p(pr), _stream()),
+               "softmax_rate_fwd")
+    return ps, pr
+
+
+def softmax_rate_bwd(px_scale: torch.Tensor, library: torch.Tensor, d_scale: Optional[torch.Tensor],
+                     d_rate: Optional[torch.Tensor]):
+    """-> (dlogits (B,G), dlibrary (B,))."""
+    lib = _lib.load()
+    B, G = px_scale.shape
+    for t, n in ((d_scale, "d_scale"), (d_rate, "d_rate")):
+        if t is not None and (t.shape != (B, G) or not t.is_contiguous() or t.dtype != torch.float32):
+            raise ValueError(f"vae_amd.ops.softmax_rate_bwd: {n} must be contiguous float32 {(B, G)}")
+    dl = torch.empty(B, G, dtype=torch.float32, device=px_scale.device)
+    dlib = torch.empty(B, dtype=torch.float32, device=px_scale.device)
+    _lib.check(lib.vae_softmax_rate_bwd(_p(px_scale), _p(library), _p(d_scale), _p(d_rate), B, G, _p(dl), G, _p(dlib),
+                                        _stream()), "softmax_rate_bwd")
+    return dl, dlib

@@ -1,0 +1,226 @@
+"""Training task with the reference's LitVAE interface (src/task.py:29-565), without Lightning.
+
+``training_step(batch, batch_idx)`` follows task.py:453-502 through the module API (autograd
+over the HIP ops) and returns the loss; ``training_step_fused(batch)`` is the production fast
+path: one fused fwd+bwd pass (vae_amd.step.ElboStep) that leaves gradients in the arena.
+"""
+from __future__ import annotations
+
+from typing import Any, Dict, Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+from torch.distributions import Normal, kl_divergence as kl
+from torch.optim.lr_scheduler import LambdaLR
+
+from . import ops
+from .arena import ParamArena
+from .distributions import NegativeBinomial, Poisson, ZeroInflatedNegativeBinomial
+from .step import ElboStep
+
+
+def cell_loss(cell_pred: Dict[str, torch.Tensor], cell_properties: Dict[str, Any], cell_prop_vals: torch.Tensor,
+              cell_mask: torch.Tensor, weights=1.0) -> torch.Tensor:
+    """LitVAE._cell_loss without GroupDRO (task.py:419-451): masked cross-entropy (ignore_index
+    -100) / MSE per property, each averaged over ALL cells of the batch."""
+    total = 0.0
+    for n, (k, prop) in enumerate(cell_properties.items()):
+        if prop["discrete"]:
+            per = nn.functional.cross_entropy(cell_pred[k], cell_prop_vals[:, n].to(torch.int64), reduction="none",
+                                              ignore_index=-100)
+        else:
+            per = (torch.squeeze(cell_pred[k]) - cell_prop_vals[:, n]) ** 2
+        total = total + (weights * per * cell_mask[:, n]).mean()
+    return total
+
+
+class WarmupConstantAndDecaySchedule(LambdaLR):
+    """sqrt(w) * min((s+1)^-0.5, (s+1) * w^-1.5) (task.py:662-676)."""
+
+    def __init__(self, optimizer, warmup_steps, last_epoch=-1):
+        self.warmup_steps = warmup_steps
+        self.alpha = np.sqrt(warmup_steps)
+        super().__init__(optimizer, self.lr_lambda, last_epoch=last_epoch)
+
+    def lr_lambda(self, step):
+        return self.alpha * np.minimum((step + 1) ** (-0.5), (step + 1) * (self.warmup_steps ** -1.5))
+
+
+class LitVAE(nn.Module):
+    def __init__(
+        self,
+        network,
+        cell_properties: Optional[Dict[str, Any]] = None,
+        batch_properties: Optional[Dict[str, Any]] = None,
+        balance_classes: bool = False,
+        dispersion: str = "gene",
+        reconstruction_loss: str = "zinb",
+        latent_distribution: str = "normal",
+        n_epochs_kl_warmup: Optional[int] = 20,
+        learning_rate: float = 0.0005,
+        warmup_steps: float = 2000.0,
+        weight_decay: float = 0.1,
+        l1_lambda: float = 0.0,
+        gene_loss_coeff: float = 5e-4,
+        save_gene_vals: bool = False,
+        library_mean: Optional[float] = None,
+        library_var: Optional[float] = None,
+        subject_batch_size: int = 1,
+        use_gdro: bool = False,
+        precision: int = ops.FP32,
+    ):
+        super().__init__()
+        self.network = network
+        self.cell_properties = cell_properties
+        self.batch_properties = batch_properties
+        self.balance_classes = balance_classes
+        self.dispersion = dispersion
+        self.reconstruction_loss = reconstruction_loss
+        self.latent_distribution = latent_distribution
+        self.n_epochs_kl_warmup = n_epochs_kl_warmup
+        self.learning_rate = learning_rate
+        self.warmup_steps = warmup_steps
+        self.weight_decay = weight_decay
+        self.l1_lambda = l1_lambda
+        self.gene_loss_coeff = gene_loss_coeff
+        self.save_gene_vals = save_gene_vals
+        self.library_mean = library_mean
+        self.library_var = library_var
+        self.subject_batch_size = subject_batch_size
+        self.use_gdro = use_gdro
+        self.precision = precision
+        self.current_epoch = 0
+        self.train_step = 0
+        self.logged: Dict[str, float] = {}
+        self._arena: Optional[ParamArena] = None
+        self._fused: Optional[ElboStep] = None
+        if use_gdro:
+            raise NotImplementedError("vae_amd: GroupDRO re-weighting (off in the shipped config) is not wired in")
+
+    # -- bookkeeping the reference delegates to Lightning ---------------------------------
+    def log(self, name, value, **_):
+        self.logged[name] = value
+
+    @property
+    def kl_weight(self):
+        if self.n_epochs_kl_warmup is not None:
+            return float(np.clip((1 + self.current_epoch) / self.n_epochs_kl_warmup, 0.0, 1.0))
+        return 1.0
+
+    def library_stats(self, gene_vals):
+        """Prior of the library-size KL (task.py:222-233)."""
+        if self.library_mean is None or self.library_var is None:
+            lib = torch.log(gene_vals.sum(dim=1))
+            return lib.mean(), torch.clip(lib.var(), 0.1, 1e3)
+        return (torch.from_numpy(np.array(self.library_mean, dtype=np.float32)),
+                torch.from_numpy(np.array(self.library_var, dtype=np.float32)))
+
+    # -- module-API path (autograd over HIP ops) --------------------------------------------
+    def get_reconstruction_loss(self, x, px_rate, px_r, px_dropout, **kwargs) -> torch.Tensor:
+        if self.reconstruction_loss == "zinb":
+            return -ZeroInflatedNegativeBinomial(mu=px_rate, theta=px_r, zi_logits=px_dropout).log_prob(x).sum(dim=-1)
+        if self.reconstruction_loss == "nb":
+            return -NegativeBinomial(mu=px_rate, theta=px_r).log_prob(x).sum(dim=-1)
+        if self.reconstruction_loss == "poisson":
+            return -Poisson(px_rate).log_prob(x).sum(dim=-1)
+        raise ValueError(f"unknown reconstruction_loss {self.reconstruction_loss!r}")
+
+    def gene_loss(self, x, qz_m, qz_v, ql_m, ql_v, local_l_mean, local_l_var, px_rate, px_r, px_dropout,
+                  training: bool = True):
+        kl_z = kl(Normal(qz_m, torch.sqrt(qz_v)), Normal(torch.zeros_like(qz_m), torch.ones_like(qz_v))).sum(dim=1)
+        local_l_mean = torch.as_tensor(local_l_mean, dtype=ql_m.dtype, device=ql_m.device)
+        local_l_var = torch.as_tensor(local_l_var, dtype=ql_m.dtype, device=ql_m.device)
+        kl_l = kl(Normal(ql_m, torch.sqrt(ql_v)), Normal(local_l_mean, torch.sqrt(local_l_var))).sum(dim=1)
+        recon_loss = self.get_reconstruction_loss(x, px_rate, px_r, px_dropout)
+        loss = recon_loss.mean() + self.kl_weight * (kl_l + kl_z).mean()
+        suffix = "" if training else "_val"
+        self.log("recon_loss" + suffix, recon_loss.mean())
+        self.log("kl_z" + suffix, kl_z.mean())
+        return loss, kl_z
+
+    def _cell_loss(self, cell_pred, cell_prop_vals, cell_mask, group_idx):
+        return cell_loss(cell_pred, self.cell_properties, cell_prop_vals, cell_mask)
+
+    def training_step(self, batch, batch_idx):
+        self.train_step += 1
+        gene_vals, cell_prop_vals, cell_mask, batch_labels, batch_mask, _, group_idx, _ = batch
+        net = self.network
+        qz_m, qz_v, z = net.z_encoder(gene_vals, batch_labels, batch_mask)
+        ql_m, ql_v, library = net.l_encoder(gene_vals, batch_labels, batch_mask)
+        px_scale, px_r, px_rate, px_dropout = net.decoder(self.dispersion, z, library, batch_labels, batch_mask)
+        if self.cell_properties is not None:
+            c_loss = self._cell_loss(net.cell_decoder(z), cell_prop_vals, cell_mask, group_idx)
+        else:
+            c_loss = 0.0
+        if self.dispersion == "gene":
+            px_r = net.px_r
+        elif self.dispersion != "gene-cell":
+            raise NotImplementedError(f"dispersion {self.dispersion!r}: dead code in the reference (task.py:475-480)")
+        px_r = torch.exp(px_r)
+        l_mean, l_var = self.library_stats(gene_vals)
+        g_loss, kl_z = self.gene_loss(gene_vals, qz_m, qz_v, ql_m, ql_v, l_mean, l_var, px_rate, px_r, px_dropout)
+        loss = self.gene_loss_coeff * g_loss + c_loss
+        if self.l1_lambda > 0:
+            l1 = sum(torch.norm(p, p=1) for n, p in net.named_parameters() if "z_encoder" in n and "bias" not in n)
+            loss = loss + self.l1_lambda * l1
+        self.log("gene_loss", g_loss)
+        self.log("cell_loss", c_loss)
+        self.log("kl_weight", self.kl_weight)
+        return loss
+
+    # -- fused fast path ------------------------------------------------------------------------
+    def attach_arena(self, device="cuda") -> ParamArena:
+        """Re-home every parameter of the network into the flat arena (data and .grad become
+        views), so the fused step, the module-API path, the optimiser and the gradient
+        all-reduce share one storage."""
+        net = self.network
+        if net.dispersion != "gene" or net.grouped_encoder or self.batch_properties:
+            raise NotImplementedError("fused step: dispersion 'gene', single encoder, no batch covariates")
+        sd = {k: v for k, v in net.named_parameters()}
+        arena = ParamArena(sd, net.n_layers, self.reconstruction_loss, device)
+        net.to(device)
+        for k, p in net.named_parameters():
+            p.data = arena.p(k)
+            p.grad = None if k in arena.no_grad else arena.g(k)
+        self._arena = arena
+        self._fused = None
+        return arena
+
+    def training_step_fused(self, batch, eps_z=None, eps_l=None, loss_scale: float = 1.0):
+        """One fused fwd+bwd pass; gradients land in ``arena.flat_grad`` (= every p.grad)."""
+        self.train_step += 1
+        if self._arena is None:
+            self.attach_arena()
+        if self.library_mean is None or self.library_var is None:
+            raise ValueError("fused step needs the library prior constants (library_mean / library_var)")
+        if self.training and any(m.p > 0 for m in self.network.modules() if isinstance(m, nn.Dropout)) or \
+                (self.training and self.network.z_encoder.drop.p >= 1e-6):
+            raise NotImplementedError("fused step: dropout / gene-dropout are not on the HIP path yet (SURVEY §8 f4)")
+        if self._fused is None or self._fused.kl_weight != self.kl_weight:
+            self._fused = ElboStep(self._arena, l_mean=float(self.library_mean), l_var=float(self.library_var),
+                                   kl_weight=self.kl_weight, gene_loss_coeff=self.gene_loss_coeff,
+                                   precision=self.precision)
+        gene_vals, cell_prop_vals, cell_mask = batch[0], batch[1], batch[2]
+        B, L = gene_vals.shape[0], self.network.n_latent
+        if eps_z is None:  # same draw order as the reference: z-encoder noise, then library noise
+            eps_z = torch.empty(B, L, device=gene_vals.device).normal_()
+            eps_l = torch.empty(B, 1, device=gene_vals.device).normal_()
+        fn = None
+        if self.cell_properties is not None and cell_prop_vals is not None:
+            fn = lambda z: self._cell_loss(self.network.cell_decoder(z), cell_prop_vals, cell_mask, None)  # noqa: E731
+        out = self._fused.run(gene_vals, eps_z, eps_l, cell_head_fn=fn, loss_scale=loss_scale)
+        self.log("gene_loss", out["gene_loss"])
+        self.log("cell_loss", out["cell_loss"])
+        return out
+
+    def configure_optimizers(self):
+        """AdamW(beta 0.9/0.998, eps 1e-7), weight decay on z_encoder / cell_decoder only, warm-up
+        then inverse-sqrt decay (task.py:532-565)."""
+        enc = [p for n, p in self.network.named_parameters() if "z_encoder" in n or "cell_decoder" in n]
+        other = [p for n, p in self.network.named_parameters() if not ("z_encoder" in n or "cell_decoder" in n)]
+        opt = torch.optim.AdamW([{"params": enc, "weight_decay": self.weight_decay},
+                                 {"params": other, "weight_decay": 0.0}], lr=self.learning_rate,
+                                weight_decay=self.weight_decay, betas=(0.9, 0.998), eps=1e-7)
+        sched = {"scheduler": WarmupConstantAndDecaySchedule(opt, warmup_steps=self.warmup_steps), "interval": "step"}
+        return {"optimizer": opt, "lr_scheduler": sched, "interval": "step"}
