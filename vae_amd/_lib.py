@@ -29,11 +29,13 @@ SIGNATURES = {
     "vae_reparam_kl_bwd": (_i32, [_ptr, _i64, _ptr, _f32, _ptr, _i64, _ptr, _i64, _ptr, _i64, _i64, _f32, _f32, _ptr, _i64, _ptr]),
     "vae_colsum": (_i32, [_ptr, _i64, _i64, _i64, _ptr, _ptr]),
     "vae_elbo_reduce": (_i32, [_ptr, _ptr, _ptr, _i64, _f32, _f32, _ptr, _ptr]),
+    "vae_gene_table_rows": (_i64, []),
     "vae_gene_table": (_i32, [_ptr, _i64, _ptr, _ptr]),
     "vae_nbzinb_max_genes": (_i64, []),
     "vae_nbzinb_fwd": (_i32, [_i32, _ptr, _i64, _ptr, _i64, _ptr, _i64, _ptr, _ptr, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _ptr]),
+    "vae_nbzinb_bwd_workspace_bytes": (_i64, [_i64, _i64]),
     "vae_nbzinb_bwd": (_i32, [_i32, _ptr, _i64, _ptr, _i64, _ptr, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _f32, _i64, _i64,
-                              _ptr, _i64, _ptr, _i64, _ptr, _ptr, _ptr, _ptr, _ptr]),
+                              _ptr, _i64, _ptr, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _i64, _ptr]),
     "vae_softmax_rate_fwd": (_i32, [_ptr, _i64, _ptr, _i64, _i64, _ptr, _ptr, _ptr]),
     "vae_softmax_rate_bwd": (_i32, [_ptr, _ptr, _ptr, _ptr, _i64, _i64, _ptr, _i64, _ptr, _ptr]),
     "vae_loglik_elem_fwd": (_i32, [_i32, _ptr, _i64, _ptr, _i64, _ptr, _i64, _ptr, _i64, _i64, _i64, _ptr, _i64, _ptr]),

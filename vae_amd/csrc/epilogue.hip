@@ -1,0 +1,562 @@
+// Fused decoder epilogue of the scVI-style VAE (gfx950): softmax over genes, library-size
+// scaling and the NB / ZINB log-likelihood with its row reduction -- forward and backward.
+//
+// Reference semantics (all fp32):
+//   px_scale = softmax_g(logit_scale)            modules.py:362,401
+//   px_rate  = exp(library) * px_scale           modules.py:404
+//   theta    = exp(px_r)                         task.py:481-483
+//   ll       = log_zinb_positive / log_nb_positive(x, px_rate, theta, logit_dropout)
+//                                                distributions.py:22-62, :65-90
+//   recon    = -ll.sum(-1)                       task.py:156-165
+//
+// HBM-bound by design: forward reads (x, logit_scale, logit_dropout) exactly once = 12 B per
+// cell*gene (NB: 8 B); backward reads them once more and writes both logit gradients in place
+// = 20 B (NB: 12 B).  To keep the VALU under the HBM time:
+//   * everything that depends on the gene only (theta, log(theta+eps), 1/(theta+eps),
+//     lgamma(theta+k)-lgamma(theta)-lgamma(k+1) and digamma(theta+k)-digamma(theta) for counts
+//     k < 16) is tabulated once per step ("gene table", L2-resident) -- no lgamma / digamma in the
+//     per-element path for the counts that make up >99% of single-cell data;
+//   * logs / exps / reciprocals use the hardware v_log_f32 / v_exp_f32 / v_rcp_f32 (1 ulp);
+//     the softmax exponential carries a compensation term for the argument scaling.
+//
+// Forward: one 512-thread workgroup per cell keeps the scale-logit row in REGISTERS between the
+// softmax statistics (wavefront shuffles + LDS) and the likelihood pass, and also reduces
+// S_b = sum_g mu * dll/dmu, which makes the backward a single element-wise pass:
+//   dlogit_scale = delta_b * (a_g - p_g * S_b).
+// Backward: (strip of 1024 genes) x (chunk of cells) per workgroup; per-gene column sums
+// (d px_r, both bias gradients) stay in registers across the chunk and are flushed with one
+// float atomic per gene per workgroup; the next cell's loads are issued before the current
+// cell's stores so that HBM latency is overlapped although the gradients alias the logits.
+#include "common.h"
+
+#include <stdlib.h>
+
+namespace {
+
+constexpr float EPS = 1e-8f;
+constexpr int KTAB = 16;                  // counts 0..KTAB-1 are served by the gene table
+constexpr int ROW_TH = 0, ROW_LTE = 1, ROW_ITE = 2, ROW_LG = 3, ROW_PSI = 4, ROW_LGD = 5, ROW_DGD = 5 + KTAB;
+constexpr int TABLE_ROWS = 5 + 2 * KTAB;
+
+// ---- hardware-rate math ------------------------------------------------------------------
+__device__ __forceinline__ float flog(float v) { return __builtin_amdgcn_logf(v) * 0.69314718055994531f; }
+__device__ __forceinline__ float fexp(float v) { return __builtin_amdgcn_exp2f(v * 1.44269504088896341f); }
+__device__ __forceinline__ float frcp(float v) { return __builtin_amdgcn_rcpf(v); }
+// exp with the rounding error of v*log2(e) fed back (keeps softmax weights at ~1 ulp for |v| <= 88)
+__device__ __forceinline__ float fexp_acc(float v) {
+  v = fmaxf(v, -100.f);  // exp underflows to 0 well before; keeps -inf (masked lanes) out of the fma
+  const float t = v * 1.44269504088896341f;
+  float r = fmaf(v, 1.44269504088896341f, -t);
+  r = fmaf(v, 1.925963033500011e-8f, r);
+  const float e = __builtin_amdgcn_exp2f(t);
+  return fmaf(e, r * 0.69314718055994531f, e);
+}
+__device__ __forceinline__ float fsoftplus(float v) { return v > 20.f ? v : flog(1.f + fexp(v)); }
+__device__ __forceinline__ float fsigmoid20(float v) {  // softplus'(v) as torch evaluates it
+  const float z = fexp(fminf(v, 20.f));
+  return v > 20.f ? 1.f : z * frcp(z + 1.f);
+}
+
+// Stirling series, z >= 8 (truncation < 3e-8)
+__device__ __forceinline__ float lgamma_stirling(float z) {
+  const float iz = frcp(z), iz2 = iz * iz;
+  return (z - 0.5f) * flog(z) - z + 0.91893853320467274178f +
+         iz * (0.083333333333f - iz2 * (0.0027777777778f - iz2 * 0.00079365079365f));
+}
+// lgamma for any z > 0: below 8 shift up by 8 with the recurrence (one extra log)
+__device__ __forceinline__ float lgamma_any(float z) {
+  if (z >= 8.f) return lgamma_stirling(z);
+  float p = z;
+#pragma unroll
+  for (int j = 1; j < 8; ++j) p *= z + (float)j;
+  return lgamma_stirling(z + 8.f) - flog(p);
+}
+__device__ __forceinline__ float digamma_asym(float z) {  // z >= 6
+  const float iz = frcp(z), iz2 = iz * iz;
+  return flog(z) - 0.5f * iz - iz2 * (0.083333333333f - iz2 * (0.0083333333333f - iz2 * 0.003968253968f));
+}
+__device__ __forceinline__ float digamma_any(float z) {
+  if (z >= 6.f) return digamma_asym(z);
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < 6; ++j) s += frcp(z + (float)j);
+  return digamma_asym(z + 6.f) - s;
+}
+
+// ---- gene table --------------------------------------------------------------------------
+// built with the accurate libm-grade functions: it runs over G genes once per step
+__device__ __forceinline__ float digamma_exact(float z) {
+  float r = 0.f;
+  while (z < 6.f) {
+    r -= 1.f / z;
+    z += 1.f;
+  }
+  const float iz = 1.f / z, iz2 = iz * iz;
+  return r + logf(z) - 0.5f * iz - iz2 * (0.083333333333f - iz2 * (0.0083333333333f - iz2 * 0.003968253968f));
+}
+__global__ void gene_table_kernel(const float* __restrict__ px_r, int G, float* __restrict__ T) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= G) return;
+  const float th = expf(px_r[g]);
+  T[ROW_TH * G + g] = th;
+  T[ROW_LTE * G + g] = logf(th + EPS);
+  T[ROW_ITE * G + g] = 1.f / (th + EPS);
+  T[ROW_LG * G + g] = lgammaf(th);
+  T[ROW_PSI * G + g] = digamma_exact(th);
+  float lg = 0.f, dg = 0.f;  // k = 0
+  for (int k = 0; k < KTAB; ++k) {
+    T[(ROW_LGD + k) * G + g] = lg;
+    T[(ROW_DGD + k) * G + g] = dg;
+    lg += logf((th + (float)k) / (float)(k + 1));  // log of the rising-factorial ratio: no cancellation
+    dg += 1.f / (th + (float)k);
+  }
+}
+
+// ---- one (cell, gene) element ------------------------------------------------------------
+// The count-dependent table entry (row LGD+k / DGD+k of the gene, k = tab_index(x)) is loaded by
+// the caller ahead of time, unconditionally, so that the L2 round trip overlaps other work;
+// counts >= KTAB or non-integer take the (rare) closed-form branch here.
+__device__ __forceinline__ int tab_index(float x) {  // 0 for zeros and for counts the table does not cover
+  const int xi = (int)x;
+  return (x > EPS && xi < KTAB && x == (float)xi) ? xi : 0;
+}
+
+struct Fwd { float ll, a; };
+
+template <bool ZINB>
+__device__ __forceinline__ Fwd elem_fwd(float x, float mu, float pi, float th, float lgd_tab, const float* __restrict__ Tg,
+                                        int G) {
+  Fwd o;
+  const float lte = flog(th + EPS);
+  const float tm = th + mu + EPS;
+  const float ltm = flog(tm), itm = frcp(tm);
+  const float dlt = lte - ltm;
+  const bool pos = x > EPS;
+  float lgd = lgd_tab;
+  if (pos && !(x < (float)KTAB && x == truncf(x)))  // rare: large or fractional count
+    lgd = lgamma_any(x + th) - Tg[ROW_LG * G] - lgamma_any(x + 1.f);
+  const float ime = frcp(mu + EPS);
+  const float nzterm = x * (-flog(ime) - ltm) + lgd;            // log(mu+eps) = -log(1/(mu+eps))
+  const float a_nz = (x * ime - (x + th) * itm) * mu;
+  if (ZINB) {
+    const float sp = fsoftplus(-pi);
+    const float ptl = fmaf(th, dlt, -pi);
+    const float z = fexp(fminf(ptl, 20.f));
+    const float big = ptl > 20.f;
+    const float spz = big ? ptl : flog(1.f + z);               // softplus(ptl), threshold 20
+    const float sgz = big ? 1.f : z * frcp(1.f + z);           // its derivative
+    const bool zero = x < EPS;
+    o.ll = pos ? (-sp + ptl + nzterm) : (zero ? spz - sp : 0.f);
+    o.a = pos ? a_nz : (zero ? -sgz * th * itm * mu : 0.f);
+  } else {
+    o.ll = th * dlt + (pos ? nzterm : 0.f);
+    o.a = pos ? a_nz : -th * itm * mu;
+  }
+  return o;
+}
+
+struct Bwd { float a, dpi, dth; };
+
+template <bool ZINB>
+__device__ __forceinline__ Bwd elem_bwd(float x, float mu, float pi, float th, float lte, float ite, float dgd_tab,
+                                        const float* __restrict__ Tg, int G) {
+  Bwd o;
+  const float tm = th + mu + EPS;
+  const float ltm = flog(tm), itm = frcp(tm);
+  const float dlt = lte - ltm;
+  const float dptl_dth = dlt + th * (ite - itm);
+  const bool pos = x > EPS;
+  float dgd = dgd_tab;
+  if (pos && !(x < (float)KTAB && x == truncf(x))) dgd = digamma_any(x + th) - Tg[ROW_PSI * G];
+  const float a_nz = (x * frcp(mu + EPS) - (x + th) * itm) * mu;
+  const float dth_nz = dptl_dth - x * itm + dgd;
+  if (ZINB) {
+    const float sg_pi = fsigmoid20(-pi);
+    const float sg = fsigmoid20(fmaf(th, dlt, -pi));
+    const bool zero = x < EPS;
+    o.a = pos ? a_nz : (zero ? -sg * th * itm * mu : 0.f);
+    o.dpi = pos ? sg_pi - 1.f : (zero ? sg_pi - sg : 0.f);
+    o.dth = pos ? dth_nz : (zero ? sg * dptl_dth : 0.f);
+  } else {
+    o.dpi = 0.f;
+    o.a = pos ? a_nz : -th * itm * mu;
+    o.dth = pos ? dth_nz : dptl_dth;
+  }
+  return o;
+}
+
+// ---- forward: one workgroup per cell ------------------------------------------------------
+// All HBM loads of the cell (scale-logit row, x row, then the dropout-logit row) are issued up
+// front; exp(l - max) is parked in LDS between the softmax statistics and the likelihood pass
+// (each lane only ever touches its own slots: LDS is used as register overflow, conflict-free),
+// which keeps the kernel at <= 128 VGPRs so that two workgroups share a CU and one loads while
+// the other computes.
+template <bool VEC>
+__device__ __forceinline__ float4 ld4(const float* __restrict__ row, int i, int G, float fill) {
+  // elements [4i, 4i+4) of a row of G floats
+  if (VEC) return reinterpret_cast<const float4*>(row)[i];
+  float4 v;
+  const int g = 4 * i;
+  v.x = g < G ? row[g] : fill;
+  v.y = g + 1 < G ? row[g + 1] : fill;
+  v.z = g + 2 < G ? row[g + 2] : fill;
+  v.w = g + 3 < G ? row[g + 3] : fill;
+  return v;
+}
+
+template <bool ZINB, bool VEC, int EPT, int THREADS>
+__global__ __launch_bounds__(THREADS, 4) void nbzinb_fwd_kernel(
+    const float* __restrict__ ls, int64_t ld_s, const float* __restrict__ lp, int64_t ld_p, const float* __restrict__ x,
+    int64_t ld_x, const float* __restrict__ library, const float* __restrict__ T, int G,
+    float* __restrict__ ll_out, float* __restrict__ rowmax, float* __restrict__ rowsum, float* __restrict__ S_out) {
+  extern __shared__ __attribute__((aligned(16))) float4 srow[];  // EPT*THREADS float4, then NW floats
+  constexpr int NW = THREADS / 64;
+  float* red = reinterpret_cast<float*>(srow + EPT * THREADS);
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const float* r_s = ls + (int64_t)b * ld_s;
+  const float* r_p = ZINB ? lp + (int64_t)b * ld_p : nullptr;
+  const float* r_x = x + (int64_t)b * ld_x;
+  const int n4 = (G + 3) >> 2;
+  const float NEG = -INFINITY;
+  const float4 Z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+
+  // phase 1: the whole scale-logit row is requested at once (EPT x 16 B per lane in flight)
+  float4 e[EPT];
+#pragma unroll
+  for (int j = 0; j < EPT; ++j) {
+    const int i = tid + j * THREADS;
+    e[j] = i < n4 ? ld4<VEC>(r_s, i, G, NEG) : make_float4(NEG, NEG, NEG, NEG);
+  }
+  // the first two likelihood-pass operand sets are requested before the reductions so they travel meanwhile
+  auto hbm = [&](int i, float4& xv, float4& pv) {
+    xv = i < n4 ? ld4<VEC>(r_x, i, G, 0.f) : Z4;
+    pv = (ZINB && i < n4) ? ld4<VEC>(r_p, i, G, 0.f) : Z4;
+  };
+  float4 xa, pa, xb, pb;
+  hbm(tid, xa, pa);
+  hbm(tid + THREADS, xb, pb);
+  float m = NEG;
+#pragma unroll
+  for (int j = 0; j < EPT; ++j) m = fmaxf(fmaxf(m, fmaxf(e[j].x, e[j].y)), fmaxf(e[j].z, e[j].w));
+  m = block_max<NW>(m, red);
+  float se = 0.f;
+#pragma unroll
+  for (int j = 0; j < EPT; ++j) {
+    float4 v;
+    v.x = fexp_acc(e[j].x - m); v.y = fexp_acc(e[j].y - m);
+    v.z = fexp_acc(e[j].z - m); v.w = fexp_acc(e[j].w - m);
+    se += (v.x + v.y) + (v.z + v.w);
+    srow[tid + j * THREADS] = v;  // own slot: LDS as register overflow, conflict-free
+  }
+  se = block_sum<NW>(se, red);
+  const float scale = expf(library[b]) / se;  // mu = exp(library) * e / sum
+
+  // phase 2: software-pipelined likelihood pass.  Iteration j evaluates float4 j while the HBM
+  // operands of j+1 and the L2 table entries of j+1 (theta, count-indexed lgamma term) travel.
+  auto tab = [&](const float4& xv, int i, float4& th, float (&lg)[4]) {
+    const int ii = i < n4 ? i : 0;
+    th = ld4<VEC>(T + ROW_TH * G, ii, G, 1.f);
+    const float xc[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) lg[c] = T[(ROW_LGD + tab_index(xc[c])) * G + min(4 * ii + c, G - 1)];
+  };
+  // vmcnt retires in issue order, so per iteration the order is: (1) table loads of j+1 (their
+  // x landed an iteration ago), (2) HBM loads of j+2, (3) evaluate j -- waiting for (1) next
+  // iteration then never waits for the younger HBM loads of (2).
+  float4 tha, thb;
+  float lga[4], lgb[4];
+  tab(xa, tid, tha, lga);
+  float acc_ll = 0.f, acc_a = 0.f;
+#pragma unroll 1
+  for (int j = 0; j < EPT; ++j) {
+    const int i = tid + j * THREADS;
+    tab(xb, i + THREADS, thb, lgb);
+    float4 xc, pc;
+    hbm(j + 2 < EPT ? i + 2 * THREADS : n4, xc, pc);
+    const float4 ev = srow[i];
+    const int g = 4 * i;
+    Fwd f0 = elem_fwd<ZINB>(xa.x, scale * ev.x, pa.x, tha.x, lga[0], T + min(g, G - 1), G);
+    Fwd f1 = elem_fwd<ZINB>(xa.y, scale * ev.y, pa.y, tha.y, lga[1], T + min(g + 1, G - 1), G);
+    Fwd f2 = elem_fwd<ZINB>(xa.z, scale * ev.z, pa.z, tha.z, lga[2], T + min(g + 2, G - 1), G);
+    Fwd f3 = elem_fwd<ZINB>(xa.w, scale * ev.w, pa.w, tha.w, lga[3], T + min(g + 3, G - 1), G);
+    const bool v0 = g < G, v1 = g + 1 < G, v2 = g + 2 < G, v3 = g + 3 < G;
+    acc_ll += (v0 ? f0.ll : 0.f) + (v1 ? f1.ll : 0.f) + (v2 ? f2.ll : 0.f) + (v3 ? f3.ll : 0.f);
+    acc_a += (v0 ? f0.a : 0.f) + (v1 ? f1.a : 0.f) + (v2 ? f2.a : 0.f) + (v3 ? f3.a : 0.f);
+    xa = xb; pa = pb; tha = thb;
+    xb = xc; pb = pc;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) lga[c] = lgb[c];
+  }
+  acc_ll = block_sum<NW>(acc_ll, red);
+  acc_a = block_sum<NW>(acc_a, red);
+  if (tid == 0) {
+    ll_out[b] = acc_ll;
+    rowmax[b] = m;
+    rowsum[b] = se;
+    S_out[b] = acc_a;
+  }
+}
+
+// ---- backward: (gene strip of 1024) x (chunk of cells) per workgroup ----------------------
+constexpr int BWD_STRIP = 1024;  // 256 threads x float4
+constexpr int BWD_MAX_ROWS = 64;  // cells per workgroup (per-cell constants staged in LDS)
+
+struct RowIn { float4 l, p, x; };
+
+template <bool ZINB, bool VEC>
+__device__ __forceinline__ RowIn load_row(const float* ls, int64_t ld_s, const float* lp, int64_t ld_p,
+                                          const float* __restrict__ x, int64_t ld_x, int b, int g0, int G) {
+  RowIn r;
+  r.l = ld4<VEC>(ls + (int64_t)b * ld_s, g0 >> 2, G, 0.f);
+  r.x = ld4<VEC>(x + (int64_t)b * ld_x, g0 >> 2, G, 0.f);
+  r.p = ZINB ? ld4<VEC>(lp + (int64_t)b * ld_p, g0 >> 2, G, 0.f) : make_float4(0.f, 0.f, 0.f, 0.f);
+  return r;
+}
+
+template <bool ZINB, bool VEC, bool SLAB>
+__global__ __launch_bounds__(256) void nbzinb_bwd_kernel(
+    const float* ls, int64_t ld_s, const float* lp, int64_t ld_p, const float* __restrict__ x, int64_t ld_x,
+    const float* __restrict__ library, const float* __restrict__ T, const float* __restrict__ rowmax,
+    const float* __restrict__ rowsum, const float* __restrict__ S, const float* __restrict__ g_ll, float g_scalar, int B,
+    int G, int rows_per_block, float* dls, int64_t ld_ds, float* dlp, int64_t ld_dp, float* __restrict__ dlibrary,
+    float* __restrict__ dpx_r, float* __restrict__ dbias_s, float* __restrict__ dbias_p, float* __restrict__ slab) {
+  __shared__ float4 rc[BWD_MAX_ROWS];  // per cell: {max + log(sumexp), exp(library), S_b, delta_b}
+  const int g0 = blockIdx.x * BWD_STRIP + threadIdx.x * 4;
+  const int b0 = blockIdx.y * rows_per_block;
+  const int b1 = min(B, b0 + rows_per_block);
+  for (int r = threadIdx.x; r < b1 - b0; r += 256) {
+    const int b = b0 + r;
+    const float delta = g_scalar * (g_ll ? g_ll[b] : 1.f);
+    rc[r] = make_float4(rowmax[b] + logf(rowsum[b]), expf(library[b]), S[b], delta);
+    if (blockIdx.x == 0 && dlibrary) dlibrary[b] = delta * S[b];
+  }
+  __syncthreads();
+  if (g0 >= G) return;
+  const int nv = min(4, G - g0);  // valid columns of this thread
+  float th[4], lt[4], it[4], acc_t[4], acc_s[4], acc_p[4];
+  const float* Tg[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int g = min(g0 + j, G - 1);
+    Tg[j] = T + g;
+    th[j] = T[ROW_TH * G + g]; lt[j] = T[ROW_LTE * G + g]; it[j] = T[ROW_ITE * G + g];
+    acc_t[j] = acc_s[j] = acc_p[j] = 0.f;
+  }
+  // 3-stage software pipeline over the cells of the chunk:
+  //   stage A (cell b+2): HBM loads of (logit_scale, logit_dropout, x)
+  //   stage B (cell b+1): x has landed -> issue the count-indexed table loads (L2)
+  //   stage C (cell b)  : evaluate, store both gradients (they alias the logits of cell b only)
+  RowIn c0 = load_row<ZINB, VEC>(ls, ld_s, lp, ld_p, x, ld_x, b0, g0, G);
+  RowIn c1 = c0;
+  if (b0 + 1 < b1) c1 = load_row<ZINB, VEC>(ls, ld_s, lp, ld_p, x, ld_x, b0 + 1, g0, G);
+  float d0[4], d1[4] = {0.f, 0.f, 0.f, 0.f};
+  {
+    const float xv[4] = {c0.x.x, c0.x.y, c0.x.z, c0.x.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) d0[j] = Tg[j][(ROW_DGD + tab_index(xv[j])) * G];
+  }
+  for (int b = b0; b < b1; ++b) {
+    // vmcnt retires in issue order: table loads of cell b+1 FIRST, HBM loads of cell b+2 after them
+    if (b + 1 < b1) {
+      const float xv[4] = {c1.x.x, c1.x.y, c1.x.z, c1.x.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) d1[j] = Tg[j][(ROW_DGD + tab_index(xv[j])) * G];
+    }
+    RowIn c2 = c1;
+    if (b + 2 < b1) c2 = load_row<ZINB, VEC>(ls, ld_s, lp, ld_p, x, ld_x, b + 2, g0, G);
+    const float4 k = rc[b - b0];
+    const float l4[4] = {c0.l.x, c0.l.y, c0.l.z, c0.l.w};
+    const float p4[4] = {c0.p.x, c0.p.y, c0.p.z, c0.p.w};
+    const float x4[4] = {c0.x.x, c0.x.y, c0.x.z, c0.x.w};
+    float o_s[4], o_p[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float p = fexp_acc(l4[j] - k.x);
+      const Bwd e = elem_bwd<ZINB>(x4[j], k.y * p, p4[j], th[j], lt[j], it[j], d0[j], Tg[j], G);
+      o_s[j] = k.w * (e.a - p * k.z);
+      o_p[j] = k.w * e.dpi;
+      acc_t[j] += k.w * e.dth * th[j];
+      acc_s[j] += o_s[j];
+      acc_p[j] += o_p[j];
+    }
+    float* w_s = dls + (int64_t)b * ld_ds + g0;
+    float* w_p = ZINB ? dlp + (int64_t)b * ld_dp + g0 : nullptr;
+    if (VEC) {
+      *reinterpret_cast<float4*>(w_s) = make_float4(o_s[0], o_s[1], o_s[2], o_s[3]);
+      if (ZINB) *reinterpret_cast<float4*>(w_p) = make_float4(o_p[0], o_p[1], o_p[2], o_p[3]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (j < nv) {
+          w_s[j] = o_s[j];
+          if (ZINB) w_p[j] = o_p[j];
+        }
+    }
+    c0 = c1;
+    c1 = c2;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) d0[j] = d1[j];
+  }
+  if (SLAB) {
+    // partial column sums of this cell chunk: plain coalesced stores into slab[chunk][3][G];
+    // colreduce_kernel adds them up in chunk order (deterministic, no float atomics)
+    float* sl = slab + (int64_t)blockIdx.y * 3 * G + g0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (j < nv) {
+        sl[j] = acc_t[j];
+        sl[G + j] = acc_s[j];
+        if (ZINB) sl[2 * G + j] = acc_p[j];
+      }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (j < nv) {
+        atomicAdd(dpx_r + g0 + j, acc_t[j]);
+        if (dbias_s) atomicAdd(dbias_s + g0 + j, acc_s[j]);
+        if (ZINB && dbias_p) atomicAdd(dbias_p + g0 + j, acc_p[j]);
+      }
+  }
+}
+
+// out_k[g] += sum_c slab[c][k][g], k = 0 (d px_r), 1 (d bias_scale), 2 (d bias_dropout)
+__global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict__ slab, int chunks, int G, int nk,
+                                                        float* __restrict__ o0, float* __restrict__ o1,
+                                                        float* __restrict__ o2) {
+  const int g = blockIdx.x * 256 + threadIdx.x;
+  const int k = blockIdx.y;
+  if (g >= G || k >= nk) return;
+  float* o = k == 0 ? o0 : (k == 1 ? o1 : o2);
+  if (!o) return;
+  float s = 0.f;
+  for (int c = 0; c < chunks; ++c) s += slab[((int64_t)c * 3 + k) * G + g];
+  o[g] += s;
+}
+
+template <bool ZINB, bool VEC, int EPT, int THREADS>
+void launch_fwd(const float* ls, int64_t ld_s, const float* lp, int64_t ld_p, const float* x, int64_t ld_x,
+                const float* library, const float* T, int B, int G, float* ll, float* rowmax, float* rowsum, float* S,
+                hipStream_t st, hipError_t* err) {
+  const size_t shmem = (size_t)EPT * THREADS * sizeof(float4) + 64;
+  auto kern = nbzinb_fwd_kernel<ZINB, VEC, EPT, THREADS>;
+  *err = hipSuccess;
+  if (shmem > 64 * 1024)
+    *err = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+  if (*err != hipSuccess) return;
+  hipLaunchKernelGGL(kern, dim3(B), dim3(THREADS), shmem, st, ls, ld_s, lp, ld_p, x, ld_x, library, T, G, ll, rowmax,
+                     rowsum, S);
+}
+
+template <bool ZINB, bool VEC>
+void dispatch_fwd(const float* ls, int64_t ld_s, const float* lp, int64_t ld_p, const float* x, int64_t ld_x,
+                  const float* library, const float* T, int B, int G, float* ll, float* rowmax, float* rowsum, float* S,
+                  hipStream_t st, hipError_t* err) {
+#define FWD_CASE(E, TH) launch_fwd<ZINB, VEC, E, TH>(ls, ld_s, lp, ld_p, x, ld_x, library, T, B, G, ll, rowmax, rowsum, S, st, err)
+  // (EPT, THREADS): 4*EPT*THREADS >= G; 512 threads while two workgroups fit a CU's LDS, else 1024
+  if (G <= 1024) FWD_CASE(1, 256);
+  else if (G <= 2048) FWD_CASE(1, 512);
+  else if (G <= 4096) FWD_CASE(2, 512);
+  else if (G <= 8192) FWD_CASE(4, 512);
+  else if (G <= 12288) FWD_CASE(6, 512);
+  else if (G <= 16384) FWD_CASE(8, 512);
+  else if (G <= 20480) FWD_CASE(10, 512);
+  else if (G <= 24576) FWD_CASE(6, 1024);
+  else if (G <= 32768) FWD_CASE(8, 1024);
+  else FWD_CASE(10, 1024);
+#undef FWD_CASE
+}
+
+}  // namespace
+
+extern "C" int64_t vae_gene_table_rows(void) { return TABLE_ROWS; }
+
+extern "C" int vae_gene_table(const float* px_r, int64_t G, float* table, void* stream) {
+  VAE_REQUIRE(px_r && table && G > 0, "vae_gene_table: bad arguments");
+  hipLaunchKernelGGL(gene_table_kernel, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, (hipStream_t)stream, px_r,
+                     (int)G, table);
+  VAE_CHECK_LAUNCH("vae_gene_table");
+  return VAE_OK;
+}
+
+extern "C" int64_t vae_nbzinb_max_genes(void) { return 10 * 1024 * 4; }
+
+extern "C" int vae_nbzinb_fwd(int zinb, const float* logit_scale, int64_t ld_s, const float* logit_dropout, int64_t ld_p,
+                              const float* x, int64_t ld_x, const float* library, const float* gene_table, int64_t B,
+                              int64_t G, float* ll, float* rowmax, float* rowsum, float* S, void* stream) {
+  VAE_REQUIRE(logit_scale && x && library && gene_table && ll && rowmax && rowsum && S, "vae_nbzinb_fwd: null pointer");
+  VAE_REQUIRE(!zinb || logit_dropout, "vae_nbzinb_fwd: ZINB needs logit_dropout");
+  VAE_REQUIRE(B > 0 && G > 0 && G <= vae_nbzinb_max_genes(), "vae_nbzinb_fwd: G=%lld outside [1, %lld]", (long long)G,
+              (long long)vae_nbzinb_max_genes());
+  VAE_REQUIRE(ld_s >= G && ld_x >= G && (!zinb || ld_p >= G), "vae_nbzinb_fwd: leading dimension too small");
+  const int vec = (G % 4 == 0) && (ld_s % 4 == 0) && (ld_x % 4 == 0) && (!zinb || ld_p % 4 == 0) &&
+                  vae_aligned16(logit_scale) && vae_aligned16(x) && (!zinb || vae_aligned16(logit_dropout)) &&
+                  vae_aligned16(gene_table);
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t err = hipSuccess;
+#define DISPATCH(Z, V, LP, LDP) dispatch_fwd<Z, V>(logit_scale, ld_s, LP, LDP, x, ld_x, library, gene_table, (int)B, (int)G, ll, rowmax, rowsum, S, st, &err)
+  if (zinb) { if (vec) DISPATCH(true, true, logit_dropout, ld_p); else DISPATCH(true, false, logit_dropout, ld_p); }
+  else      { if (vec) DISPATCH(false, true, nullptr, 0); else DISPATCH(false, false, nullptr, 0); }
+#undef DISPATCH
+  if (err != hipSuccess) return vae_set_error(VAE_ERR_LAUNCH, "vae_nbzinb_fwd: cannot raise LDS limit: %s", hipGetErrorString(err));
+  VAE_CHECK_LAUNCH("vae_nbzinb_fwd");
+  return VAE_OK;
+}
+
+namespace {
+void bwd_grid(int64_t B, int64_t G, int* strips, int* chunks, int* rows_per_block) {
+  *strips = (int)((G + BWD_STRIP - 1) / BWD_STRIP);
+  static const int target = getenv("VAE_BWD_WORKGROUPS") ? atoi(getenv("VAE_BWD_WORKGROUPS")) : 1024;  // tuning knob
+  int c = (target + *strips - 1) / *strips;  // default ~4 workgroups per CU
+  if (c > 64) c = 64;                        // bounds the slab reduction for small gene counts
+  if (c > B) c = (int)B;
+  *rows_per_block = (int)((B + c - 1) / c);
+  if (*rows_per_block > BWD_MAX_ROWS) *rows_per_block = BWD_MAX_ROWS;
+  *chunks = (int)((B + *rows_per_block - 1) / *rows_per_block);
+}
+}  // namespace
+
+extern "C" int64_t vae_nbzinb_bwd_workspace_bytes(int64_t B, int64_t G) {
+  int strips, chunks, rpb;
+  bwd_grid(B, G, &strips, &chunks, &rpb);
+  return (int64_t)chunks * 3 * G * (int64_t)sizeof(float);
+}
+
+extern "C" int vae_nbzinb_bwd(int zinb, const float* logit_scale, int64_t ld_s, const float* logit_dropout, int64_t ld_p,
+                              const float* x, int64_t ld_x, const float* library, const float* gene_table,
+                              const float* rowmax, const float* rowsum, const float* S, const float* g_ll,
+                              float g_scalar, int64_t B, int64_t G, float* dlogit_scale, int64_t ld_ds,
+                              float* dlogit_dropout, int64_t ld_dp, float* dlibrary, float* dpx_r, float* dbias_scale,
+                              float* dbias_dropout, float* workspace, int64_t workspace_bytes, void* stream) {
+  VAE_REQUIRE(logit_scale && x && library && gene_table && rowmax && rowsum && S && dlogit_scale && dpx_r,
+              "vae_nbzinb_bwd: null pointer");
+  VAE_REQUIRE(!zinb || (logit_dropout && dlogit_dropout), "vae_nbzinb_bwd: ZINB needs the dropout logits and their gradient");
+  VAE_REQUIRE(B > 0 && G > 0, "vae_nbzinb_bwd: bad shape");
+  VAE_REQUIRE(ld_s >= G && ld_x >= G && ld_ds >= G && (!zinb || (ld_p >= G && ld_dp >= G)),
+              "vae_nbzinb_bwd: leading dimension too small");
+  const bool vec = (G % 4 == 0) && (ld_s % 4 == 0) && (ld_x % 4 == 0) && (ld_ds % 4 == 0) &&
+                   (!zinb || (ld_p % 4 == 0 && ld_dp % 4 == 0)) && vae_aligned16(logit_scale) && vae_aligned16(x) &&
+                   vae_aligned16(dlogit_scale) && (!zinb || (vae_aligned16(logit_dropout) && vae_aligned16(dlogit_dropout)));
+  int strips, chunks, rows_per_block;
+  bwd_grid(B, G, &strips, &chunks, &rows_per_block);
+  const bool slab = workspace != nullptr;
+  VAE_REQUIRE(!slab || workspace_bytes >= vae_nbzinb_bwd_workspace_bytes(B, G),
+              "vae_nbzinb_bwd: workspace too small (see vae_nbzinb_bwd_workspace_bytes)");
+  dim3 grid(strips, chunks);
+  hipStream_t st = (hipStream_t)stream;
+#define LAUNCH_BWD(Z, V, S_)                                                                                          \
+  hipLaunchKernelGGL((nbzinb_bwd_kernel<Z, V, S_>), grid, dim3(256), 0, st, logit_scale, ld_s, logit_dropout, ld_p, x,  \
+                     ld_x, library, gene_table, rowmax, rowsum, S, g_ll, g_scalar, (int)B, (int)G, rows_per_block,    \
+                     dlogit_scale, ld_ds, dlogit_dropout, ld_dp, dlibrary, dpx_r, dbias_scale, dbias_dropout, workspace)
+#define LAUNCH_BWD2(Z, V) do { if (slab) LAUNCH_BWD(Z, V, true); else LAUNCH_BWD(Z, V, false); } while (0)
+  if (zinb) { if (vec) LAUNCH_BWD2(true, true); else LAUNCH_BWD2(true, false); }
+  else      { if (vec) LAUNCH_BWD2(false, true); else LAUNCH_BWD2(false, false); }
+#undef LAUNCH_BWD2
+#undef LAUNCH_BWD
+  VAE_CHECK_LAUNCH("vae_nbzinb_bwd");
+  if (slab) {
+    hipLaunchKernelGGL(colreduce_kernel, dim3((unsigned)((G + 255) / 256), zinb ? 3 : 2), dim3(256), 0, st, workspace,
+                       chunks, (int)G, zinb ? 3 : 2, dpx_r, dbias_scale, dbias_dropout);
+    VAE_CHECK_LAUNCH("vae_nbzinb_bwd(colreduce)");
+  }
+  return VAE_OK;
+}

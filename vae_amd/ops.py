@@ -193,12 +193,17 @@ def elbo_reduce(ll: torch.Tensor, kl_z: torch.Tensor, kl_l: torch.Tensor, kl_wei
 
 
 def gene_table(px_r: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """(4, G): theta = exp(px_r), log(theta + 1e-8), lgamma(theta), digamma(theta)."""
+    """(vae_gene_table_rows(), G) per-gene constants of the fused epilogue: theta = exp(px_r),
+    log(theta+1e-8), 1/(theta+1e-8), lgamma(theta), digamma(theta) and, for counts k < 16,
+    lgamma(theta+k)-lgamma(theta)-lgamma(k+1) and digamma(theta+k)-digamma(theta)."""
     lib = _lib.load()
     G = px_r.numel()
     _chk1d(px_r, G, "px_r")
+    rows = lib.vae_gene_table_rows()
     if out is None:
-        out = torch.empty(4, G, dtype=torch.float32, device=px_r.device)
+        out = torch.empty(rows, G, dtype=torch.float32, device=px_r.device)
+    if out.shape != (rows, G) or not out.is_contiguous():
+        raise ValueError(f"vae_amd.ops.gene_table: out must be contiguous {(rows, G)}")
     _lib.check(lib.vae_gene_table(_p(px_r), G, _p(out), _stream()), "gene_table")
     return out
 
@@ -219,8 +224,8 @@ def nbzinb_fwd(zinb: bool, logit_scale: torch.Tensor, logit_dropout: Optional[to
         if logit_dropout.shape != (B, G):
             raise ValueError("vae_amd.ops.nbzinb_fwd: logit_dropout shape mismatch")
     _chk1d(library, B, "library")
-    if table.shape != (4, G) or not table.is_contiguous():
-        raise ValueError("vae_amd.ops.nbzinb_fwd: table must be the (4, G) gene table")
+    if table.shape != (lib.vae_gene_table_rows(), G) or not table.is_contiguous():
+        raise ValueError("vae_amd.ops.nbzinb_fwd: table must be the gene table made by ops.gene_table")
     o = torch.empty(4, B, dtype=torch.float32, device=x.device)
     _lib.check(lib.vae_nbzinb_fwd(int(zinb), _p(logit_scale), _ld(logit_scale), _p(logit_dropout if zinb else None),
                                   _ld(logit_dropout) if zinb else 0, _p(x), _ld(x), _p(library), _p(table), B, G,
@@ -232,21 +237,27 @@ def nbzinb_bwd(zinb: bool, logit_scale: torch.Tensor, logit_dropout: Optional[to
                library: torch.Tensor, table: torch.Tensor, rowmax, rowsum, S, g_ll: Optional[torch.Tensor],
                g_scalar: float, dlogit_scale: torch.Tensor, dlogit_dropout: Optional[torch.Tensor],
                dlibrary: Optional[torch.Tensor], dpx_r: torch.Tensor, dbias_scale: Optional[torch.Tensor],
-               dbias_dropout: Optional[torch.Tensor]) -> None:
+               dbias_dropout: Optional[torch.Tensor], deterministic: bool = True) -> None:
     """Gradient of sum_b g_scalar*g_ll[b]*ll[b].  dlogit_* may alias logit_* (in place).
-    dpx_r / dbias_* are ACCUMULATED into (float atomics)."""
+    dpx_r / dbias_* are ACCUMULATED into: through per-chunk slabs summed in a fixed order
+    (deterministic=True, default) or with float atomics."""
     lib = _lib.load()
     B, G = x.shape
+    if table.shape != (lib.vae_gene_table_rows(), G) or not table.is_contiguous():
+        raise ValueError("vae_amd.ops.nbzinb_bwd: table must be the gene table made by ops.gene_table")
     _chk2d(dlogit_scale, "dlogit_scale")
     if zinb:
         _chk2d(dlogit_dropout, "dlogit_dropout")
     _chk1d(g_ll, B, "g_ll"); _chk1d(dlibrary, B, "dlibrary"); _chk1d(dpx_r, G, "dpx_r")
     _chk1d(dbias_scale, G, "dbias_scale"); _chk1d(dbias_dropout, G, "dbias_dropout")
+    nbytes = lib.vae_nbzinb_bwd_workspace_bytes(B, G) if deterministic else 0
+    ws = workspace(nbytes, x.device) if deterministic else None
     _lib.check(lib.vae_nbzinb_bwd(int(zinb), _p(logit_scale), _ld(logit_scale), _p(logit_dropout if zinb else None),
                                   _ld(logit_dropout) if zinb else 0, _p(x), _ld(x), _p(library), _p(table), _p(rowmax),
                                   _p(rowsum), _p(S), _p(g_ll), float(g_scalar), B, G, _p(dlogit_scale), _ld(dlogit_scale),
                                   _p(dlogit_dropout if zinb else None), _ld(dlogit_dropout) if zinb else 0, _p(dlibrary),
-                                  _p(dpx_r), _p(dbias_scale), _p(dbias_dropout if zinb else None), _stream()),
+                                  _p(dpx_r), _p(dbias_scale), _p(dbias_dropout if zinb else None), _p(ws), nbytes,
+                                  _stream()),
                "nbzinb_bwd")
 
 

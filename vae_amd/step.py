@@ -53,7 +53,7 @@ class ElboStep:
         self.G = a.p("px_r").shape[0]
         self.L = a.p("z_encoder.mean_encoder.weight").shape[0]
         self.Hd = a.p(_dec(0, "w")).shape[0]
-        self.table = torch.empty(4, self.G, dtype=torch.float32, device=a.device)
+        self.table = ops.gene_table(a.p("px_r")) if a.flat.is_cuda else None
 
     # ------------------------------------------------------------------------------------
     def run(self, x: torch.Tensor, eps_z: torch.Tensor, eps_l: torch.Tensor,
