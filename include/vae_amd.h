@@ -1,0 +1,189 @@
+/* vae_amd.h -- C ABI of libvae_amd.so: hand-written gfx950 (MI355X) kernels for the training
+ * hot path of the scVI-style VAE of DiseaseNeuroGenomics/vae (fwd + bwd ELBO).
+ *
+ * The reference has no FFI layer: the path sits behind Python nn.Module / function
+ * signatures (SURVEY.md par. 8b).  These entry points are what a binding for that path
+ * attaches to; each comment names the reference code the call replaces
+ * (paths relative to the reference's src/).  The reference-side stub is in INTEGRATION.md.
+ *
+ * Conventions
+ *   - all matrices are fp32, row-major, with an explicit leading dimension (elements);
+ *   - every pointer is a DEVICE pointer owned by the caller; the library never allocates,
+ *     frees or retains memory (scratch is passed in; sizes come from the *_workspace_bytes
+ *     queries);
+ *   - `stream` is a hipStream_t (NULL = default stream); calls only enqueue work;
+ *   - return value: 0 = ok, VAE_ERR_* otherwise, message via vae_last_error() (thread-local);
+ *     no C++ exception crosses the boundary;
+ *   - outputs documented as "accumulated" are added to (zero them for a plain result).
+ */
+#ifndef VAE_AMD_H
+#define VAE_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VAE_OK 0
+#define VAE_ERR_ARG 1
+#define VAE_ERR_LAUNCH 2
+#define VAE_ERR_UNSUPPORTED 3
+
+/* layouts / precisions of vae_gemm */
+#define VAE_NT 0 /* C[m,n] = sum_k A[m,k] B[n,k]   nn.Linear forward            */
+#define VAE_NN 1 /* C[m,n] = sum_k A[m,k] B[k,n]   autograd dgrad               */
+#define VAE_TN 2 /* C[m,n] = sum_k A[k,m] B[k,n]   autograd wgrad               */
+#define VAE_FP32 0 /* exact fp32 MFMA (v_mfma_f32_32x32x2_f32)                  */
+#define VAE_BF16 1 /* operands rounded to bf16, fp32 accumulate (..32x32x16_bf16) */
+
+/* ---- library ---------------------------------------------------------------------------- */
+int vae_version(void);             /* 100 * major + minor */
+const char* vae_arch(void);        /* "gfx950" */
+const char* vae_last_error(void);  /* message of the last failing call on this thread */
+int vae_device_count(void);        /* GPUs visible to HIP; 0 on a CPU-only host, never fails */
+
+/* ---- GEMM: nn.Linear forward / backward (modules.py:111,248-249,361-369 + autograd) ------ */
+/* x_mean (nullable): per-cell mean; normalises the count operand on the fly, x/mean - 1
+ * (Encoder.forward, modules.py:264): rows of A for VAE_NT, rows (k) of B for VAE_TN.
+ * bias (nullable): [N], added to every row.  accumulate != 0: C += result.
+ * workspace: >= vae_gemm_workspace_bytes(M,N,K) bytes, 16-byte aligned (may be NULL if 0). */
+int64_t vae_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K);
+int vae_gemm(int layout, int precision, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B,
+             int64_t ldb, float* C, int64_t ldc, const float* bias, const float* x_mean, int accumulate,
+             float* workspace, int64_t workspace_bytes, void* stream);
+
+/* ---- row kernels ----------------------------------------------------------------------------- */
+/* mean[b] = mean_g x[b,g]                                   Encoder.forward, modules.py:264      */
+int vae_row_mean(const float* x, int64_t ldx, int64_t B, int64_t G, float* mean, void* stream);
+
+/* out = LayerNorm(GELU(pre)) * gamma + beta, eps 1e-5; saves per-row mean / rstd of GELU(pre)
+ *                                                           FCLayers, modules.py:112-114          */
+int vae_gelu_ln_fwd(const float* pre, int64_t ld_pre, const float* gamma, const float* beta, int64_t B, int64_t W,
+                    float* out, int64_t ld_out, float* mean, float* rstd, void* stream);
+/* backward of the above; dpre may alias dout.  dgamma, dbeta, dbias (= column sums of dpre, the
+ * bias gradient of the Linear that produced `pre`) are accumulated (each nullable).              */
+int vae_gelu_ln_bwd(const float* dout, int64_t ld_dout, const float* pre, int64_t ld_pre, const float* mean,
+                    const float* rstd, const float* gamma, int64_t B, int64_t W, float* dpre, int64_t ld_dpre,
+                    float* dgamma, float* dbeta, float* dbias, void* stream);
+
+/* fused reparameterisation sample + Gaussian KL.  heads[b,0:L] = q_m, heads[b,L] = pre-activation
+ * of the ONE shared variance:  q_v = softplus(.)+1e-4, z = q_m + eps*sqrt(q_v),
+ * kl[b] = sum_j KL(N(q_m_j, sqrt q_v) || N(prior_mean, sqrt prior_var))
+ *                        Encoder.forward modules.py:268-270, :11-12; LitVAE.gene_loss task.py:188-198 */
+int vae_reparam_kl_fwd(const float* heads, int64_t ld_heads, const float* eps, int64_t ld_eps, int64_t B, int64_t L,
+                       float prior_mean, float prior_var, float* qv, float* z, int64_t ld_z, float* kl, void* stream);
+/* dheads (B, L+1) from dz (B, L) and the upstream gradient on kl[b] = g_kl_scalar * g_kl[b]
+ * (g_kl nullable = 1)                                                                              */
+int vae_reparam_kl_bwd(const float* dz, int64_t ld_dz, const float* g_kl, float g_kl_scalar, const float* heads,
+                       int64_t ld_heads, const float* eps, int64_t ld_eps, const float* qv, int64_t B, int64_t L,
+                       float prior_mean, float prior_var, float* dheads, int64_t ld_dheads, void* stream);
+
+/* dst[i] += src[i]  (adds the cell-property heads' latent gradient, task.py:469-471, to dz)         */
+int vae_add_inplace(const float* src, float* dst, int64_t n, void* stream);
+
+/* out[n] += sum_m in[m,n]   (bias gradients of the small Linears)                                  */
+int vae_colsum(const float* in, int64_t ld, int64_t M, int64_t N, float* out, void* stream);
+
+/* out5 = { mean(-ll), mean(kl_z), mean(kl_l), gene_loss, gene_loss_coeff*gene_loss },
+ * gene_loss = mean(-ll) + kl_weight*mean(kl_l + kl_z)      LitVAE.gene_loss task.py:202, :489      */
+int vae_elbo_reduce(const float* ll, const float* kl_z, const float* kl_l, int64_t B, float kl_weight,
+                    float gene_loss_coeff, float* out5, void* stream);
+
+/* ---- fused decoder epilogue ---------------------------------------------------------------------
+ * softmax over genes (modules.py:362,401), px_rate = exp(library)*px_scale (:404),
+ * theta = exp(px_r) (task.py:481-483), NB / ZINB log-likelihood (distributions.py:22-62, :65-90),
+ * sum over genes (task.py:156-165) -- and its backward.                                           */
+int64_t vae_gene_table_rows(void);
+/* per-gene constants of the epilogue, (vae_gene_table_rows(), G); rebuild whenever px_r changes   */
+int vae_gene_table(const float* px_r, int64_t G, float* table, void* stream);
+int64_t vae_nbzinb_max_genes(void);
+/* ll[b] = sum_g log p(x[b,g]); rowmax / rowsum / S are what the backward needs (each [B])         */
+int vae_nbzinb_fwd(int zinb, const float* logit_scale, int64_t ld_s, const float* logit_dropout, int64_t ld_p,
+                   const float* x, int64_t ld_x, const float* library, const float* gene_table, int64_t B, int64_t G,
+                   float* ll, float* rowmax, float* rowsum, float* S, void* stream);
+/* gradient of sum_b g_scalar*g_ll[b]*ll[b] (g_ll nullable = 1).  dlogit_* may alias logit_*.
+ * dlibrary [B] is written; dpx_r, dbias_scale, dbias_dropout [G] are accumulated -- in a fixed
+ * order through `workspace` (>= vae_nbzinb_bwd_workspace_bytes) or, if workspace is NULL, with
+ * float atomics.                                                                                   */
+int64_t vae_nbzinb_bwd_workspace_bytes(int64_t B, int64_t G);
+int vae_nbzinb_bwd(int zinb, const float* logit_scale, int64_t ld_s, const float* logit_dropout, int64_t ld_p,
+                   const float* x, int64_t ld_x, const float* library, const float* gene_table, const float* rowmax,
+                   const float* rowsum, const float* S, const float* g_ll, float g_scalar, int64_t B, int64_t G,
+                   float* dlogit_scale, int64_t ld_ds, float* dlogit_dropout, int64_t ld_dp, float* dlibrary,
+                   float* dpx_r, float* dbias_scale, float* dbias_dropout, float* workspace, int64_t workspace_bytes,
+                   void* stream);
+
+/* ---- stand-alone pieces behind the module API ----------------------------------------------------
+ * (px_scale, px_rate) of DecoderSCVI.forward, modules.py:401-404, both (B,G) contiguous           */
+int vae_softmax_rate_fwd(const float* logit_scale, int64_t ld_s, const float* library, int64_t B, int64_t G,
+                         float* px_scale, float* px_rate, void* stream);
+int vae_softmax_rate_bwd(const float* px_scale, const float* library, const float* d_scale, const float* d_rate,
+                         int64_t B, int64_t G, float* dlogits, int64_t ld_d, float* dlibrary, void* stream);
+/* element-wise log_nb_positive / log_zinb_positive (distributions.py:65-90 / :22-62), eps = 1e-8;
+ * theta addressed as theta[b*ld_theta + g] (ld_theta = 0 broadcasts a (G,) vector)                */
+int vae_loglik_elem_fwd(int zinb, const float* x, int64_t ld_x, const float* mu, int64_t ld_mu, const float* theta,
+                        int64_t ld_theta, const float* pi, int64_t ld_pi, int64_t B, int64_t G, float* out,
+                        int64_t ld_out, void* stream);
+int vae_loglik_elem_bwd(int zinb, const float* gout, int64_t ld_g, const float* x, int64_t ld_x, const float* mu,
+                        int64_t ld_mu, const float* theta, int64_t ld_theta, const float* pi, int64_t ld_pi, int64_t B,
+                        int64_t G, float* dmu, float* dtheta, float* dpi, void* stream);
+
+/* ---- the whole training step -------------------------------------------------------------------
+ * LitVAE.training_step (task.py:453-502) for dispersion "gene", no batch covariates, dropout off:
+ * one call enqueues the forward, one the backward; all intermediates live in `workspace`.
+ * Parameter / gradient pointers follow the reference's state_dict (SURVEY.md par. 3.4); tensors the
+ * kernels address as one stacked matrix must be adjacent in memory (vae_amd/arena.py):
+ *   enc_w0 = [z_encoder.encoder.fc_layers.0.weight ; l_encoder.encoder.fc_layers.0.weight] (H+Hl, G)
+ *   hz_w   = [z_encoder.mean_encoder.weight ; z_encoder.var_encoder.weight]                 (L+1, H)
+ *   hl_w   = [l_encoder.mean_encoder.weight ; l_encoder.var_encoder.weight]                 (2, Hl)
+ *   heads_w= [decoder.px_scale_decoder.0.weight ; decoder.px_dropout_decoder.weight]        (2G, Hd)
+ *            (NB: the first G rows only), and the matching bias vectors.                          */
+#define VAE_MAX_LAYERS 4
+typedef struct {
+  int64_t B, G, H, Hl, L, Hd;
+  int32_t n_layers;  /* 1..VAE_MAX_LAYERS (z-encoder and decoder; the library encoder has 1)        */
+  int32_t zinb;      /* 1 = ZINB, 0 = NB                                                          */
+  int32_t precision; /* VAE_FP32 / VAE_BF16 for every GEMM                                         */
+  float l_mean, l_var;        /* prior of the library-size KL (task.py:230-231)                     */
+  float kl_weight;            /* task.py:213-220                                                    */
+  float gene_loss_coeff;      /* task.py:489                                                        */
+  float loss_scale;           /* multiplies every gradient (1 for plain training)                   */
+} vae_step_config;
+
+typedef struct {
+  float* px_r;                                   /* (G)                                              */
+  float *enc_w0, *enc_b0;                        /* (H+Hl, G), (H+Hl)                                */
+  float *encz_ln_g[VAE_MAX_LAYERS], *encz_ln_b[VAE_MAX_LAYERS]; /* z-encoder LayerNorm per layer (H)  */
+  float *encz_w[VAE_MAX_LAYERS], *encz_b[VAE_MAX_LAYERS];       /* layers >= 1: (H,H), (H); [0] unused */
+  float *encl_ln_g, *encl_ln_b;                  /* library-encoder LayerNorm (Hl)                   */
+  float *hz_w, *hz_b, *hl_w, *hl_b;              /* (L+1,H), (L+1), (2,Hl), (2)                      */
+  float *dec_w[VAE_MAX_LAYERS], *dec_b[VAE_MAX_LAYERS];         /* (Hd, L) / (Hd, Hd), (Hd)          */
+  float *dec_ln_g[VAE_MAX_LAYERS], *dec_ln_b[VAE_MAX_LAYERS];   /* (Hd)                              */
+  float *heads_w, *heads_b;                      /* (2G or G, Hd), (2G or G)                         */
+} vae_step_tensors;
+
+/* named slices of the workspace that a caller may read after the forward (offsets in floats)      */
+enum { VAE_WS_QZ_HEADS = 0, /* (B, L+1): [:, :L] = qz_m                                            */
+       VAE_WS_QZ_V, VAE_WS_Z, VAE_WS_KL_Z, VAE_WS_QL_HEADS, VAE_WS_QL_V, VAE_WS_LIBRARY, VAE_WS_KL_L,
+       VAE_WS_LL,      /* (B) log-likelihood row sums; recon = -ll                                 */
+       VAE_WS_SCALARS, /* 5 floats, see vae_elbo_reduce                                            */
+       VAE_WS_DZ_EXTRA,/* (B, L): written by the CALLER between forward and backward (cell heads)  */
+       VAE_WS_NSLICES };
+int64_t vae_elbo_step_workspace_bytes(const vae_step_config* cfg);
+int64_t vae_elbo_step_ws_offset(const vae_step_config* cfg, int slice);
+int vae_elbo_step_forward(const vae_step_config* cfg, const vae_step_tensors* params, const float* x, int64_t ldx,
+                          const float* eps_z, const float* eps_l, float* workspace, int64_t workspace_bytes,
+                          void* stream);
+/* grads: same layout as params; small tensors (biases, LayerNorm, px_r) are ACCUMULATED into, the
+ * weight matrices are overwritten.  use_dz_extra != 0 adds workspace[VAE_WS_DZ_EXTRA] to dz.
+ * event_heads_ready (nullable hipEvent_t) is recorded once the decoder-head weight gradient -- the
+ * largest all-reduce bucket -- has been enqueued.                                                   */
+int vae_elbo_step_backward(const vae_step_config* cfg, const vae_step_tensors* params, const vae_step_tensors* grads,
+                           const float* x, int64_t ldx, const float* eps_z, const float* eps_l, int use_dz_extra,
+                           float* workspace, int64_t workspace_bytes, void* event_heads_ready, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VAE_AMD_H */

@@ -38,9 +38,38 @@ SIGNATURES = {
                               _ptr, _i64, _ptr, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _i64, _ptr]),
     "vae_softmax_rate_fwd": (_i32, [_ptr, _i64, _ptr, _i64, _i64, _ptr, _ptr, _ptr]),
     "vae_softmax_rate_bwd": (_i32, [_ptr, _ptr, _ptr, _ptr, _i64, _i64, _ptr, _i64, _ptr, _ptr]),
+    "vae_add_inplace": (_i32, [_ptr, _ptr, _i64, _ptr]),
+    "vae_elbo_step_workspace_bytes": (_i64, [_ptr]),
+    "vae_elbo_step_ws_offset": (_i64, [_ptr, _i32]),
+    "vae_elbo_step_forward": (_i32, [_ptr, _ptr, _ptr, _i64, _ptr, _ptr, _ptr, _i64, _ptr]),
+    "vae_elbo_step_backward": (_i32, [_ptr, _ptr, _ptr, _ptr, _i64, _ptr, _ptr, _i32, _ptr, _i64, _ptr, _ptr]),
     "vae_loglik_elem_fwd": (_i32, [_i32, _ptr, _i64, _ptr, _i64, _ptr, _i64, _ptr, _i64, _i64, _i64, _ptr, _i64, _ptr]),
     "vae_loglik_elem_bwd": (_i32, [_i32, _ptr, _i64, _ptr, _i64, _ptr, _i64, _ptr, _i64, _ptr, _i64, _i64, _i64, _ptr, _ptr, _ptr, _ptr]),
 }
+
+VAE_MAX_LAYERS = 4
+_fp = C.POINTER(C.c_float)
+
+
+class StepConfig(C.Structure):
+    """vae_step_config of include/vae_amd.h"""
+    _fields_ = [("B", _i64), ("G", _i64), ("H", _i64), ("Hl", _i64), ("L", _i64), ("Hd", _i64),
+                ("n_layers", C.c_int32), ("zinb", C.c_int32), ("precision", C.c_int32),
+                ("l_mean", _f32), ("l_var", _f32), ("kl_weight", _f32), ("gene_loss_coeff", _f32), ("loss_scale", _f32)]
+
+
+class StepTensors(C.Structure):
+    """vae_step_tensors of include/vae_amd.h (device pointers as void*)"""
+    _A = _ptr * VAE_MAX_LAYERS
+    _fields_ = [("px_r", _ptr), ("enc_w0", _ptr), ("enc_b0", _ptr),
+                ("encz_ln_g", _A), ("encz_ln_b", _A), ("encz_w", _A), ("encz_b", _A),
+                ("encl_ln_g", _ptr), ("encl_ln_b", _ptr),
+                ("hz_w", _ptr), ("hz_b", _ptr), ("hl_w", _ptr), ("hl_b", _ptr),
+                ("dec_w", _A), ("dec_b", _A), ("dec_ln_g", _A), ("dec_ln_b", _A),
+                ("heads_w", _ptr), ("heads_b", _ptr)]
+
+
+WS_SLICES = ("QZ_HEADS", "QZ_V", "Z", "KL_Z", "QL_HEADS", "QL_V", "LIBRARY", "KL_L", "LL", "SCALARS", "DZ_EXTRA")
 
 _lib = None
 

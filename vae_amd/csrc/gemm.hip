@@ -13,10 +13,12 @@
 // x/mean - 1 (Encoder.forward, modules.py:264), so the normalised count matrix is never
 // materialised in HBM.
 //
-// Tile: 128x128x32 per 256-thread workgroup, 4 waves as 2x2, each wave a 64x64 output
-// (2x2 MFMA 32x32 accumulators).  Global->register prefetch of tile t+1 overlaps the MFMAs
-// of tile t; skinny shapes (K = genes) are split over K into fp32 slabs that a second
-// kernel sums in a fixed order (deterministic, no float atomics).
+// Tiles: 256-thread workgroups, 4 waves as 2x2.  Large shapes use 128x128x32 (each wave a 64x64
+// output = 2x2 MFMA 32x32 accumulators); the many small contractions of the step (latent heads,
+// decoder hidden layer: one dimension <= 64) use 64x64x32 (one accumulator per wave) so that
+// they spread over enough workgroups.  Global->register prefetch of tile t+1 overlaps the
+// MFMAs of tile t; skinny shapes (K = genes or cells) are split over K into fp32 slabs that a
+// second kernel sums in a fixed order (deterministic, no float atomics).
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -25,7 +27,7 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 32;
+constexpr int BK = 32;
 constexpr int NT = 0, NN = 1, TN = 2;
 
 struct GemmArgs {
@@ -43,19 +45,19 @@ struct GemmArgs {
   int tiles_n;
 };
 
-// ---- global -> register tile loaders (4 float4 per thread per operand) ------------------
+// ---- global -> register tile loaders (R*8/256 float4 per thread per operand, R = 64 or 128) ----
 // KC: operand stored (rows, K) row-major, k contiguous.  chunk c: row = c>>3, k4 = c&7.
-template <bool NORM>
+template <bool NORM, int R>
 __device__ __forceinline__ void load_kc(const float* __restrict__ X, int64_t ld, int r0, int rmax, int k0, int kend,
-                                        int vec, const float* __restrict__ mean, float4 (&reg)[4]) {
+                                        int vec, const float* __restrict__ mean, float4 (&reg)[R / 32]) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < R / 32; ++i) {
     const int c = threadIdx.x + 256 * i;
     const int r = r0 + (c >> 3), k = k0 + (c & 7) * 4;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (r < rmax && k < kend) {
       const float* p = X + (int64_t)r * ld + k;
-      bool m0 = true, m1 = k + 1 < kend, m2 = k + 2 < kend, m3 = k + 3 < kend;
+      const bool m1 = k + 1 < kend, m2 = k + 2 < kend, m3 = k + 3 < kend;
       if (vec && m3) {
         v = *reinterpret_cast<const float4*>(p);
       } else {
@@ -64,29 +66,29 @@ __device__ __forceinline__ void load_kc(const float* __restrict__ X, int64_t ld,
         if (m2) v.z = p[2];
         if (m3) v.w = p[3];
       }
-      if (NORM) {
-        const float mu = mean[r];
-        v.x = m0 ? v.x / mu - 1.f : 0.f;
-        v.y = m1 ? v.y / mu - 1.f : 0.f;
-        v.z = m2 ? v.z / mu - 1.f : 0.f;
-        v.w = m3 ? v.w / mu - 1.f : 0.f;
+      if (NORM) {  // x/mean - 1 as fma(x, 1/mean, -1): one reciprocal per 4 counts
+        const float inv = 1.f / mean[r];
+        v.x = fmaf(v.x, inv, -1.f);
+        v.y = m1 ? fmaf(v.y, inv, -1.f) : 0.f;
+        v.z = m2 ? fmaf(v.z, inv, -1.f) : 0.f;
+        v.w = m3 ? fmaf(v.w, inv, -1.f) : 0.f;
       }
     }
     reg[i] = v;
   }
 }
-// RC: operand stored (K, rows) row-major, row index contiguous.  chunk c: k = c>>5, r4 = c&31.
-template <bool NORM>
+// RC: operand stored (K, rows) row-major, row index contiguous.  chunk c: k = c / (R/4), r4 = c % (R/4).
+template <bool NORM, int R>
 __device__ __forceinline__ void load_rc(const float* __restrict__ X, int64_t ld, int r0, int rmax, int k0, int kend,
-                                        int vec, const float* __restrict__ mean, float4 (&reg)[4]) {
+                                        int vec, const float* __restrict__ mean, float4 (&reg)[R / 32]) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < R / 32; ++i) {
     const int c = threadIdx.x + 256 * i;
-    const int k = k0 + (c >> 5), r = r0 + (c & 31) * 4;
+    const int k = k0 + c / (R / 4), r = r0 + (c % (R / 4)) * 4;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (k < kend && r < rmax) {
       const float* p = X + (int64_t)k * ld + r;
-      bool m1 = r + 1 < rmax, m2 = r + 2 < rmax, m3 = r + 3 < rmax;
+      const bool m1 = r + 1 < rmax, m2 = r + 2 < rmax, m3 = r + 3 < rmax;
       if (vec && m3) {
         v = *reinterpret_cast<const float4*>(p);
       } else {
@@ -96,11 +98,11 @@ __device__ __forceinline__ void load_rc(const float* __restrict__ X, int64_t ld,
         if (m3) v.w = p[3];
       }
       if (NORM) {
-        const float mu = mean[k];
-        v.x = v.x / mu - 1.f;
-        v.y = m1 ? v.y / mu - 1.f : 0.f;
-        v.z = m2 ? v.z / mu - 1.f : 0.f;
-        v.w = m3 ? v.w / mu - 1.f : 0.f;
+        const float inv = 1.f / mean[k];
+        v.x = fmaf(v.x, inv, -1.f);
+        v.y = m1 ? fmaf(v.y, inv, -1.f) : 0.f;
+        v.z = m2 ? fmaf(v.z, inv, -1.f) : 0.f;
+        v.w = m3 ? fmaf(v.w, inv, -1.f) : 0.f;
       }
     }
     reg[i] = v;
@@ -108,36 +110,43 @@ __device__ __forceinline__ void load_rc(const float* __restrict__ X, int64_t ld,
 }
 
 // ---- fp32 LDS image: k-major [BK][LD] floats; operand reads are conflict-free ds_read_b32 ----
-constexpr int LD32_KC = 130;  // filled by 4-byte scatter writes (2-way on writes: free)
-constexpr int LD32_RC = 132;  // filled by 16-byte row writes (needs LD % 4 == 0)
+template <int R> struct Ld32 {
+  static constexpr int KC = R + 2;  // filled by 4-byte scatter writes (2-way on writes: free)
+  static constexpr int RC = R + 4;  // filled by 16-byte row writes (needs LD % 4 == 0)
+};
 
-__device__ __forceinline__ void store32_kc(float* s, const float4 (&reg)[4]) {
+template <int R>
+__device__ __forceinline__ void store32_kc(float* s, const float4 (&reg)[R / 32]) {
+  constexpr int LD = Ld32<R>::KC;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < R / 32; ++i) {
     const int c = threadIdx.x + 256 * i;
     const int r = c >> 3, k = (c & 7) * 4;
-    s[(k + 0) * LD32_KC + r] = reg[i].x;
-    s[(k + 1) * LD32_KC + r] = reg[i].y;
-    s[(k + 2) * LD32_KC + r] = reg[i].z;
-    s[(k + 3) * LD32_KC + r] = reg[i].w;
+    s[(k + 0) * LD + r] = reg[i].x;
+    s[(k + 1) * LD + r] = reg[i].y;
+    s[(k + 2) * LD + r] = reg[i].z;
+    s[(k + 3) * LD + r] = reg[i].w;
   }
 }
-__device__ __forceinline__ void store32_rc(float* s, const float4 (&reg)[4]) {
+template <int R>
+__device__ __forceinline__ void store32_rc(float* s, const float4 (&reg)[R / 32]) {
+  constexpr int LD = Ld32<R>::RC;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < R / 32; ++i) {
     const int c = threadIdx.x + 256 * i;
-    const int k = c >> 5, r = (c & 31) * 4;
-    *reinterpret_cast<float4*>(&s[k * LD32_RC + r]) = reg[i];
+    const int k = c / (R / 4), r = (c % (R / 4)) * 4;
+    *reinterpret_cast<float4*>(&s[k * LD + r]) = reg[i];
   }
 }
 
-// ---- bf16 LDS image: row-major [128][LD16] bf16, k contiguous; 80-byte rows make the
+// ---- bf16 LDS image: row-major [R][LD16] bf16, k contiguous; 80-byte rows make the
 //      ds_read_b128 fragment reads conflict-free (5*row mod 16 is a bijection on 16 rows) ----
 constexpr int LD16 = 40;
 
-__device__ __forceinline__ void store16_kc(__bf16* s, const float4 (&reg)[4]) {
+template <int R>
+__device__ __forceinline__ void store16_kc(__bf16* s, const float4 (&reg)[R / 32]) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < R / 32; ++i) {
     const int c = threadIdx.x + 256 * i;
     const int r = c >> 3, k = (c & 7) * 4;
     bf16x4 v;
@@ -145,11 +154,12 @@ __device__ __forceinline__ void store16_kc(__bf16* s, const float4 (&reg)[4]) {
     *reinterpret_cast<bf16x4*>(&s[r * LD16 + k]) = v;
   }
 }
-__device__ __forceinline__ void store16_rc(__bf16* s, const float4 (&reg)[4]) {
+template <int R>
+__device__ __forceinline__ void store16_rc(__bf16* s, const float4 (&reg)[R / 32]) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < R / 32; ++i) {
     const int c = threadIdx.x + 256 * i;
-    const int k = c >> 5, r = (c & 31) * 4;
+    const int k = c / (R / 4), r = (c % (R / 4)) * 4;
     s[(r + 0) * LD16 + k] = (__bf16)reg[i].x;
     s[(r + 1) * LD16 + k] = (__bf16)reg[i].y;
     s[(r + 2) * LD16 + k] = (__bf16)reg[i].z;
@@ -157,15 +167,17 @@ __device__ __forceinline__ void store16_rc(__bf16* s, const float4 (&reg)[4]) {
   }
 }
 
-constexpr int SMEM32 = BK * (LD32_RC > LD32_KC ? LD32_RC : LD32_KC);  // floats per operand
-constexpr int SMEM16 = 128 * LD16;                                       // bf16 per operand
-
-template <int LAYOUT, int PREC, bool NORM>
+// TW = MFMA 32x32 accumulators per wave per dimension: 2 -> 128x128 tile, 1 -> 64x64 tile
+template <int LAYOUT, int PREC, bool NORM, int TW>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
+  constexpr int R = 64 * TW;  // tile rows (= BM = BN)
+  constexpr int NR = R / 32;  // float4 registers per thread per operand
   constexpr bool A_KC = (LAYOUT != TN);
   constexpr bool B_KC = (LAYOUT == NT);
   constexpr bool NORM_A = NORM && LAYOUT == NT;
   constexpr bool NORM_B = NORM && LAYOUT == TN;
+  constexpr int SMEM32 = BK * Ld32<R>::RC;  // floats per operand (RC >= KC)
+  constexpr int SMEM16 = R * LD16;          // bf16 per operand
 
   __shared__ __attribute__((aligned(16))) float smem[PREC == 0 ? 2 * SMEM32 : SMEM16];
   float* sA32 = smem;
@@ -174,7 +186,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
   __bf16* sB16 = sA16 + SMEM16;
 
   const int tile = blockIdx.x;
-  const int m0 = (tile / g.tiles_n) * BM, n0 = (tile % g.tiles_n) * BN;
+  const int m0 = (tile / g.tiles_n) * R, n0 = (tile % g.tiles_n) * R;
   const int s = blockIdx.y;
   const int kbeg = s * g.k_per_split;
   const int kend = min(g.K, kbeg + g.k_per_split);
@@ -183,62 +195,70 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
   const int wm = wave >> 1, wn = wave & 1;
   const int l31 = lane & 31, h = lane >> 5;
 
-  f32x16 acc[2][2];
+  f32x16 acc[TW][TW];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < TW; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < TW; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  float4 ra[4], rb[4];
+  float4 ra[NR], rb[NR];
   auto fetch = [&](int k0) {
-    if (A_KC) load_kc<NORM_A>(g.A, g.lda, m0, g.M, k0, kend, g.vecA, g.mean, ra);
-    else      load_rc<false>(g.A, g.lda, m0, g.M, k0, kend, g.vecA, nullptr, ra);
-    if (B_KC) load_kc<false>(g.B, g.ldb, n0, g.N, k0, kend, g.vecB, nullptr, rb);
-    else      load_rc<NORM_B>(g.B, g.ldb, n0, g.N, k0, kend, g.vecB, g.mean, rb);
+    if (A_KC) load_kc<NORM_A, R>(g.A, g.lda, m0, g.M, k0, kend, g.vecA, g.mean, ra);
+    else      load_rc<false, R>(g.A, g.lda, m0, g.M, k0, kend, g.vecA, nullptr, ra);
+    if (B_KC) load_kc<false, R>(g.B, g.ldb, n0, g.N, k0, kend, g.vecB, nullptr, rb);
+    else      load_rc<NORM_B, R>(g.B, g.ldb, n0, g.N, k0, kend, g.vecB, g.mean, rb);
   };
 
   if (kbeg < kend) fetch(kbeg);
   for (int k0 = kbeg; k0 < kend; k0 += BK) {
     __syncthreads();  // previous tile's fragment reads are done
     if (PREC == 0) {
-      if (A_KC) store32_kc(sA32, ra); else store32_rc(sA32, ra);
-      if (B_KC) store32_kc(sB32, rb); else store32_rc(sB32, rb);
+      if (A_KC) store32_kc<R>(sA32, ra); else store32_rc<R>(sA32, ra);
+      if (B_KC) store32_kc<R>(sB32, rb); else store32_rc<R>(sB32, rb);
     } else {
-      if (A_KC) store16_kc(sA16, ra); else store16_rc(sA16, ra);
-      if (B_KC) store16_kc(sB16, rb); else store16_rc(sB16, rb);
+      if (A_KC) store16_kc<R>(sA16, ra); else store16_rc<R>(sA16, ra);
+      if (B_KC) store16_kc<R>(sB16, rb); else store16_rc<R>(sB16, rb);
     }
     __syncthreads();
     if (k0 + BK < kend) fetch(k0 + BK);  // in flight during the MFMAs below
 
     if (PREC == 0) {
-      constexpr int LDA = A_KC ? LD32_KC : LD32_RC;
-      constexpr int LDB = B_KC ? LD32_KC : LD32_RC;
-      const float* pa = sA32 + h * LDA + wm * 64 + l31;
-      const float* pb = sB32 + h * LDB + wn * 64 + l31;
+      constexpr int LDA = A_KC ? Ld32<R>::KC : Ld32<R>::RC;
+      constexpr int LDB = B_KC ? Ld32<R>::KC : Ld32<R>::RC;
+      const float* pa = sA32 + h * LDA + wm * (32 * TW) + l31;
+      const float* pb = sB32 + h * LDB + wn * (32 * TW) + l31;
 #pragma unroll
       for (int kk = 0; kk < BK / 2; ++kk) {
-        const float a0 = pa[kk * 2 * LDA], a1 = pa[kk * 2 * LDA + 32];
-        const float b0 = pb[kk * 2 * LDB], b1 = pb[kk * 2 * LDB + 32];
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        float a[TW], b[TW];
+#pragma unroll
+        for (int t = 0; t < TW; ++t) {
+          a[t] = pa[kk * 2 * LDA + 32 * t];
+          b[t] = pb[kk * 2 * LDB + 32 * t];
+        }
+#pragma unroll
+        for (int i = 0; i < TW; ++i)
+#pragma unroll
+          for (int j = 0; j < TW; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
       }
     } else {
-      const __bf16* pa = sA16 + (wm * 64 + l31) * LD16 + h * 8;
-      const __bf16* pb = sB16 + (wn * 64 + l31) * LD16 + h * 8;
+      const __bf16* pa = sA16 + (wm * (32 * TW) + l31) * LD16 + h * 8;
+      const __bf16* pb = sB16 + (wn * (32 * TW) + l31) * LD16 + h * 8;
 #pragma unroll
       for (int ks = 0; ks < BK / 16; ++ks) {
-        const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(pa + ks * 16);
-        const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(pa + 32 * LD16 + ks * 16);
-        const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(pb + ks * 16);
-        const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(pb + 32 * LD16 + ks * 16);
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+        bf16x8 a[TW], b[TW];
+#pragma unroll
+        for (int t = 0; t < TW; ++t) {
+          a[t] = *reinterpret_cast<const bf16x8*>(pa + 32 * t * LD16 + ks * 16);
+          b[t] = *reinterpret_cast<const bf16x8*>(pb + 32 * t * LD16 + ks * 16);
+        }
+#pragma unroll
+        for (int i = 0; i < TW; ++i)
+#pragma unroll
+          for (int j = 0; j < TW; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
       }
     }
   }
@@ -251,15 +271,15 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
     ldc = g.N;
   }
 #pragma unroll
-  for (int mi = 0; mi < 2; ++mi)
+  for (int mi = 0; mi < TW; ++mi)
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-      const int n = n0 + wn * 64 + ni * 32 + l31;
+    for (int ni = 0; ni < TW; ++ni) {
+      const int n = n0 + wn * (32 * TW) + ni * 32 + l31;
       if (n >= g.N) continue;
       const float bv = (g.split == 1 && g.bias) ? g.bias[n] : 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const int m = m0 + wm * (32 * TW) + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
         if (m < g.M) {
           float* p = out + (int64_t)m * ldc + n;
           float v = acc[mi][ni][r] + bv;
@@ -285,28 +305,44 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ ws, int split, in
   }
 }
 
-int choose_split(int M, int N, int K) {
-  const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
-  if (tiles >= 192) return 1;
+// Tile size and K split for a shape.  small = 64x64 tiles (one dimension <= 64, or little work).
+struct Plan { int tile; int split; };
+Plan make_plan(int M, int N, int K) {
+  Plan p;
+  const bool small = (M <= 64 || N <= 64) || (2.0 * M * N * K < 2e8);
+  p.tile = small ? 64 : 128;
+  const int tiles = ((M + p.tile - 1) / p.tile) * ((N + p.tile - 1) / p.tile);
   const int ktiles = (K + BK - 1) / BK;
-  int split = (512 + tiles - 1) / tiles;       // ~2 workgroups per CU
-  const int max_split = ktiles / 4 > 0 ? ktiles / 4 : 1;  // >= 4 K-tiles (128 k) per slab
-  if (split > max_split) split = max_split;
-  if (split > 64) split = 64;
-  return split < 1 ? 1 : split;
+  const int target = small ? 256 : 512;               // workgroups wanted on the chip
+  const int min_ktiles = small ? 2 : 4;                // K-tiles per slab at least
+  int split = 1;
+  if (tiles < (small ? 128 : 192)) {
+    split = (target + tiles - 1) / tiles;
+    const int max_split = ktiles / min_ktiles > 0 ? ktiles / min_ktiles : 1;
+    if (split > max_split) split = max_split;
+    if (split > 64) split = 64;
+    if (split < 1) split = 1;
+  }
+  p.split = split;
+  return p;
 }
 
-template <int LAYOUT, int PREC>
+template <int LAYOUT, int PREC, int TW>
 void launch(const GemmArgs& g, bool norm, dim3 grid, hipStream_t st) {
-  if (norm) hipLaunchKernelGGL((gemm_kernel<LAYOUT, PREC, true>), grid, dim3(256), 0, st, g);
-  else      hipLaunchKernelGGL((gemm_kernel<LAYOUT, PREC, false>), grid, dim3(256), 0, st, g);
+  if (norm) hipLaunchKernelGGL((gemm_kernel<LAYOUT, PREC, true, TW>), grid, dim3(256), 0, st, g);
+  else      hipLaunchKernelGGL((gemm_kernel<LAYOUT, PREC, false, TW>), grid, dim3(256), 0, st, g);
+}
+template <int LAYOUT, int PREC>
+void launch_t(const GemmArgs& g, bool norm, dim3 grid, hipStream_t st, int tile) {
+  if (tile == 128) launch<LAYOUT, PREC, 2>(g, norm, grid, st);
+  else             launch<LAYOUT, PREC, 1>(g, norm, grid, st);
 }
 
 }  // namespace
 
 extern "C" int64_t vae_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K) {
-  const int split = choose_split((int)M, (int)N, (int)K);
-  return split > 1 ? (int64_t)split * M * N * (int64_t)sizeof(float) : 0;
+  const Plan p = make_plan((int)M, (int)N, (int)K);
+  return p.split > 1 ? (int64_t)p.split * M * N * (int64_t)sizeof(float) : 0;
 }
 
 extern "C" int vae_gemm(int layout, int precision, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
@@ -329,9 +365,10 @@ extern "C" int vae_gemm(int layout, int precision, int64_t M, int64_t N, int64_t
   g.accumulate = accumulate;
   g.vecA = (lda % 4 == 0) && vae_aligned16(A);
   g.vecB = (ldb % 4 == 0) && vae_aligned16(B);
-  const int tiles_m = (g.M + BM - 1) / BM;
-  g.tiles_n = (g.N + BN - 1) / BN;
-  int split = choose_split(g.M, g.N, g.K);
+  const Plan plan = make_plan(g.M, g.N, g.K);
+  const int tiles_m = (g.M + plan.tile - 1) / plan.tile;
+  g.tiles_n = (g.N + plan.tile - 1) / plan.tile;
+  int split = plan.split;
   const int ktiles = (g.K + BK - 1) / BK;
   const int tiles_per_split = (ktiles + split - 1) / split;
   g.k_per_split = tiles_per_split * BK;
@@ -348,13 +385,13 @@ extern "C" int vae_gemm(int layout, int precision, int64_t M, int64_t N, int64_t
   dim3 grid(tiles_m * g.tiles_n, split);
   const bool norm = x_mean != nullptr;
   if (precision == 0) {
-    if (layout == NT) launch<NT, 0>(g, norm, grid, st);
-    else if (layout == NN) launch<NN, 0>(g, false, grid, st);
-    else launch<TN, 0>(g, norm, grid, st);
+    if (layout == NT) launch_t<NT, 0>(g, norm, grid, st, plan.tile);
+    else if (layout == NN) launch_t<NN, 0>(g, false, grid, st, plan.tile);
+    else launch_t<TN, 0>(g, norm, grid, st, plan.tile);
   } else {
-    if (layout == NT) launch<NT, 1>(g, norm, grid, st);
-    else if (layout == NN) launch<NN, 1>(g, false, grid, st);
-    else launch<TN, 1>(g, norm, grid, st);
+    if (layout == NT) launch_t<NT, 1>(g, norm, grid, st, plan.tile);
+    else if (layout == NN) launch_t<NN, 1>(g, false, grid, st, plan.tile);
+    else launch_t<TN, 1>(g, norm, grid, st, plan.tile);
   }
   VAE_CHECK_LAUNCH("vae_gemm");
   if (split > 1) {

@@ -229,6 +229,11 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ i
   atomicAdd(out + n, s);
 }
 
+__global__ void add_inplace_kernel(const float* __restrict__ src, float* __restrict__ dst, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    dst[i] += src[i];
+}
+
 // ---------------------------------------------------------------------------------------
 // ELBO reduction (LitVAE.gene_loss task.py:202 and training_step :489):
 //   out[0] = mean(recon) = -mean(ll), out[1] = mean(kl_z), out[2] = mean(kl_l),
@@ -340,5 +345,14 @@ extern "C" int vae_elbo_reduce(const float* ll, const float* kl_z, const float* 
   hipLaunchKernelGGL(elbo_reduce_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, ll, kl_z, kl_l, (int)B, kl_weight,
                      gene_loss_coeff, out5);
   VAE_CHECK_LAUNCH("vae_elbo_reduce");
+  return VAE_OK;
+}
+
+extern "C" int vae_add_inplace(const float* src, float* dst, int64_t n, void* stream) {
+  VAE_REQUIRE(src && dst && n > 0, "vae_add_inplace: bad arguments");
+  int blocks = (int)((n + 255) / 256);
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(add_inplace_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, dst, n);
+  VAE_CHECK_LAUNCH("vae_add_inplace");
   return VAE_OK;
 }

@@ -1,0 +1,260 @@
+// The fused training step as ONE native call per direction: LitVAE.training_step
+// (reference task.py:453-502) = encoders -> decoder -> NB/ZINB + KL -> loss, and its backward,
+// enqueued on a HIP stream as a fixed launch sequence over a caller-provided workspace.
+// No allocation, no host synchronisation: safe to replay in a tight loop (or to capture).
+#include "../../include/vae_amd.h"
+#include "common.h"
+
+#include <string.h>
+
+namespace {
+
+struct Layout {
+  // offsets in floats into the workspace
+  int64_t mean, pre_enc0, h_enc0, ln_mz[VAE_MAX_LAYERS], ln_rz[VAE_MAX_LAYERS], ln_ml, ln_rl;
+  int64_t encz_pre[VAE_MAX_LAYERS], encz_h[VAE_MAX_LAYERS];  // layers >= 1
+  int64_t heads_z, heads_l, qz_v, z, kl_z, ql_v, library, kl_l;
+  int64_t dec_pre[VAE_MAX_LAYERS], dec_h[VAE_MAX_LAYERS], ln_md[VAE_MAX_LAYERS], ln_rd[VAE_MAX_LAYERS];
+  int64_t logits, table, ll, rowmax, rowsum, S, scalars;
+  int64_t dz_extra, dlibrary, dheads_z, dheads_l, dpre_enc0, dh, dpx, dz;
+  int64_t scratch;        // split-K slabs / column-sum slabs (shared, used by one launch at a time)
+  int64_t scratch_floats;
+  int64_t total;
+};
+
+inline int64_t up4(int64_t v) { return (v + 3) & ~(int64_t)3; }
+inline int64_t maxi(int64_t a, int64_t b) { return a > b ? a : b; }
+
+bool make_layout(const vae_step_config& c, Layout* lo) {
+  if (c.B <= 0 || c.G <= 0 || c.H <= 0 || c.Hl <= 0 || c.L <= 0 || c.Hd <= 0) return false;
+  if (c.n_layers < 1 || c.n_layers > VAE_MAX_LAYERS) return false;
+  int64_t off = 0;
+  auto take = [&](int64_t n) { const int64_t o = off; off = up4(off + n); return o; };
+  const int64_t B = c.B, G = c.G, H = c.H, Hl = c.Hl, L = c.L, Hd = c.Hd;
+  const int64_t NH = c.zinb ? 2 * G : G;
+  lo->mean = take(B);
+  lo->pre_enc0 = take(B * (H + Hl));
+  lo->h_enc0 = take(B * (H + Hl));
+  for (int n = 0; n < c.n_layers; ++n) { lo->ln_mz[n] = take(B); lo->ln_rz[n] = take(B); }
+  lo->ln_ml = take(B); lo->ln_rl = take(B);
+  for (int n = 1; n < c.n_layers; ++n) { lo->encz_pre[n] = take(B * H); lo->encz_h[n] = take(B * H); }
+  lo->heads_z = take(B * (L + 1)); lo->heads_l = take(B * 2);
+  lo->qz_v = take(B); lo->z = take(B * L); lo->kl_z = take(B);
+  lo->ql_v = take(B); lo->library = take(B); lo->kl_l = take(B);
+  for (int n = 0; n < c.n_layers; ++n) {
+    lo->dec_pre[n] = take(B * Hd); lo->dec_h[n] = take(B * Hd); lo->ln_md[n] = take(B); lo->ln_rd[n] = take(B);
+  }
+  lo->logits = take(B * NH);
+  lo->table = take(vae_gene_table_rows() * G);
+  lo->ll = take(B); lo->rowmax = take(B); lo->rowsum = take(B); lo->S = take(B); lo->scalars = take(8);
+  lo->dz_extra = take(B * L); lo->dlibrary = take(B);
+  lo->dheads_z = take(B * (L + 1)); lo->dheads_l = take(B * 2);
+  lo->dpre_enc0 = take(B * (H + Hl)); lo->dh = take(B * H); lo->dpx = take(B * Hd); lo->dz = take(B * L);
+  // scratch: the largest split-K / column-slab need of any launch in the step
+  int64_t s = 0;
+  auto gw = [&](int64_t M, int64_t N, int64_t K) { s = maxi(s, vae_gemm_workspace_bytes(M, N, K)); };
+  gw(B, H + Hl, G); gw(H + Hl, G, B);                       // encoder first layer fwd / wgrad
+  gw(B, H, H); gw(H, H, B);                                 // deeper encoder layers
+  gw(B, L + 1, H); gw(L + 1, H, B); gw(B, H, L + 1);        // z heads
+  gw(B, 2, Hl); gw(2, Hl, B); gw(B, Hl, 2);                 // library heads
+  gw(B, Hd, L); gw(Hd, L, B); gw(B, L, Hd);                 // decoder first layer
+  gw(B, Hd, Hd); gw(Hd, Hd, B);                             // deeper decoder layers
+  gw(B, NH, Hd); gw(NH, Hd, B); gw(B, Hd, NH);              // decoder heads
+  s = maxi(s, vae_nbzinb_bwd_workspace_bytes(B, G));
+  lo->scratch_floats = up4(s / 4 + 4);
+  lo->scratch = take(lo->scratch_floats);
+  lo->total = off;
+  return true;
+}
+
+#define TRY(call)               \
+  do {                          \
+    const int rc__ = (call);    \
+    if (rc__ != VAE_OK) return rc__; \
+  } while (0)
+
+struct Ctx {
+  const vae_step_config& c;
+  float* ws;
+  Layout lo;
+  void* st;
+  int gemm(int layout, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* Bm, int64_t ldb,
+           float* C, int64_t ldc, const float* bias, const float* mean, int acc) const {
+    return vae_gemm(layout, c.precision, M, N, K, A, lda, Bm, ldb, C, ldc, bias, mean, acc, ws + lo.scratch,
+                    lo.scratch_floats * 4, st);
+  }
+};
+
+int check_common(const vae_step_config* cfg, const void* a, const void* b, const float* x, int64_t ldx,
+                 const float* eps_z, const float* eps_l, float* ws, int64_t ws_bytes, Layout* lo, const char* who) {
+  if (!cfg || !a || !b || !x || !eps_z || !eps_l || !ws) return vae_set_error(VAE_ERR_ARG, "%s: null pointer", who);
+  if (!make_layout(*cfg, lo)) return vae_set_error(VAE_ERR_ARG, "%s: bad configuration", who);
+  if (ldx < cfg->G) return vae_set_error(VAE_ERR_ARG, "%s: ldx < G", who);
+  if (cfg->G > vae_nbzinb_max_genes())
+    return vae_set_error(VAE_ERR_ARG, "%s: G=%lld exceeds %lld", who, (long long)cfg->G, (long long)vae_nbzinb_max_genes());
+  if (!(cfg->l_var > 0.f)) return vae_set_error(VAE_ERR_ARG, "%s: l_var must be positive", who);
+  if (ws_bytes < lo->total * 4)
+    return vae_set_error(VAE_ERR_ARG, "%s: workspace too small: %lld < %lld bytes", who, (long long)ws_bytes,
+                         (long long)(lo->total * 4));
+  if (!vae_aligned16(ws)) return vae_set_error(VAE_ERR_ARG, "%s: workspace must be 16-byte aligned", who);
+  return VAE_OK;
+}
+
+}  // namespace
+
+extern "C" int64_t vae_elbo_step_workspace_bytes(const vae_step_config* cfg) {
+  Layout lo;
+  if (!cfg || !make_layout(*cfg, &lo)) return -1;
+  return lo.total * 4;
+}
+
+extern "C" int64_t vae_elbo_step_ws_offset(const vae_step_config* cfg, int slice) {
+  Layout lo;
+  if (!cfg || !make_layout(*cfg, &lo)) return -1;
+  switch (slice) {
+    case VAE_WS_QZ_HEADS: return lo.heads_z;
+    case VAE_WS_QZ_V: return lo.qz_v;
+    case VAE_WS_Z: return lo.z;
+    case VAE_WS_KL_Z: return lo.kl_z;
+    case VAE_WS_QL_HEADS: return lo.heads_l;
+    case VAE_WS_QL_V: return lo.ql_v;
+    case VAE_WS_LIBRARY: return lo.library;
+    case VAE_WS_KL_L: return lo.kl_l;
+    case VAE_WS_LL: return lo.ll;
+    case VAE_WS_SCALARS: return lo.scalars;
+    case VAE_WS_DZ_EXTRA: return lo.dz_extra;
+    default: return -1;
+  }
+}
+
+extern "C" int vae_elbo_step_forward(const vae_step_config* cfg, const vae_step_tensors* p, const float* x, int64_t ldx,
+                                     const float* eps_z, const float* eps_l, float* ws, int64_t ws_bytes, void* stream) {
+  Layout lo;
+  TRY(check_common(cfg, p, p, x, ldx, eps_z, eps_l, ws, ws_bytes, &lo, "vae_elbo_step_forward"));
+  const vae_step_config& c = *cfg;
+  const Ctx k{c, ws, lo, stream};
+  const int64_t B = c.B, G = c.G, H = c.H, Hl = c.Hl, L = c.L, Hd = c.Hd, HE = c.H + c.Hl;
+  const int64_t NH = c.zinb ? 2 * G : G;
+
+  // encoders: x/mean-1 -> Linear(G, H+Hl) -> GELU -> LayerNorm (z and library halves)
+  TRY(vae_row_mean(x, ldx, B, G, ws + lo.mean, stream));
+  TRY(k.gemm(VAE_NT, B, HE, G, x, ldx, p->enc_w0, G, ws + lo.pre_enc0, HE, p->enc_b0, ws + lo.mean, 0));
+  TRY(vae_gelu_ln_fwd(ws + lo.pre_enc0, HE, p->encz_ln_g[0], p->encz_ln_b[0], B, H, ws + lo.h_enc0, HE,
+                      ws + lo.ln_mz[0], ws + lo.ln_rz[0], stream));
+  TRY(vae_gelu_ln_fwd(ws + lo.pre_enc0 + H, HE, p->encl_ln_g, p->encl_ln_b, B, Hl, ws + lo.h_enc0 + H, HE,
+                      ws + lo.ln_ml, ws + lo.ln_rl, stream));
+  const float* hz = ws + lo.h_enc0;
+  int64_t ld_hz = HE;
+  for (int n = 1; n < c.n_layers; ++n) {
+    TRY(k.gemm(VAE_NT, B, H, H, hz, ld_hz, p->encz_w[n], H, ws + lo.encz_pre[n], H, p->encz_b[n], nullptr, 0));
+    TRY(vae_gelu_ln_fwd(ws + lo.encz_pre[n], H, p->encz_ln_g[n], p->encz_ln_b[n], B, H, ws + lo.encz_h[n], H,
+                        ws + lo.ln_mz[n], ws + lo.ln_rz[n], stream));
+    hz = ws + lo.encz_h[n];
+    ld_hz = H;
+  }
+  // latent heads + reparameterisation + KL
+  TRY(k.gemm(VAE_NT, B, L + 1, H, hz, ld_hz, p->hz_w, H, ws + lo.heads_z, L + 1, p->hz_b, nullptr, 0));
+  TRY(k.gemm(VAE_NT, B, 2, Hl, ws + lo.h_enc0 + H, HE, p->hl_w, Hl, ws + lo.heads_l, 2, p->hl_b, nullptr, 0));
+  TRY(vae_reparam_kl_fwd(ws + lo.heads_z, L + 1, eps_z, L, B, L, 0.f, 1.f, ws + lo.qz_v, ws + lo.z, L, ws + lo.kl_z, stream));
+  TRY(vae_reparam_kl_fwd(ws + lo.heads_l, 2, eps_l, 1, B, 1, c.l_mean, c.l_var, ws + lo.ql_v, ws + lo.library, 1,
+                         ws + lo.kl_l, stream));
+  // decoder hidden layers
+  const float* px = ws + lo.z;
+  int64_t kin = L;
+  for (int n = 0; n < c.n_layers; ++n) {
+    TRY(k.gemm(VAE_NT, B, Hd, kin, px, kin, p->dec_w[n], kin, ws + lo.dec_pre[n], Hd, p->dec_b[n], nullptr, 0));
+    TRY(vae_gelu_ln_fwd(ws + lo.dec_pre[n], Hd, p->dec_ln_g[n], p->dec_ln_b[n], B, Hd, ws + lo.dec_h[n], Hd,
+                        ws + lo.ln_md[n], ws + lo.ln_rd[n], stream));
+    px = ws + lo.dec_h[n];
+    kin = Hd;
+  }
+  // decoder heads -> fused softmax / library scale / NB-ZINB / row sum -> ELBO scalars
+  TRY(k.gemm(VAE_NT, B, NH, Hd, px, Hd, p->heads_w, Hd, ws + lo.logits, NH, p->heads_b, nullptr, 0));
+  TRY(vae_gene_table(p->px_r, G, ws + lo.table, stream));
+  TRY(vae_nbzinb_fwd(c.zinb, ws + lo.logits, NH, c.zinb ? ws + lo.logits + G : nullptr, NH, x, ldx, ws + lo.library,
+                     ws + lo.table, B, G, ws + lo.ll, ws + lo.rowmax, ws + lo.rowsum, ws + lo.S, stream));
+  TRY(vae_elbo_reduce(ws + lo.ll, ws + lo.kl_z, ws + lo.kl_l, B, c.kl_weight, c.gene_loss_coeff, ws + lo.scalars, stream));
+  return VAE_OK;
+}
+
+extern "C" int vae_elbo_step_backward(const vae_step_config* cfg, const vae_step_tensors* p, const vae_step_tensors* g,
+                                      const float* x, int64_t ldx, const float* eps_z, const float* eps_l,
+                                      int use_dz_extra, float* ws, int64_t ws_bytes, void* event_heads_ready,
+                                      void* stream) {
+  Layout lo;
+  TRY(check_common(cfg, p, g, x, ldx, eps_z, eps_l, ws, ws_bytes, &lo, "vae_elbo_step_backward"));
+  const vae_step_config& c = *cfg;
+  const Ctx k{c, ws, lo, stream};
+  const int64_t B = c.B, G = c.G, H = c.H, Hl = c.Hl, L = c.L, Hd = c.Hd, HE = c.H + c.Hl;
+  const int64_t NH = c.zinb ? 2 * G : G;
+  // d loss / d ll[b] = -coeff/B ; d loss / d kl[b] = coeff*kl_weight/B   (task.py:202,489)
+  const float g_ll = -c.gene_loss_coeff / (float)B * c.loss_scale;
+  const float g_kl = c.gene_loss_coeff * c.kl_weight / (float)B * c.loss_scale;
+  float* logits = ws + lo.logits;
+  float* lp = c.zinb ? logits + G : nullptr;
+
+  // epilogue backward: logits := dlogits (in place)
+  TRY(vae_nbzinb_bwd(c.zinb, logits, NH, lp, NH, x, ldx, ws + lo.library, ws + lo.table, ws + lo.rowmax, ws + lo.rowsum,
+                     ws + lo.S, nullptr, g_ll, B, G, logits, NH, lp, NH, ws + lo.dlibrary, g->px_r, g->heads_b,
+                     c.zinb ? g->heads_b + G : nullptr, ws + lo.scratch, lo.scratch_floats * 4, stream));
+  const float* px = ws + lo.dec_h[c.n_layers - 1];
+  TRY(k.gemm(VAE_TN, NH, Hd, B, logits, NH, px, Hd, g->heads_w, Hd, nullptr, nullptr, 0));  // dW = dlogits^T px
+  if (event_heads_ready) {
+    if (hipEventRecord((hipEvent_t)event_heads_ready, (hipStream_t)stream) != hipSuccess)
+      return vae_set_error(VAE_ERR_LAUNCH, "vae_elbo_step_backward: hipEventRecord failed");
+  }
+  TRY(k.gemm(VAE_NN, B, Hd, NH, logits, NH, p->heads_w, Hd, ws + lo.dpx, Hd, nullptr, nullptr, 0));
+
+  // decoder hidden layers
+  float* dcur = ws + lo.dpx;
+  for (int n = c.n_layers - 1; n >= 0; --n) {
+    const float* inp = n == 0 ? ws + lo.z : ws + lo.dec_h[n - 1];
+    const int64_t kin = n == 0 ? L : Hd;
+    TRY(vae_gelu_ln_bwd(dcur, Hd, ws + lo.dec_pre[n], Hd, ws + lo.ln_md[n], ws + lo.ln_rd[n], p->dec_ln_g[n], B, Hd, dcur,
+                        Hd, g->dec_ln_g[n], g->dec_ln_b[n], g->dec_b[n], stream));
+    TRY(k.gemm(VAE_TN, Hd, kin, B, dcur, Hd, inp, kin, g->dec_w[n], kin, nullptr, nullptr, 0));
+    if (n > 0) {
+      // dgrad into the scratch-free buffer of the layer below: reuse dec_pre[n] (no longer needed)
+      float* nxt = ws + lo.dec_pre[n];
+      TRY(k.gemm(VAE_NN, B, Hd, Hd, dcur, Hd, p->dec_w[n], Hd, nxt, Hd, nullptr, nullptr, 0));
+      dcur = nxt;
+    } else {
+      TRY(k.gemm(VAE_NN, B, L, Hd, dcur, Hd, p->dec_w[0], L, ws + lo.dz, L, nullptr, nullptr, 0));
+    }
+  }
+  // reparameterisation / KL backward (cell-head gradient enters through dz_extra)
+  const float* dz = ws + lo.dz;
+  if (use_dz_extra) TRY(vae_add_inplace(ws + lo.dz_extra, ws + lo.dz, B * L, stream));
+  TRY(vae_reparam_kl_bwd(dz, L, nullptr, g_kl, ws + lo.heads_z, L + 1, eps_z, L, ws + lo.qz_v, B, L, 0.f, 1.f,
+                         ws + lo.dheads_z, L + 1, stream));
+  TRY(vae_reparam_kl_bwd(ws + lo.dlibrary, 1, nullptr, g_kl, ws + lo.heads_l, 2, eps_l, 1, ws + lo.ql_v, B, 1, c.l_mean,
+                         c.l_var, ws + lo.dheads_l, 2, stream));
+  const float* hz = c.n_layers > 1 ? ws + lo.encz_h[c.n_layers - 1] : ws + lo.h_enc0;
+  const int64_t ld_hz = c.n_layers > 1 ? H : HE;
+  TRY(k.gemm(VAE_TN, L + 1, H, B, ws + lo.dheads_z, L + 1, hz, ld_hz, g->hz_w, H, nullptr, nullptr, 0));
+  TRY(k.gemm(VAE_TN, 2, Hl, B, ws + lo.dheads_l, 2, ws + lo.h_enc0 + H, HE, g->hl_w, Hl, nullptr, nullptr, 0));
+  TRY(vae_colsum(ws + lo.dheads_z, L + 1, B, L + 1, g->hz_b, stream));
+  TRY(vae_colsum(ws + lo.dheads_l, 2, B, 2, g->hl_b, stream));
+  TRY(k.gemm(VAE_NN, B, H, L + 1, ws + lo.dheads_z, L + 1, p->hz_w, H, ws + lo.dh, H, nullptr, nullptr, 0));
+  TRY(k.gemm(VAE_NN, B, Hl, 2, ws + lo.dheads_l, 2, p->hl_w, Hl, ws + lo.dpre_enc0 + H, HE, nullptr, nullptr, 0));
+
+  // deeper z-encoder layers
+  float* dh = ws + lo.dh;
+  for (int n = c.n_layers - 1; n >= 1; --n) {
+    const float* inp = n == 1 ? ws + lo.h_enc0 : ws + lo.encz_h[n - 1];
+    const int64_t ld_in = n == 1 ? HE : H;
+    TRY(vae_gelu_ln_bwd(dh, H, ws + lo.encz_pre[n], H, ws + lo.ln_mz[n], ws + lo.ln_rz[n], p->encz_ln_g[n], B, H, dh, H,
+                        g->encz_ln_g[n], g->encz_ln_b[n], g->encz_b[n], stream));
+    TRY(k.gemm(VAE_TN, H, H, B, dh, H, inp, ld_in, g->encz_w[n], H, nullptr, nullptr, 0));
+    float* nxt = ws + lo.encz_pre[n];  // free from here on
+    TRY(k.gemm(VAE_NN, B, H, H, dh, H, p->encz_w[n], H, nxt, H, nullptr, nullptr, 0));
+    dh = nxt;
+  }
+  // first encoder layer: GELU/LayerNorm backward of both halves, then ONE wgrad over the counts
+  TRY(vae_gelu_ln_bwd(dh, H, ws + lo.pre_enc0, HE, ws + lo.ln_mz[0], ws + lo.ln_rz[0], p->encz_ln_g[0], B, H,
+                      ws + lo.dpre_enc0, HE, g->encz_ln_g[0], g->encz_ln_b[0], g->enc_b0, stream));
+  TRY(vae_gelu_ln_bwd(ws + lo.dpre_enc0 + H, HE, ws + lo.pre_enc0 + H, HE, ws + lo.ln_ml, ws + lo.ln_rl, p->encl_ln_g, B,
+                      Hl, ws + lo.dpre_enc0 + H, HE, g->encl_ln_g, g->encl_ln_b, g->enc_b0 + H, stream));
+  TRY(k.gemm(VAE_TN, HE, G, B, ws + lo.dpre_enc0, HE, x, ldx, g->enc_w0, G, nullptr, ws + lo.mean, 0));
+  return VAE_OK;
+}

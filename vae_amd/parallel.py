@@ -42,7 +42,9 @@ class GradAllReducer:
         self.buckets = {"dec_heads": [(lo, hi)], "rest": [(0, lo), (after, arena.used_end)]}
 
     # -- called by the step right after the kernels writing a bucket were enqueued -----------
-    def bucket_ready(self, tag: str) -> None:
+    def bucket_ready(self, tag: str, after_event=None) -> None:
+        """Start reducing bucket ``tag``.  ``after_event``: an event already recorded (by the native
+        step) at the point of the compute stream where the bucket became final; default = now."""
         if self.world == 1:
             return
         for lo, hi in self.buckets[tag]:
@@ -50,8 +52,10 @@ class GradAllReducer:
                 continue
             buf = self.arena.flat_grad[lo:hi]
             if self.on_gpu:
-                ev = torch.cuda.Event()
-                ev.record(torch.cuda.current_stream())
+                ev = after_event
+                if ev is None:
+                    ev = torch.cuda.Event()
+                    ev.record(torch.cuda.current_stream())
                 with torch.cuda.stream(self.comm_stream):
                     self.comm_stream.wait_event(ev)
                     self._launch(buf)

@@ -3,9 +3,12 @@
 This is the hot path of the reference's ``LitVAE.training_step`` (task.py:453-502):
 z/l encoders -> decoder -> exp(px_r) -> Gaussian KLs + NB/ZINB reconstruction ->
 ``loss = gene_loss_coeff * gene_loss + cell_loss`` -> gradients of every parameter.
-It runs as a fixed sequence of kernel launches on the current HIP stream -- no autograd
-graph, no (B,G) temporaries beyond the logits buffer, which is overwritten in place by its
-own gradient.  Parameters and gradients live in a ``ParamArena``.
+
+The whole launch sequence lives in native code (csrc/step.hip): ONE C-ABI call enqueues the
+forward, one the backward, on the current HIP stream, over a single pre-allocated workspace --
+no autograd graph, no per-op Python, no allocation, no (B,G) temporaries beyond the logits
+buffer (which its own gradient overwrites in place).  Parameters and gradients live in a
+``ParamArena``.
 
 Stage list (kernel in csrc/ -> reference lines):
   row_mean                x.mean(-1)                              modules.py:264
@@ -21,12 +24,45 @@ and the mirror-image backward kernels.
 """
 from __future__ import annotations
 
+import ctypes as C
 from typing import Callable, Dict, Optional
 
 import torch
 
-from . import ops
+from . import _lib, ops
 from .arena import ParamArena, _dec, _enc
+
+
+def _tensors(view, cat, n_layers: int, zinb: bool) -> _lib.StepTensors:
+    """Fill a vae_step_tensors from arena accessors (view(name) / cat(*names) -> tensor)."""
+    t = _lib.StepTensors()
+    ptr = lambda x: x.data_ptr()  # noqa: E731
+    t.px_r = ptr(view("px_r"))
+    t.enc_w0 = ptr(cat(_enc("z_encoder", 0, "w"), _enc("l_encoder", 0, "w")))
+    t.enc_b0 = ptr(cat(_enc("z_encoder", 0, "b"), _enc("l_encoder", 0, "b")))
+    for n in range(n_layers):
+        t.encz_ln_g[n] = ptr(view(_enc("z_encoder", n, "g")))
+        t.encz_ln_b[n] = ptr(view(_enc("z_encoder", n, "beta")))
+        if n > 0:
+            t.encz_w[n] = ptr(view(_enc("z_encoder", n, "w")))
+            t.encz_b[n] = ptr(view(_enc("z_encoder", n, "b")))
+        t.dec_w[n] = ptr(view(_dec(n, "w")))
+        t.dec_b[n] = ptr(view(_dec(n, "b")))
+        t.dec_ln_g[n] = ptr(view(_dec(n, "g")))
+        t.dec_ln_b[n] = ptr(view(_dec(n, "beta")))
+    t.encl_ln_g = ptr(view(_enc("l_encoder", 0, "g")))
+    t.encl_ln_b = ptr(view(_enc("l_encoder", 0, "beta")))
+    t.hz_w = ptr(cat("z_encoder.mean_encoder.weight", "z_encoder.var_encoder.weight"))
+    t.hz_b = ptr(cat("z_encoder.mean_encoder.bias", "z_encoder.var_encoder.bias"))
+    t.hl_w = ptr(cat("l_encoder.mean_encoder.weight", "l_encoder.var_encoder.weight"))
+    t.hl_b = ptr(cat("l_encoder.mean_encoder.bias", "l_encoder.var_encoder.bias"))
+    if zinb:
+        t.heads_w = ptr(cat("decoder.px_scale_decoder.0.weight", "decoder.px_dropout_decoder.weight"))
+        t.heads_b = ptr(cat("decoder.px_scale_decoder.0.bias", "decoder.px_dropout_decoder.bias"))
+    else:
+        t.heads_w = ptr(view("decoder.px_scale_decoder.0.weight"))
+        t.heads_b = ptr(view("decoder.px_scale_decoder.0.bias"))
+    return t
 
 
 class ElboStep:
@@ -39,11 +75,14 @@ class ElboStep:
 
     def __init__(self, arena: ParamArena, *, l_mean: float, l_var: float, kl_weight: float = 1.0,
                  gene_loss_coeff: float = 5e-3, precision: int = ops.FP32):
+        if arena.likelihood not in ("zinb", "nb"):
+            raise ValueError(f"ElboStep: likelihood must be 'zinb' or 'nb', got {arena.likelihood!r}")
+        if not arena.flat.is_cuda:
+            raise RuntimeError("ElboStep: the arena must live on the GPU (no CPU fallback)")
+        self.lib = _lib.load()
         self.a = arena
         self.n_layers = arena.n_layers
         self.zinb = arena.likelihood == "zinb"
-        if arena.likelihood not in ("zinb", "nb"):
-            raise ValueError(f"ElboStep: likelihood must be 'zinb' or 'nb', got {arena.likelihood!r}")
         self.l_mean, self.l_var = float(l_mean), float(l_var)
         self.kl_weight, self.coeff = float(kl_weight), float(gene_loss_coeff)
         self.precision = precision
@@ -53,150 +92,103 @@ class ElboStep:
         self.G = a.p("px_r").shape[0]
         self.L = a.p("z_encoder.mean_encoder.weight").shape[0]
         self.Hd = a.p(_dec(0, "w")).shape[0]
-        self.table = ops.gene_table(a.p("px_r")) if a.flat.is_cuda else None
+        if self.n_layers > _lib.VAE_MAX_LAYERS:
+            raise ValueError(f"ElboStep: at most {_lib.VAE_MAX_LAYERS} layers")
+        self.params = _tensors(a.p, a.pcat, self.n_layers, self.zinb)
+        self.grads = _tensors(a.g, a.gcat, self.n_layers, self.zinb)
+        self._plans: Dict[int, tuple] = {}
+        self._ev_heads = None
+
+    def _plan(self, B: int, loss_scale: float):
+        """Config struct, workspace and named views for batch size B (cached)."""
+        key = B
+        if key not in self._plans:
+            cfg = _lib.StepConfig(B=B, G=self.G, H=self.H, Hl=self.Hl, L=self.L, Hd=self.Hd, n_layers=self.n_layers,
+                                  zinb=int(self.zinb), precision=self.precision, l_mean=self.l_mean, l_var=self.l_var,
+                                  kl_weight=self.kl_weight, gene_loss_coeff=self.coeff, loss_scale=1.0)
+            nbytes = self.lib.vae_elbo_step_workspace_bytes(C.byref(cfg))
+            if nbytes <= 0:
+                raise RuntimeError("vae_amd: bad step configuration")
+            ws = torch.empty(nbytes // 4, dtype=torch.float32, device=self.a.device)
+            off = {n: self.lib.vae_elbo_step_ws_offset(C.byref(cfg), i) for i, n in enumerate(_lib.WS_SLICES)}
+            L = self.L
+            v = dict(
+                heads_z=ws[off["QZ_HEADS"]:off["QZ_HEADS"] + B * (L + 1)].view(B, L + 1),
+                qz_v=ws[off["QZ_V"]:off["QZ_V"] + B].view(B, 1),
+                z=ws[off["Z"]:off["Z"] + B * L].view(B, L),
+                kl_z=ws[off["KL_Z"]:off["KL_Z"] + B],
+                heads_l=ws[off["QL_HEADS"]:off["QL_HEADS"] + B * 2].view(B, 2),
+                ql_v=ws[off["QL_V"]:off["QL_V"] + B].view(B, 1),
+                library=ws[off["LIBRARY"]:off["LIBRARY"] + B].view(B, 1),
+                kl_l=ws[off["KL_L"]:off["KL_L"] + B],
+                ll=ws[off["LL"]:off["LL"] + B],
+                scalars=ws[off["SCALARS"]:off["SCALARS"] + 5],
+                dz_extra=ws[off["DZ_EXTRA"]:off["DZ_EXTRA"] + B * L].view(B, L),
+            )
+            self._plans[key] = (cfg, ws, nbytes, v)
+        cfg, ws, nbytes, v = self._plans[key]
+        cfg.loss_scale = float(loss_scale)
+        cfg.kl_weight = self.kl_weight
+        return cfg, ws, nbytes, v
 
     # ------------------------------------------------------------------------------------
     def run(self, x: torch.Tensor, eps_z: torch.Tensor, eps_l: torch.Tensor,
             cell_head_fn: Optional[Callable[[torch.Tensor], torch.Tensor]] = None,
             backward: bool = True, loss_scale: float = 1.0, reducer=None) -> Dict[str, torch.Tensor]:
-        a, P = self.a, self.precision
+        """One step.  The returned tensors are VIEWS of the step workspace: they are overwritten by
+        the next ``run`` with the same batch size (clone what must survive)."""
+        a = self.a
+        for t, name in ((x, "x"), (eps_z, "eps_z"), (eps_l, "eps_l")):
+            if not t.is_cuda or t.dtype != torch.float32 or t.dim() != 2 or t.stride(1) != 1:
+                raise ValueError(f"ElboStep: {name} must be a 2-D float32 GPU tensor with a contiguous last dim")
         B, G = x.shape
-        H, Hl, L, Hd, nl = self.H, self.Hl, self.L, self.Hd, self.n_layers
+        L = self.L
         if G != self.G:
             raise ValueError(f"ElboStep: x has {G} genes, model has {self.G}")
-        if eps_z.shape != (B, L) or eps_l.shape != (B, 1):
-            raise ValueError("ElboStep: eps_z must be (B, L) and eps_l (B, 1)")
-        gemm = ops.gemm
-
-        # ---------------- forward ----------------
-        mean = ops.row_mean(x)
-        w_enc0 = a.pcat(_enc("z_encoder", 0, "w"), _enc("l_encoder", 0, "w"))
-        b_enc0 = a.pcat(_enc("z_encoder", 0, "b"), _enc("l_encoder", 0, "b"))
-        pre_enc0 = gemm(ops.NT, x, w_enc0, bias=b_enc0, x_mean=mean, precision=P)          # (B, H+Hl)
-        h_enc0 = torch.empty(B, H + Hl, dtype=torch.float32, device=x.device)
-        _, mz0, rz0 = ops.gelu_ln_fwd(pre_enc0[:, :H], a.p(_enc("z_encoder", 0, "g")), a.p(_enc("z_encoder", 0, "beta")),
-                                      out=h_enc0[:, :H])
-        _, ml, rl = ops.gelu_ln_fwd(pre_enc0[:, H:], a.p(_enc("l_encoder", 0, "g")), a.p(_enc("l_encoder", 0, "beta")),
-                                    out=h_enc0[:, H:])
-        hz, hl = h_enc0[:, :H], h_enc0[:, H:]
-        z_layers = [(None, pre_enc0[:, :H], mz0, rz0)]  # (input, pre, mean, rstd) per z-encoder layer
-        for n in range(1, nl):
-            pre = gemm(ops.NT, hz, a.p(_enc("z_encoder", n, "w")), bias=a.p(_enc("z_encoder", n, "b")), precision=P)
-            hz_n, m_, r_ = ops.gelu_ln_fwd(pre, a.p(_enc("z_encoder", n, "g")), a.p(_enc("z_encoder", n, "beta")))
-            z_layers.append((hz, pre, m_, r_))
-            hz = hz_n
-
-        w_hz = a.pcat("z_encoder.mean_encoder.weight", "z_encoder.var_encoder.weight")     # (L+1, H)
-        b_hz = a.pcat("z_encoder.mean_encoder.bias", "z_encoder.var_encoder.bias")
-        w_hl = a.pcat("l_encoder.mean_encoder.weight", "l_encoder.var_encoder.weight")     # (2, Hl)
-        b_hl = a.pcat("l_encoder.mean_encoder.bias", "l_encoder.var_encoder.bias")
-        heads_z = gemm(ops.NT, hz, w_hz, bias=b_hz, precision=P)
-        heads_l = gemm(ops.NT, hl, w_hl, bias=b_hl, precision=P)
-        qz_v, z, kl_z = ops.reparam_kl_fwd(heads_z, eps_z, 0.0, 1.0)
-        ql_v, library, kl_l = ops.reparam_kl_fwd(heads_l, eps_l, self.l_mean, self.l_var)
-
-        d_layers = []
-        px = z
-        for n in range(nl):
-            pre = gemm(ops.NT, px, a.p(_dec(n, "w")), bias=a.p(_dec(n, "b")), precision=P)
-            px_n, m_, r_ = ops.gelu_ln_fwd(pre, a.p(_dec(n, "g")), a.p(_dec(n, "beta")))
-            d_layers.append((px, pre, m_, r_))
-            px = px_n
-
-        if self.zinb:
-            w_heads = a.pcat("decoder.px_scale_decoder.0.weight", "decoder.px_dropout_decoder.weight")  # (2G, Hd)
-            b_heads = a.pcat("decoder.px_scale_decoder.0.bias", "decoder.px_dropout_decoder.bias")
-        else:
-            w_heads, b_heads = a.p("decoder.px_scale_decoder.0.weight"), a.p("decoder.px_scale_decoder.0.bias")
-        logits = gemm(ops.NT, px, w_heads, bias=b_heads, precision=P)                        # (B, 2G) or (B, G)
-        ls = logits[:, :G]
-        lp = logits[:, G:] if self.zinb else None
-
-        ops.gene_table(a.p("px_r"), out=self.table)
-        lib1 = library.view(B)
-        ll, rowmax, rowsum, S = ops.nbzinb_fwd(self.zinb, ls, lp, x, lib1, self.table)
-        scalars = ops.elbo_reduce(ll, kl_z, kl_l, self.kl_weight, self.coeff)
-
-        out = dict(qz_m=heads_z[:, :L], qz_v=qz_v.view(B, 1), z=z, ql_m=heads_l[:, :1], ql_v=ql_v.view(B, 1),
-                   library=library, recon=-ll, kl_z=kl_z, kl_l=kl_l, recon_mean=scalars[0], gene_loss=scalars[3],
-                   scalars=scalars)
+        if eps_z.shape != (B, L) or eps_l.shape != (B, 1) or not eps_z.is_contiguous() or not eps_l.is_contiguous():
+            raise ValueError("ElboStep: eps_z must be contiguous (B, L) and eps_l (B, 1)")
+        cfg, ws, nbytes, v = self._plan(B, loss_scale)
+        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        ldx = x.stride(0) if B > 1 else G
+        rc = self.lib.vae_elbo_step_forward(C.byref(cfg), C.byref(self.params), x.data_ptr(), ldx, eps_z.data_ptr(),
+                                            eps_l.data_ptr(), ws.data_ptr(), nbytes, stream)
+        _lib.check(rc, "elbo_step_forward")
+        s = v["scalars"]
+        out = dict(qz_m=v["heads_z"][:, :L], qz_v=v["qz_v"], z=v["z"], ql_m=v["heads_l"][:, :1], ql_v=v["ql_v"],
+                   library=v["library"], recon=-v["ll"], kl_z=v["kl_z"], kl_l=v["kl_l"], recon_mean=s[0],
+                   gene_loss=s[3], scalars=s)
 
         # ---------------- cell heads (tiny; torch autograd on z only) ----------------
-        dz_extra = None
-        cell_loss = None
+        use_extra = 0
+        if backward:
+            a.zero_small_grads()
         if cell_head_fn is not None:
-            z_leaf = z.detach().requires_grad_(True)
+            z_leaf = v["z"].detach().clone().requires_grad_(True)
             with torch.enable_grad():
                 cell_loss = cell_head_fn(z_leaf)
             if backward:
-                a.zero_small_grads()
                 (cell_loss * loss_scale).backward()
-                dz_extra = z_leaf.grad
-            cell_loss = cell_loss.detach()
-            out["cell_loss"] = cell_loss
-            out["loss"] = scalars[4] + cell_loss
+                v["dz_extra"].copy_(z_leaf.grad)
+                use_extra = 1
+            out["cell_loss"] = cell_loss.detach()
+            out["loss"] = s[4] + out["cell_loss"]
         else:
             out["cell_loss"] = torch.zeros((), device=x.device)
-            out["loss"] = scalars[4]
-            if backward:
-                a.zero_small_grads()
+            out["loss"] = s[4]
         if not backward:
             return out
 
-        # ---------------- backward ----------------
-        # d loss / d ll[b] = -coeff/B ; d loss / d kl[b] = coeff*kl_weight/B   (task.py:202,489)
-        g_ll = -self.coeff / B * loss_scale
-        g_kl = self.coeff * self.kl_weight / B * loss_scale
-        dlibrary = torch.empty(B, dtype=torch.float32, device=x.device)
-        if self.zinb:
-            db_s, db_p = a.g("decoder.px_scale_decoder.0.bias"), a.g("decoder.px_dropout_decoder.bias")
-        else:
-            db_s, db_p = a.g("decoder.px_scale_decoder.0.bias"), None
-        ops.nbzinb_bwd(self.zinb, ls, lp, x, lib1, self.table, rowmax, rowsum, S, None, g_ll, ls, lp, dlibrary,
-                       a.g("px_r"), db_s, db_p)                                             # logits := dlogits
-        if self.zinb:
-            gw_heads = a.gcat("decoder.px_scale_decoder.0.weight", "decoder.px_dropout_decoder.weight")
-        else:
-            gw_heads = a.g("decoder.px_scale_decoder.0.weight")
-        gemm(ops.TN, logits, px, out=gw_heads, precision=P)                                  # dW = dlogits^T px
+        ev = None
+        if reducer is not None and reducer.world > 1:
+            if self._ev_heads is None:
+                self._ev_heads = torch.cuda.Event()
+                self._ev_heads.record()  # materialises the hipEvent_t handle
+            ev = C.c_void_p(self._ev_heads.cuda_event)
+        rc = self.lib.vae_elbo_step_backward(C.byref(cfg), C.byref(self.params), C.byref(self.grads), x.data_ptr(), ldx,
+                                             eps_z.data_ptr(), eps_l.data_ptr(), use_extra, ws.data_ptr(), nbytes, ev,
+                                             stream)
+        _lib.check(rc, "elbo_step_backward")
         if reducer is not None:
-            reducer.bucket_ready("dec_heads")  # the largest gradient travels while the rest computes
-        dpx = gemm(ops.NN, logits, w_heads, precision=P)                                     # (B, Hd)
-        del logits, ls, lp
-
-        for n in reversed(range(nl)):
-            inp, pre, m_, r_ = d_layers[n]
-            dpre = ops.gelu_ln_bwd(dpx, pre, m_, r_, a.p(_dec(n, "g")), a.g(_dec(n, "g")), a.g(_dec(n, "beta")),
-                                   a.g(_dec(n, "b")), dpre=dpx)
-            gemm(ops.TN, dpre, inp, out=a.g(_dec(n, "w")), precision=P)
-            dpx = gemm(ops.NN, dpre, a.p(_dec(n, "w")), precision=P)
-        dz = dpx                                                                             # (B, L)
-        if dz_extra is not None:
-            dz = dz + dz_extra
-
-        dheads_z = ops.reparam_kl_bwd(dz, None, g_kl, heads_z, eps_z, qz_v, 0.0, 1.0)
-        dheads_l = ops.reparam_kl_bwd(dlibrary.view(B, 1), None, g_kl, heads_l, eps_l, ql_v, self.l_mean, self.l_var)
-        gemm(ops.TN, dheads_z, hz, out=a.gcat("z_encoder.mean_encoder.weight", "z_encoder.var_encoder.weight"), precision=P)
-        gemm(ops.TN, dheads_l, hl, out=a.gcat("l_encoder.mean_encoder.weight", "l_encoder.var_encoder.weight"), precision=P)
-        ops.colsum_into(dheads_z, a.gcat("z_encoder.mean_encoder.bias", "z_encoder.var_encoder.bias"))
-        ops.colsum_into(dheads_l, a.gcat("l_encoder.mean_encoder.bias", "l_encoder.var_encoder.bias"))
-        dh = gemm(ops.NN, dheads_z, w_hz, precision=P)                                       # (B, H)
-        dpre_enc0 = torch.empty(B, H + Hl, dtype=torch.float32, device=x.device)
-        gemm(ops.NN, dheads_l, w_hl, out=dpre_enc0[:, H:], precision=P)                      # dhl, turned into dpre below
-
-        for n in reversed(range(1, nl)):
-            inp, pre, m_, r_ = z_layers[n]
-            dpre = ops.gelu_ln_bwd(dh, pre, m_, r_, a.p(_enc("z_encoder", n, "g")), a.g(_enc("z_encoder", n, "g")),
-                                   a.g(_enc("z_encoder", n, "beta")), a.g(_enc("z_encoder", n, "b")), dpre=dh)
-            gemm(ops.TN, dpre, inp, out=a.g(_enc("z_encoder", n, "w")), precision=P)
-            dh = gemm(ops.NN, dpre, a.p(_enc("z_encoder", n, "w")), precision=P)
-        ops.gelu_ln_bwd(dh, pre_enc0[:, :H], mz0, rz0, a.p(_enc("z_encoder", 0, "g")), a.g(_enc("z_encoder", 0, "g")),
-                        a.g(_enc("z_encoder", 0, "beta")), a.g(_enc("z_encoder", 0, "b")), dpre=dpre_enc0[:, :H])
-        ops.gelu_ln_bwd(dpre_enc0[:, H:], pre_enc0[:, H:], ml, rl, a.p(_enc("l_encoder", 0, "g")),
-                        a.g(_enc("l_encoder", 0, "g")), a.g(_enc("l_encoder", 0, "beta")), a.g(_enc("l_encoder", 0, "b")),
-                        dpre=dpre_enc0[:, H:])
-        gemm(ops.TN, dpre_enc0, x, out=a.gcat(_enc("z_encoder", 0, "w"), _enc("l_encoder", 0, "w")), x_mean=mean,
-             precision=P)                                                                    # dW = dpre^T (x/mean-1)
-        if reducer is not None:
+            reducer.bucket_ready("dec_heads", after_event=self._ev_heads if ev is not None else None)
             reducer.bucket_ready("rest")
         return out
