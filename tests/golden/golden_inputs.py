@@ -131,6 +131,8 @@ E2E_CASES = [
 WIDE_CASE = _case("zinb_wide20k", "zinb", 1, False, B=4, G=20000, H=8, Hd=8, Hl=4, L=3,
                   sample_stride=97, stream=29)
 
+INIT_CASE = dict(G=48, H=12, Hd=10, Hl=6, L=3, n_layers=2, cell_properties=_HEADS, grad_reverse={"C": 0.5, "E": 0.2})
+
 # x, mu, theta, pi grid of SURVEY.md §8c(i) (softplus-threshold edges at |pi| ~ 20)
 LIKELIHOOD_GRID = (
     np.array([0, 1, 2, 5, 50, 255, 1e3, 5e4]),

@@ -154,8 +154,26 @@ def save_likelihood_grid():
     print("wrote", path, os.path.getsize(path) // 1024, "KiB")
 
 
+def save_init_fixture():
+    """Initial weights of the reference VAE under torch.manual_seed(43) (train.py:20) for a small
+    configuration: the product's VAE must consume the RNG identically and reproduce them."""
+    from golden_inputs import INIT_CASE
+    c = INIT_CASE
+    torch.manual_seed(43)
+    with contextlib.redirect_stdout(io.StringIO()):
+        net = ref_networks.VAE(c["G"], n_hidden=c["H"], n_hidden_decoder=c["Hd"], n_hidden_library=c["Hl"],
+                               n_latent=c["L"], n_latent_cell_decoder=c["L"], n_layers=c["n_layers"], dropout_rate=0.1,
+                               input_dropout_rate=0.0, cell_properties=c["cell_properties"],
+                               grad_reverse_dict=c["grad_reverse"], cell_decoder_hidden_layer=False)
+    blob = {k: v.detach().numpy() for k, v in net.state_dict().items()}
+    path = os.path.join(HERE, "init_seed43.npz")
+    np.savez_compressed(path, **blob)
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB")
+
+
 if __name__ == "__main__":
     torch.set_num_threads(4)
+    save_init_fixture()
     save_likelihood_grid()
     for c in E2E_CASES:
         save_case(c, keep_big=True)

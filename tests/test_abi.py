@@ -1,0 +1,77 @@
+"""CPU: the C-ABI library loads and exports every symbol include/vae_amd.h declares; argument
+validation returns error codes without touching a GPU (no compute calls here)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    src = open(os.path.join(ROOT, "include", "vae_amd.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(vae_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_and_library_agree():
+    from vae_amd import _lib
+    lib = _lib.load()
+    names = header_functions()
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/vae_amd.h but not exported by libvae_amd.so"
+    # every symbol the Python binding uses is declared in the header
+    for n in _lib.SIGNATURES:
+        assert n in names, f"{n} bound in vae_amd/_lib.py but missing from include/vae_amd.h"
+
+
+def test_probe_functions():
+    from vae_amd import _lib
+    lib = _lib.load()
+    assert lib.vae_version() >= 100
+    assert lib.vae_arch() == b"gfx950"
+    assert lib.vae_device_count() >= 0
+    assert lib.vae_gene_table_rows() == 37
+    assert lib.vae_nbzinb_max_genes() >= 30000
+
+
+def test_argument_validation_without_gpu():
+    """Bad arguments are rejected before any HIP call; messages come through vae_last_error."""
+    from vae_amd import _lib
+    lib = _lib.load()
+    rc = lib.vae_gemm(7, 0, 4, 4, 4, None, 4, None, 4, None, 4, None, None, 0, None, 0, None)
+    assert rc == 1 and b"layout" in lib.vae_last_error()
+    rc = lib.vae_gemm(0, 0, 4, 4, 4, None, 4, None, 4, None, 4, None, None, 0, None, 0, None)
+    assert rc == 1 and b"null" in lib.vae_last_error()
+    rc = lib.vae_gemm(0, 3, 4, 4, 4, None, 4, None, 4, None, 4, None, None, 0, None, 0, None)
+    assert rc == 1 and b"precision" in lib.vae_last_error()
+    rc = lib.vae_nbzinb_fwd(1, None, 0, None, 0, None, 0, None, None, 1, 1, None, None, None, None, None)
+    assert rc == 1
+    with pytest.raises(RuntimeError, match="status 1"):
+        _lib.check(rc, "nbzinb_fwd")
+
+
+def test_workspace_queries():
+    from vae_amd import _lib
+    lib = _lib.load()
+    assert lib.vae_gemm_workspace_bytes(4096, 40000, 256) == 0          # enough tiles: no split-K
+    assert lib.vae_gemm_workspace_bytes(512, 384, 20000) > 0            # skinny: split over genes
+    assert lib.vae_nbzinb_bwd_workspace_bytes(512, 20000) % (3 * 20000 * 4) == 0
+    cfg = _lib.StepConfig(B=512, G=20000, H=256, Hl=128, L=30, Hd=256, n_layers=1, zinb=1, precision=0, l_mean=0.0,
+                          l_var=1.0, kl_weight=1.0, gene_loss_coeff=5e-3, loss_scale=1.0)
+    n = lib.vae_elbo_step_workspace_bytes(C.byref(cfg))
+    assert n > 512 * 40000 * 4                                          # holds the logits at least
+    offs = [lib.vae_elbo_step_ws_offset(C.byref(cfg), i) for i in range(len(_lib.WS_SLICES))]
+    assert all(o >= 0 for o in offs) and len(set(offs)) == len(offs)
+    assert lib.vae_elbo_step_ws_offset(C.byref(cfg), 99) == -1
+    cfg.n_layers = 9
+    assert lib.vae_elbo_step_workspace_bytes(C.byref(cfg)) == -1
+
+
+def test_ops_refuse_cpu_tensors():
+    import torch
+    from vae_amd import ops
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.row_mean(torch.ones(2, 8))

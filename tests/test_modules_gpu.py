@@ -1,0 +1,131 @@
+"""GPU: the reference's module API (VAE / Encoder / DecoderSCVI / distributions / LitVAE) running on
+the HIP kernels, against the reference-made goldens.  Two routes are checked:
+  * LitVAE.training_step  -- module by module through autograd Functions over the C-ABI ops;
+  * LitVAE.training_step_fused -- the native fused step sharing the same parameters (arena views).
+"""
+import copy
+import io
+import contextlib
+
+import numpy as np
+import pytest
+import torch
+
+from golden_inputs import E2E_CASES, build_case_inputs
+from helpers import load_golden, rel_err
+
+pytestmark = pytest.mark.gpu
+TOL_CELL, TOL_GRAD = 1e-5, 1e-4
+
+
+def build_task(case):
+    from vae_amd.networks import VAE
+    from vae_amd.task import LitVAE
+    case = copy.deepcopy(case)
+    params, x, eps_z, eps_l, targets, mask = build_case_inputs(case)
+    with contextlib.redirect_stdout(io.StringIO()):
+        net = VAE(case["G"], n_hidden=case["H"], n_hidden_decoder=case["Hd"], n_hidden_library=case["Hl"],
+                  n_latent=case["L"], n_latent_cell_decoder=case["L"], n_layers=case["n_layers"], dropout_rate=0.0,
+                  input_dropout_rate=0.0, cell_properties=case["cell_properties"], grad_reverse_dict=case["grad_reverse"],
+                  reconstruction_loss=case["likelihood"], cell_decoder_hidden_layer=False)
+    net.load_state_dict({k: v.float() for k, v in params.items()})
+    task = LitVAE(net, cell_properties=case["cell_properties"] if case["use_cell_loss"] else None,
+                  reconstruction_loss=case["likelihood"], n_epochs_kl_warmup=None, gene_loss_coeff=case["gene_loss_coeff"],
+                  library_mean=np.float32(case["l_mean"]), library_var=np.float32(case["l_var"]))
+    task.train()
+    batch = (x.float().cuda(), targets.cuda(), mask.cuda(), None, None, None, None, None)
+    return case, task, batch, eps_z.float().cuda(), eps_l.float().cuda()
+
+
+def check_grads(net, gold, tag=""):
+    n = 0
+    for k, p in net.named_parameters():
+        if f"f64/gradnone/{k}" in gold.files:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+            continue
+        assert p.grad is not None, k
+        assert rel_err(p.grad.cpu().numpy(), gold[f"f64/grad/{k}"]) < TOL_GRAD, f"{tag}{k}"
+        n += 1
+    assert n >= 15
+
+
+@pytest.mark.parametrize("case", [E2E_CASES[0], E2E_CASES[2], E2E_CASES[4], E2E_CASES[5]], ids=lambda c: c["name"])
+def test_module_api_training_step(case, monkeypatch):
+    import vae_amd.modules as M
+    gold = load_golden(f"e2e_{case['name']}.npz")
+    case, task, batch, eps_z, eps_l = build_task(case)
+    task.network.cuda()
+    queue = [eps_z, eps_l]
+    monkeypatch.setattr(M, "reparameterize_gaussian", lambda mu, var: mu + queue.pop(0) * var.sqrt())
+    loss = task.training_step(batch, 0)
+    loss.backward()
+    g = float(gold["f64/out/loss"])
+    assert abs(float(loss.detach()) - g) < TOL_CELL * abs(g)
+    check_grads(task.network, gold)
+
+
+@pytest.mark.parametrize("case", [E2E_CASES[1], E2E_CASES[4]], ids=lambda c: c["name"])
+def test_fused_step_through_litvae(case):
+    gold = load_golden(f"e2e_{case['name']}.npz")
+    case, task, batch, eps_z, eps_l = build_task(case)
+    arena = task.attach_arena("cuda")
+    out = task.training_step_fused(batch, eps_z, eps_l)
+    g = float(gold["f64/out/loss"])
+    assert abs(float(out["loss"]) - g) < TOL_CELL * abs(g)
+    check_grads(task.network, gold, "fused:")
+    # parameters are arena views: an optimiser step on the module moves the arena
+    before = arena.flat.clone()
+    opt = task.configure_optimizers()["optimizer"]
+    opt.step()
+    assert not torch.equal(before, arena.flat)
+
+
+def test_module_forward_outputs():
+    """DecoderSCVI / Encoder forward tensors (px_scale, px_rate, px_dropout, q_m, q_v) vs goldens."""
+    import vae_amd.modules as M
+    case = E2E_CASES[2]
+    gold = load_golden(f"e2e_{case['name']}.npz")
+    case, task, batch, eps_z, eps_l = build_task(case)
+    net = task.network.cuda()
+    queue = [eps_z, eps_l]
+    orig = M.reparameterize_gaussian
+    M.reparameterize_gaussian = lambda mu, var: mu + queue.pop(0) * var.sqrt()
+    try:
+        with torch.no_grad():
+            out = net(batch[0])
+    finally:
+        M.reparameterize_gaussian = orig
+    for k in ("qz_m", "qz_v", "z", "ql_m", "ql_v", "library", "px_scale", "px_rate", "px_dropout"):
+        assert rel_err(out[k].cpu().numpy(), gold[f"f64/out/{k}"]) < 2e-5, k
+    assert out["px_r"] is None
+    assert abs(float(out["px_scale"].sum(-1).mean()) - 1.0) < 1e-5
+
+
+def test_distribution_api():
+    from oracle import vae_oracle as O
+    from vae_amd.distributions import NegativeBinomial, ZeroInflatedNegativeBinomial, log_zinb_positive
+    g = torch.Generator().manual_seed(3)
+    x = torch.poisson(torch.rand(6, 40, generator=g) * 4, generator=g)
+    mu = (torch.rand(6, 40, generator=g) * 5 + 0.01).requires_grad_(True)
+    theta = (torch.rand(40, generator=g) * 3 + 0.1).requires_grad_(True)
+    pi = torch.randn(6, 40, generator=g).requires_grad_(True)
+    ref = O.log_zinb_positive(x.double(), mu.double(), theta.double(), pi.double())
+    ref.sum().backward()
+    gm, gt, gp = mu.grad.clone(), theta.grad.clone(), pi.grad.clone()
+    xc = x.cuda()
+    muc, thc, pic = (t.detach().cuda().requires_grad_(True) for t in (mu, theta, pi))
+    d = ZeroInflatedNegativeBinomial(mu=muc, theta=thc, zi_logits=pic)
+    lp = d.log_prob(xc)
+    lp.sum().backward()
+    assert rel_err(lp.detach().cpu().numpy(), ref.detach().numpy()) < 2e-6
+    assert rel_err(muc.grad.cpu().numpy(), gm.numpy()) < 1e-5
+    assert rel_err(thc.grad.cpu().numpy(), gt.numpy()) < 1e-5 and thc.grad.shape == (40,)
+    assert rel_err(pic.grad.cpu().numpy(), gp.numpy()) < 1e-5
+    nb = NegativeBinomial(mu=muc.detach(), theta=thc.detach()).log_prob(xc)
+    assert rel_err(nb.cpu().numpy(), O.log_nb_positive(x.double(), mu.detach().double(), theta.detach().double()).numpy()) < 2e-6
+    with pytest.warns(UserWarning):                       # fractional counts: warn like the reference, still evaluate
+        ZeroInflatedNegativeBinomial(mu=muc.detach(), theta=thc.detach(), zi_logits=pic.detach()).log_prob(xc + 0.5)
+    with pytest.raises(ValueError):
+        log_zinb_positive(xc, muc, thc, pic, eps=1e-6)
+    with pytest.raises(ValueError):
+        NegativeBinomial(mu=muc.detach(), theta=thc.detach(), total_count=thc.detach())
