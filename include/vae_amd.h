@@ -74,10 +74,12 @@ int vae_gelu_ln_bwd(const float* dout, int64_t ld_dout, const float* pre, int64_
 int vae_reparam_kl_fwd(const float* heads, int64_t ld_heads, const float* eps, int64_t ld_eps, int64_t B, int64_t L,
                        float prior_mean, float prior_var, float* qv, float* z, int64_t ld_z, float* kl, void* stream);
 /* dheads (B, L+1) from dz (B, L) and the upstream gradient on kl[b] = g_kl_scalar * g_kl[b]
- * (g_kl nullable = 1)                                                                              */
+ * (g_kl nullable = 1).  dbias (nullable, [L+1]): column sums of dheads are accumulated = the bias
+ * gradient of the [mean_encoder; var_encoder] heads.  L <= 64.                                     */
 int vae_reparam_kl_bwd(const float* dz, int64_t ld_dz, const float* g_kl, float g_kl_scalar, const float* heads,
                        int64_t ld_heads, const float* eps, int64_t ld_eps, const float* qv, int64_t B, int64_t L,
-                       float prior_mean, float prior_var, float* dheads, int64_t ld_dheads, void* stream);
+                       float prior_mean, float prior_var, float* dheads, int64_t ld_dheads, float* dbias,
+                       void* stream);
 
 /* dst[i] += src[i]  (adds the cell-property heads' latent gradient, task.py:469-471, to dz)         */
 int vae_add_inplace(const float* src, float* dst, int64_t n, void* stream);

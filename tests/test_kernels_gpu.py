@@ -125,8 +125,10 @@ def test_reparam_kl_fwd_bwd(ops, B, L, pm, pv):
     assert rel_err(qv_g.cpu().numpy(), qv.detach().numpy()[:, 0]) < 2e-6
     assert rel_err(z_g.cpu().numpy(), z.detach().numpy()) < 2e-6
     assert rel_err(kl_g.cpu().numpy(), kl.detach().numpy()) < 5e-6
-    dh = ops.reparam_kl_bwd(dz.float().cuda(), gk.float().cuda(), 0.37, hq, eps.float().cuda(), qv_g, pm, pv)
+    dbias = torch.zeros(L + 1, device="cuda")
+    dh = ops.reparam_kl_bwd(dz.float().cuda(), gk.float().cuda(), 0.37, hq, eps.float().cuda(), qv_g, pm, pv, dbias=dbias)
     assert rel_err(dh.cpu().numpy(), heads.grad.numpy()) < 1e-5
+    assert rel_err(dbias.cpu().numpy(), heads.grad.sum(0).numpy()) < 1e-5
 
 
 def test_colsum_and_elbo_reduce(ops):

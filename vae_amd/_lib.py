@@ -26,7 +26,7 @@ SIGNATURES = {
     "vae_gelu_ln_fwd": (_i32, [_ptr, _i64, _ptr, _ptr, _i64, _i64, _ptr, _i64, _ptr, _ptr, _ptr]),
     "vae_gelu_ln_bwd": (_i32, [_ptr, _i64, _ptr, _i64, _ptr, _ptr, _ptr, _i64, _i64, _ptr, _i64, _ptr, _ptr, _ptr, _ptr]),
     "vae_reparam_kl_fwd": (_i32, [_ptr, _i64, _ptr, _i64, _i64, _i64, _f32, _f32, _ptr, _ptr, _i64, _ptr, _ptr]),
-    "vae_reparam_kl_bwd": (_i32, [_ptr, _i64, _ptr, _f32, _ptr, _i64, _ptr, _i64, _ptr, _i64, _i64, _f32, _f32, _ptr, _i64, _ptr]),
+    "vae_reparam_kl_bwd": (_i32, [_ptr, _i64, _ptr, _f32, _ptr, _i64, _ptr, _i64, _ptr, _i64, _i64, _f32, _f32, _ptr, _i64, _ptr, _ptr]),
     "vae_colsum": (_i32, [_ptr, _i64, _i64, _i64, _ptr, _ptr]),
     "vae_elbo_reduce": (_i32, [_ptr, _ptr, _ptr, _i64, _f32, _f32, _ptr, _ptr]),
     "vae_gene_table_rows": (_i64, []),

@@ -428,8 +428,15 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict_
   if (g >= G || k >= nk) return;
   float* o = k == 0 ? o0 : (k == 1 ? o1 : o2);
   if (!o) return;
+  const float* p = slab + (int64_t)k * G + g;
+  const int64_t st = (int64_t)3 * G;
   float s = 0.f;
-  for (int c = 0; c < chunks; ++c) s += slab[((int64_t)c * 3 + k) * G + g];
+  int c = 0;
+  for (; c + 4 <= chunks; c += 4) {  // four loads in flight, fixed summation order
+    const float a = p[c * st], b = p[(c + 1) * st], d = p[(c + 2) * st], e = p[(c + 3) * st];
+    s = (((s + a) + b) + d) + e;
+  }
+  for (; c < chunks; ++c) s += p[c * st];
   o[g] += s;
 }
 

@@ -21,9 +21,12 @@
 // second kernel sums in a fixed order (deterministic, no float atomics).
 #include "common.h"
 
+#include <stdlib.h>
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
 namespace {
 
@@ -77,14 +80,14 @@ __device__ __forceinline__ void load_kc(const float* __restrict__ X, int64_t ld,
     reg[i] = v;
   }
 }
-// RC: operand stored (K, rows) row-major, row index contiguous.  chunk c: k = c / (R/4), r4 = c % (R/4).
+// RC: operand stored (K, rows) row-major, row index contiguous.  chunk pair q = c / (R/4): k = 2q, 2q+1; r4 = c % (R/4).
 template <bool NORM, int R>
 __device__ __forceinline__ void load_rc(const float* __restrict__ X, int64_t ld, int r0, int rmax, int k0, int kend,
                                         int vec, const float* __restrict__ mean, float4 (&reg)[R / 32]) {
 #pragma unroll
   for (int i = 0; i < R / 32; ++i) {
-    const int c = threadIdx.x + 256 * i;
-    const int k = k0 + c / (R / 4), r = r0 + (c % (R / 4)) * 4;
+    const int c = threadIdx.x + 256 * (i >> 1);  // registers (2j, 2j+1) hold k = (2q, 2q+1) of the same 4 rows
+    const int k = k0 + 2 * (c / (R / 4)) + (i & 1), r = r0 + (c % (R / 4)) * 4;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (k < kend && r < rmax) {
       const float* p = X + (int64_t)k * ld + r;
@@ -133,8 +136,8 @@ __device__ __forceinline__ void store32_rc(float* s, const float4 (&reg)[R / 32]
   constexpr int LD = Ld32<R>::RC;
 #pragma unroll
   for (int i = 0; i < R / 32; ++i) {
-    const int c = threadIdx.x + 256 * i;
-    const int k = c / (R / 4), r = (c % (R / 4)) * 4;
+    const int c = threadIdx.x + 256 * (i >> 1);
+    const int k = 2 * (c / (R / 4)) + (i & 1), r = (c % (R / 4)) * 4;
     *reinterpret_cast<float4*>(&s[k * LD + r]) = reg[i];
   }
 }
@@ -156,14 +159,20 @@ __device__ __forceinline__ void store16_kc(__bf16* s, const float4 (&reg)[R / 32
 }
 template <int R>
 __device__ __forceinline__ void store16_rc(__bf16* s, const float4 (&reg)[R / 32]) {
+  // transposing store: each register pair carries (k, k+1) for 4 rows -> one packed 4-byte write per row
 #pragma unroll
-  for (int i = 0; i < R / 32; ++i) {
-    const int c = threadIdx.x + 256 * i;
-    const int k = c / (R / 4), r = (c % (R / 4)) * 4;
-    s[(r + 0) * LD16 + k] = (__bf16)reg[i].x;
-    s[(r + 1) * LD16 + k] = (__bf16)reg[i].y;
-    s[(r + 2) * LD16 + k] = (__bf16)reg[i].z;
-    s[(r + 3) * LD16 + k] = (__bf16)reg[i].w;
+  for (int i = 0; i < R / 32; i += 2) {
+    const int c = threadIdx.x + 256 * (i >> 1);
+    const int k = 2 * (c / (R / 4)), r = (c % (R / 4)) * 4;
+    const float lo[4] = {reg[i].x, reg[i].y, reg[i].z, reg[i].w};
+    const float hi[4] = {reg[i + 1].x, reg[i + 1].y, reg[i + 1].z, reg[i + 1].w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      bf16x2 v;
+      v[0] = (__bf16)lo[j];
+      v[1] = (__bf16)hi[j];
+      *reinterpret_cast<bf16x2*>(&s[(r + j) * LD16 + k]) = v;
+    }
   }
 }
 
@@ -203,16 +212,16 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  float4 ra[NR], rb[NR];
-  auto fetch = [&](int k0) {
+  // one register stage: tile t+1 is requested while tile t is multiplied (a second stage costs
+  // ~70 VGPRs = one resident workgroup per CU, which measured slower than the latency it hides)
+  float4 ra0[NR], rb0[NR];
+  auto fetch = [&](int k0, float4 (&ra)[NR], float4 (&rb)[NR]) {
     if (A_KC) load_kc<NORM_A, R>(g.A, g.lda, m0, g.M, k0, kend, g.vecA, g.mean, ra);
     else      load_rc<false, R>(g.A, g.lda, m0, g.M, k0, kend, g.vecA, nullptr, ra);
     if (B_KC) load_kc<false, R>(g.B, g.ldb, n0, g.N, k0, kend, g.vecB, nullptr, rb);
     else      load_rc<NORM_B, R>(g.B, g.ldb, n0, g.N, k0, kend, g.vecB, g.mean, rb);
   };
-
-  if (kbeg < kend) fetch(kbeg);
-  for (int k0 = kbeg; k0 < kend; k0 += BK) {
+  auto stage = [&](const float4 (&ra)[NR], const float4 (&rb)[NR]) {
     __syncthreads();  // previous tile's fragment reads are done
     if (PREC == 0) {
       if (A_KC) store32_kc<R>(sA32, ra); else store32_rc<R>(sA32, ra);
@@ -222,8 +231,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
       if (B_KC) store16_kc<R>(sB16, rb); else store16_rc<R>(sB16, rb);
     }
     __syncthreads();
-    if (k0 + BK < kend) fetch(k0 + BK);  // in flight during the MFMAs below
-
+  };
+  auto multiply = [&]() {
     if (PREC == 0) {
       constexpr int LDA = A_KC ? Ld32<R>::KC : Ld32<R>::RC;
       constexpr int LDB = B_KC ? Ld32<R>::KC : Ld32<R>::RC;
@@ -261,6 +270,13 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
       }
     }
+  };
+
+  if (kbeg < kend) fetch(kbeg, ra0, rb0);
+  for (int k0 = kbeg; k0 < kend; k0 += BK) {
+    stage(ra0, rb0);
+    if (k0 + BK < kend) fetch(k0 + BK, ra0, rb0);  // in flight during the MFMAs below
+    multiply();
   }
 
   // C/D map of the 32x32 MFMAs: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -291,17 +307,51 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
 }
 
 // Sums the split-K slabs in slab order, adds the bias, writes (or accumulates into) C.
-__global__ void splitk_reduce_kernel(const float* __restrict__ ws, int split, int M, int N, const float* __restrict__ bias,
-                                     float* __restrict__ C, int64_t ldc, int accumulate) {
+// VEC: N % 4 == 0, ldc % 4 == 0, 16-byte aligned pointers -> 16 B per lane, 4 slabs in flight.
+template <bool VEC>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int split, int M, int N,
+                                                            const float* __restrict__ bias, float* __restrict__ C,
+                                                            int64_t ldc, int accumulate) {
   const int64_t total = (int64_t)M * N;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int m = (int)(i / N), n = (int)(i % N);
-    float v = 0.f;
-    for (int s = 0; s < split; ++s) v += ws[(int64_t)s * total + i];
-    if (bias) v += bias[n];
-    float* p = C + (int64_t)m * ldc + n;
-    if (accumulate) v += *p;
-    *p = v;
+  if (VEC) {
+    const int64_t total4 = total >> 2;
+    const int n4 = N >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (int64_t)gridDim.x * blockDim.x) {
+      const float4* p = reinterpret_cast<const float4*>(ws) + i;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      int s = 0;
+      for (; s + 4 <= split; s += 4) {  // fixed order: slab s, s+1, s+2, s+3
+        const float4 a = p[(int64_t)s * total4], b = p[(int64_t)(s + 1) * total4];
+        const float4 c = p[(int64_t)(s + 2) * total4], d = p[(int64_t)(s + 3) * total4];
+        v.x = (((v.x + a.x) + b.x) + c.x) + d.x; v.y = (((v.y + a.y) + b.y) + c.y) + d.y;
+        v.z = (((v.z + a.z) + b.z) + c.z) + d.z; v.w = (((v.w + a.w) + b.w) + c.w) + d.w;
+      }
+      for (; s < split; ++s) {
+        const float4 a = p[(int64_t)s * total4];
+        v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+      }
+      const int m = (int)(i / n4), n = (int)(i % n4) * 4;
+      if (bias) {
+        const float4 bb = *reinterpret_cast<const float4*>(bias + n);
+        v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
+      }
+      float4* o = reinterpret_cast<float4*>(C + (int64_t)m * ldc + n);
+      if (accumulate) {
+        const float4 c0 = *o;
+        v.x += c0.x; v.y += c0.y; v.z += c0.z; v.w += c0.w;
+      }
+      *o = v;
+    }
+  } else {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+      const int m = (int)(i / N), n = (int)(i % N);
+      float v = 0.f;
+      for (int s = 0; s < split; ++s) v += ws[(int64_t)s * total + i];
+      if (bias) v += bias[n];
+      float* p = C + (int64_t)m * ldc + n;
+      if (accumulate) v += *p;
+      *p = v;
+    }
   }
 }
 
@@ -309,7 +359,10 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ ws, int split, in
 struct Plan { int tile; int split; };
 Plan make_plan(int M, int N, int K) {
   Plan p;
-  const bool small = (M <= 64 || N <= 64) || (2.0 * M * N * K < 2e8);
+  static const int force_tile = getenv("VAE_GEMM_TILE") ? atoi(getenv("VAE_GEMM_TILE")) : 0;  // tuning knob
+  bool small = (M <= 64 || N <= 64) || (2.0 * M * N * K < 2e8);
+  if (force_tile == 64) small = true;
+  if (force_tile == 128) small = false;
   p.tile = small ? 64 : 128;
   const int tiles = ((M + p.tile - 1) / p.tile) * ((N + p.tile - 1) / p.tile);
   const int ktiles = (K + BK - 1) / BK;
@@ -396,10 +449,16 @@ extern "C" int vae_gemm(int layout, int precision, int64_t M, int64_t N, int64_t
   VAE_CHECK_LAUNCH("vae_gemm");
   if (split > 1) {
     const int64_t total = M * N;
-    int blocks = (int)((total + 255) / 256);
+    const bool vec = (N % 4 == 0) && (ldc % 4 == 0) && vae_aligned16(C) && (!bias || vae_aligned16(bias)) &&
+                     (total % 4 == 0);
+    int blocks = (int)(((vec ? total / 4 : total) + 255) / 256);
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, workspace, split, g.M, g.N, bias, C, ldc,
-                       accumulate);
+    if (vec)
+      hipLaunchKernelGGL(splitk_reduce_kernel<true>, dim3(blocks), dim3(256), 0, st, workspace, split, g.M, g.N, bias, C,
+                         ldc, accumulate);
+    else
+      hipLaunchKernelGGL(splitk_reduce_kernel<false>, dim3(blocks), dim3(256), 0, st, workspace, split, g.M, g.N, bias,
+                         C, ldc, accumulate);
     VAE_CHECK_LAUNCH("vae_gemm(splitk_reduce)");
   }
   return VAE_OK;

@@ -163,56 +163,79 @@ __global__ __launch_bounds__(256) void gelu_ln_bwd_kernel(const float* dout, int
 // heads[b, 0:L] = q_m, heads[b, L] = pre-activation of the ONE shared variance (modules.py:249).
 //   q_v = softplus(.) + 1e-4 ; z = q_m + eps * sqrt(q_v)
 //   kl  = sum_j 0.5 * (r + ((q_m_j - pm)/sp)^2 - 1 - log r),  r = (sqrt(q_v)/sp)^2
-// One thread per cell: L <= 64 and the arrays are tiny (B x L).
+// One wavefront per cell: lane j owns latent dimension j (L <= 64), reductions are shuffles.
 // ---------------------------------------------------------------------------------------
-__global__ void reparam_kl_fwd_kernel(const float* __restrict__ heads, int64_t ld_h, const float* __restrict__ eps,
-                                      int64_t ld_e, int B, int L, float prior_mean, float prior_var,
-                                      float* __restrict__ qv, float* __restrict__ z, int64_t ld_z,
-                                      float* __restrict__ kl) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void reparam_kl_fwd_kernel(const float* __restrict__ heads, int64_t ld_h,
+                                                             const float* __restrict__ eps, int64_t ld_e, int B, int L,
+                                                             float prior_mean, float prior_var, float* __restrict__ qv,
+                                                             float* __restrict__ z, int64_t ld_z, float* __restrict__ kl) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (b >= B) return;
   const float* hrow = heads + (int64_t)b * ld_h;
   const float v = softplus20(hrow[L]) + 1e-4f;
   const float sq = sqrtf(v), sp = sqrtf(prior_var);
   const float r0 = sq / sp;
   const float r = r0 * r0;
-  const float base = r - 1.f - logf(r);
+  const float lr = logf(r);
   float acc = 0.f;
-  for (int j = 0; j < L; ++j) {
-    const float m = hrow[j];
+  if (lane < L) {
+    const float m = hrow[lane];
     const float t = (m - prior_mean) / sp;
-    acc += 0.5f * (r + t * t - 1.f - logf(r));
-    z[(int64_t)b * ld_z + j] = m + eps[(int64_t)b * ld_e + j] * sq;
+    acc = 0.5f * (r + t * t - 1.f - lr);
+    z[(int64_t)b * ld_z + lane] = m + eps[(int64_t)b * ld_e + lane] * sq;
   }
-  (void)base;
-  qv[b] = v;
-  kl[b] = acc;
+  acc = wave_sum(acc);
+  if (lane == 0) {
+    qv[b] = v;
+    kl[b] = acc;
+  }
 }
 
 // Backward: dheads from dz (gradient reaching the sample) and the upstream gradient on kl[b]
-// (g_kl_scalar * g_kl[b], g_kl may be null).  dz_extra (nullable) is added to dz first: it
-// carries the cell-property heads' contribution to the latent.
-__global__ void reparam_kl_bwd_kernel(const float* __restrict__ dz, int64_t ld_dz, const float* __restrict__ g_kl,
-                                      float g_kl_scalar, const float* __restrict__ heads, int64_t ld_h,
-                                      const float* __restrict__ eps, int64_t ld_e, const float* __restrict__ qv, int B,
-                                      int L, float prior_mean, float prior_var, float* __restrict__ dheads,
-                                      int64_t ld_dh) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= B) return;
-  const float gk = g_kl_scalar * (g_kl ? g_kl[b] : 1.f);
-  const float* hrow = heads + (int64_t)b * ld_h;
-  const float v = qv[b];
-  const float sq = sqrtf(v);
-  float dv = 0.f;
-  for (int j = 0; j < L; ++j) {
-    const float d = dz[(int64_t)b * ld_dz + j];
-    const float m = hrow[j];
-    dheads[(int64_t)b * ld_dh + j] = d + gk * (m - prior_mean) / prior_var;
-    dv += d * eps[(int64_t)b * ld_e + j];
+// (g_kl_scalar * g_kl[b], g_kl may be null).  dbias (nullable, [L+1]) accumulates the column sums
+// of dheads = the bias gradient of the [mean; variance] heads.
+__global__ __launch_bounds__(256) void reparam_kl_bwd_kernel(const float* __restrict__ dz, int64_t ld_dz,
+                                                             const float* __restrict__ g_kl, float g_kl_scalar,
+                                                             const float* __restrict__ heads, int64_t ld_h,
+                                                             const float* __restrict__ eps, int64_t ld_e,
+                                                             const float* __restrict__ qv, int B, int L, float prior_mean,
+                                                             float prior_var, float* __restrict__ dheads, int64_t ld_dh,
+                                                             float* __restrict__ dbias) {
+  __shared__ float comb[4][WAVE + 1];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float col = 0.f, colv = 0.f;  // column sums: lane j < L -> dq_m[j]; colv (lane 0) -> d var pre-activation
+  for (int b = blockIdx.x * 4 + wave; b < B; b += gridDim.x * 4) {
+    const float gk = g_kl_scalar * (g_kl ? g_kl[b] : 1.f);
+    const float* hrow = heads + (int64_t)b * ld_h;
+    const float v = qv[b];
+    const float sq = sqrtf(v);
+    float dv = 0.f;
+    if (lane < L) {
+      const float d = dz[(int64_t)b * ld_dz + lane];
+      const float o = d + gk * (hrow[lane] - prior_mean) / prior_var;
+      dheads[(int64_t)b * ld_dh + lane] = o;
+      col += o;
+      dv = d * eps[(int64_t)b * ld_e + lane];
+    }
+    dv = wave_sum(dv);
+    // d z_j / d v = eps_j / (2 sqrt v);  d kl / d v = L * 0.5 * (1/pv - 1/v)
+    dv = dv * 0.5f / sq + gk * (float)L * 0.5f * (1.f / prior_var - 1.f / v);
+    const float o = dv * softplus20_grad(hrow[L]);
+    if (lane == 0) {
+      dheads[(int64_t)b * ld_dh + L] = o;
+      colv += o;
+    }
   }
-  // d z_j / d v = eps_j / (2 sqrt v);  d kl / d v = L * 0.5 * (1/pv - 1/v)
-  dv = dv * 0.5f / sq + gk * (float)L * 0.5f * (1.f / prior_var - 1.f / v);
-  dheads[(int64_t)b * ld_dh + L] = dv * softplus20_grad(hrow[L]);
+  if (dbias) {
+    comb[wave][lane] = col;
+    if (lane == 0) comb[wave][WAVE] = colv;
+    __syncthreads();
+    if (wave == 0) {
+      if (lane < L) atomicAdd(dbias + lane, comb[0][lane] + comb[1][lane] + comb[2][lane] + comb[3][lane]);
+      if (lane == 0) atomicAdd(dbias + L, comb[0][WAVE] + comb[1][WAVE] + comb[2][WAVE] + comb[3][WAVE]);
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -308,7 +331,8 @@ extern "C" int vae_reparam_kl_fwd(const float* heads, int64_t ld_heads, const fl
   VAE_REQUIRE(heads && eps && qv && z && kl, "vae_reparam_kl_fwd: null pointer");
   VAE_REQUIRE(B > 0 && L > 0 && ld_heads >= L + 1 && ld_eps >= L && ld_z >= L, "vae_reparam_kl_fwd: bad shape");
   VAE_REQUIRE(prior_var > 0.f, "vae_reparam_kl_fwd: prior variance must be positive");
-  hipLaunchKernelGGL(reparam_kl_fwd_kernel, dim3((unsigned)((B + 127) / 128)), dim3(128), 0, (hipStream_t)stream, heads,
+  VAE_REQUIRE(L <= WAVE, "vae_reparam_kl_fwd: latent size %lld exceeds %d", (long long)L, WAVE);
+  hipLaunchKernelGGL(reparam_kl_fwd_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, (hipStream_t)stream, heads,
                      ld_heads, eps, ld_eps, (int)B, (int)L, prior_mean, prior_var, qv, z, ld_z, kl);
   VAE_CHECK_LAUNCH("vae_reparam_kl_fwd");
   return VAE_OK;
@@ -317,13 +341,15 @@ extern "C" int vae_reparam_kl_fwd(const float* heads, int64_t ld_heads, const fl
 extern "C" int vae_reparam_kl_bwd(const float* dz, int64_t ld_dz, const float* g_kl, float g_kl_scalar,
                                   const float* heads, int64_t ld_heads, const float* eps, int64_t ld_eps,
                                   const float* qv, int64_t B, int64_t L, float prior_mean, float prior_var,
-                                  float* dheads, int64_t ld_dheads, void* stream) {
+                                  float* dheads, int64_t ld_dheads, float* dbias, void* stream) {
   VAE_REQUIRE(dz && heads && eps && qv && dheads, "vae_reparam_kl_bwd: null pointer");
-  VAE_REQUIRE(B > 0 && L > 0 && ld_heads >= L + 1 && ld_eps >= L && ld_dz >= L && ld_dheads >= L + 1,
+  VAE_REQUIRE(B > 0 && L > 0 && L <= WAVE && ld_heads >= L + 1 && ld_eps >= L && ld_dz >= L && ld_dheads >= L + 1,
               "vae_reparam_kl_bwd: bad shape");
-  hipLaunchKernelGGL(reparam_kl_bwd_kernel, dim3((unsigned)((B + 127) / 128)), dim3(128), 0, (hipStream_t)stream, dz,
-                     ld_dz, g_kl, g_kl_scalar, heads, ld_heads, eps, ld_eps, qv, (int)B, (int)L, prior_mean, prior_var,
-                     dheads, ld_dheads);
+  int blocks = (int)((B + 3) / 4);
+  if (blocks > 64) blocks = 64;  // few workgroups: one float atomic per column per workgroup
+  hipLaunchKernelGGL(reparam_kl_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dz, ld_dz, g_kl,
+                     g_kl_scalar, heads, ld_heads, eps, ld_eps, qv, (int)B, (int)L, prior_mean, prior_var, dheads,
+                     ld_dheads, dbias);
   VAE_CHECK_LAUNCH("vae_reparam_kl_bwd");
   return VAE_OK;
 }

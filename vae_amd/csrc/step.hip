@@ -226,15 +226,13 @@ extern "C" int vae_elbo_step_backward(const vae_step_config* cfg, const vae_step
   const float* dz = ws + lo.dz;
   if (use_dz_extra) TRY(vae_add_inplace(ws + lo.dz_extra, ws + lo.dz, B * L, stream));
   TRY(vae_reparam_kl_bwd(dz, L, nullptr, g_kl, ws + lo.heads_z, L + 1, eps_z, L, ws + lo.qz_v, B, L, 0.f, 1.f,
-                         ws + lo.dheads_z, L + 1, stream));
+                         ws + lo.dheads_z, L + 1, g->hz_b, stream));
   TRY(vae_reparam_kl_bwd(ws + lo.dlibrary, 1, nullptr, g_kl, ws + lo.heads_l, 2, eps_l, 1, ws + lo.ql_v, B, 1, c.l_mean,
-                         c.l_var, ws + lo.dheads_l, 2, stream));
+                         c.l_var, ws + lo.dheads_l, 2, g->hl_b, stream));
   const float* hz = c.n_layers > 1 ? ws + lo.encz_h[c.n_layers - 1] : ws + lo.h_enc0;
   const int64_t ld_hz = c.n_layers > 1 ? H : HE;
   TRY(k.gemm(VAE_TN, L + 1, H, B, ws + lo.dheads_z, L + 1, hz, ld_hz, g->hz_w, H, nullptr, nullptr, 0));
   TRY(k.gemm(VAE_TN, 2, Hl, B, ws + lo.dheads_l, 2, ws + lo.h_enc0 + H, HE, g->hl_w, Hl, nullptr, nullptr, 0));
-  TRY(vae_colsum(ws + lo.dheads_z, L + 1, B, L + 1, g->hz_b, stream));
-  TRY(vae_colsum(ws + lo.dheads_l, 2, B, 2, g->hl_b, stream));
   TRY(k.gemm(VAE_NN, B, H, L + 1, ws + lo.dheads_z, L + 1, p->hz_w, H, ws + lo.dh, H, nullptr, nullptr, 0));
   TRY(k.gemm(VAE_NN, B, Hl, 2, ws + lo.dheads_l, 2, p->hl_w, Hl, ws + lo.dpre_enc0 + H, HE, nullptr, nullptr, 0));
 

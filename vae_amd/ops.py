@@ -158,17 +158,19 @@ def reparam_kl_fwd(heads: torch.Tensor, eps: torch.Tensor, prior_mean: float, pr
 
 
 def reparam_kl_bwd(dz: torch.Tensor, g_kl: Optional[torch.Tensor], g_kl_scalar: float, heads: torch.Tensor,
-                   eps: torch.Tensor, qv: torch.Tensor, prior_mean: float, prior_var: float) -> torch.Tensor:
+                   eps: torch.Tensor, qv: torch.Tensor, prior_mean: float, prior_var: float,
+                   dbias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """-> dheads (B, L+1); ``dbias`` (L+1,), if given, accumulates its column sums (float atomics)."""
     lib = _lib.load()
     _chk2d(dz, "dz"); _chk2d(heads, "heads"); _chk2d(eps, "eps")
     B, L = eps.shape
     if dz.shape != (B, L) or heads.shape != (B, L + 1):
         raise ValueError("vae_amd.ops.reparam_kl_bwd: shape mismatch")
-    _chk1d(qv, B, "qv"); _chk1d(g_kl, B, "g_kl")
+    _chk1d(qv, B, "qv"); _chk1d(g_kl, B, "g_kl"); _chk1d(dbias, L + 1, "dbias")
     dheads = torch.empty(B, L + 1, dtype=torch.float32, device=heads.device)
     _lib.check(lib.vae_reparam_kl_bwd(_p(dz), _ld(dz), _p(g_kl), float(g_kl_scalar), _p(heads), _ld(heads), _p(eps),
                                       _ld(eps), _p(qv), B, L, float(prior_mean), float(prior_var), _p(dheads),
-                                      _ld(dheads), _stream()), "reparam_kl_bwd")
+                                      _ld(dheads), _p(dbias), _stream()), "reparam_kl_bwd")
     return dheads
 
 
