@@ -187,7 +187,7 @@ class LitVAE(nn.Module):
         self._fused = None
         return arena
 
-    def training_step_fused(self, batch, eps_z=None, eps_l=None, loss_scale: float = 1.0):
+    def training_step_fused(self, batch, eps_z=None, eps_l=None, loss_scale: float = 1.0, reducer=None):
         """One fused fwd+bwd pass; gradients land in ``arena.flat_grad`` (= every p.grad)."""
         self.train_step += 1
         if self._arena is None:
@@ -209,7 +209,7 @@ class LitVAE(nn.Module):
         fn = None
         if self.cell_properties is not None and cell_prop_vals is not None:
             fn = lambda z: self._cell_loss(self.network.cell_decoder(z), cell_prop_vals, cell_mask, None)  # noqa: E731
-        out = self._fused.run(gene_vals, eps_z, eps_l, cell_head_fn=fn, loss_scale=loss_scale)
+        out = self._fused.run(gene_vals, eps_z, eps_l, cell_head_fn=fn, loss_scale=loss_scale, reducer=reducer)
         self.log("gene_loss", out["gene_loss"])
         self.log("cell_loss", out["cell_loss"])
         return out

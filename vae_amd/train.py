@@ -1,0 +1,76 @@
+"""Training entry point with the reference's ``main`` signature (src/train.py:17-65), without
+Lightning and without the authors' data files: the count matrix is passed in.
+
+The loop is the reference's: seed 43, VAE(**model_cfg), library prior from log1p(row sums)
+(data.py:233-244), AdamW + warm-up/decay schedule (task.py:532-565), gradient-norm clip 0.5
+(train.py:54), ``max_steps``.  Each step is ONE fused fwd+bwd pass on the HIP kernels; with
+several processes (torch.distributed initialised) gradients are averaged over ranks."""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import ops
+from .config import model_cfg as _model_cfg, task_cfg as _task_cfg, trainer_cfg as _trainer_cfg
+from .networks import VAE
+from .parallel import GradAllReducer, broadcast_parameters
+from .task import LitVAE
+
+
+def library_size_stats(counts: torch.Tensor, n: int = 200_000):
+    """mean / variance of log1p(row sums) over at most n cells (data.py:233-244)."""
+    lib = torch.log1p(counts[:n].sum(dim=1).double())
+    return float(lib.mean()), float(lib.var(unbiased=False))
+
+
+def main(train_idx: List[int], test_idx: List[int], cell_class: str, additional_restriction: Optional[str] = None, *,
+         counts: torch.Tensor = None, cell_prop_vals: Optional[torch.Tensor] = None,
+         cell_mask: Optional[torch.Tensor] = None, cell_properties: Optional[Dict] = None,
+         model_cfg: Optional[Dict] = None, task_cfg: Optional[Dict] = None, trainer_cfg: Optional[Dict] = None,
+         batch_size: int = 256, max_steps: int = 50_000, device: str = "cuda", log_every: int = 0):
+    """Train on ``counts[train_idx]`` (cells x genes, fp32, on ``device``); returns the LitVAE task.
+
+    ``test_idx`` / ``cell_class`` / ``additional_restriction`` are accepted for signature parity;
+    dataset restriction and validation belong to the data layer, which is out of scope here."""
+    if counts is None:
+        raise ValueError("vae_amd.train.main: pass the count matrix (cells x genes) as `counts`")
+    torch.manual_seed(43)  # pl.seed_everything(43), train.py:20
+    mcfg, tcfg, rcfg = dict(_model_cfg), dict(_task_cfg), dict(_trainer_cfg)
+    mcfg.update(model_cfg or {}); tcfg.update(task_cfg or {}); rcfg.update(trainer_cfg or {})
+    cell_properties = cell_properties or {"_": {"discrete": True, "values": [0, 1], "stop_grad": True}}
+    mcfg.setdefault("grad_reverse_dict", {})
+    mcfg["grad_reverse_dict"] = {k: v for k, v in mcfg["grad_reverse_dict"].items() if k in cell_properties}
+    x_all = counts[torch.as_tensor(train_idx, device=counts.device)] if train_idx is not None else counts
+    x_all = x_all.to(device=device, dtype=torch.float32)
+    network = VAE(n_input=x_all.shape[1], cell_properties=cell_properties, batch_properties=None, **mcfg)
+    lib_mean, lib_var = library_size_stats(x_all)
+    precision = ops.BF16 if str(rcfg["precision"]).startswith("bf16") else ops.FP32
+    use_heads = cell_prop_vals is not None
+    task = LitVAE(network, cell_properties=cell_properties if use_heads else None, library_mean=lib_mean,
+                  library_var=lib_var, precision=precision,
+                  **{k: v for k, v in tcfg.items() if k not in ("batch_properties",)})
+    task.train()  # dropout / gene-dropout > 0 is refused by the fused step: set both rates to 0
+    arena = task.attach_arena(device)
+    broadcast_parameters(arena)
+    reducer = GradAllReducer(arena) if dist.is_initialized() and dist.get_world_size() > 1 else None
+    opt_cfg = task.configure_optimizers()
+    opt, sched = opt_cfg["optimizer"], opt_cfg["lr_scheduler"]["scheduler"]
+    n = x_all.shape[0]
+    gen = torch.Generator(device=device).manual_seed(43)
+    params = [p for p in network.parameters() if p.grad is not None]
+    for step in range(max_steps):
+        idx = torch.randint(0, n, (batch_size,), generator=gen, device=device)
+        batch = (x_all[idx], None if not use_heads else cell_prop_vals[idx], None if not use_heads else cell_mask[idx],
+                 None, None, idx, None, None)
+        out = task.training_step_fused(batch, reducer=reducer)
+        if reducer is not None:
+            reducer.finish()
+        torch.nn.utils.clip_grad_norm_(params, rcfg["grad_clip_value"])
+        opt.step()
+        sched.step()
+        if log_every and step % log_every == 0:
+            print(f"step {step}: loss {float(out['loss']):.5f} gene_loss {float(out['gene_loss']):.3f}")
+    return task
