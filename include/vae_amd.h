@@ -56,6 +56,10 @@ int vae_gemm(int layout, int precision, int64_t M, int64_t N, int64_t K, const f
 /* ---- row kernels ----------------------------------------------------------------------------- */
 /* mean[b] = mean_g x[b,g]                                   Encoder.forward, modules.py:264      */
 int vae_row_mean(const float* x, int64_t ldx, int64_t B, int64_t G, float* mean, void* stream);
+/* mean[b] as above and xn[b,g] = x[b,g] / mean[b] - 1 (IEEE division, then the subtraction, as
+ * torch evaluates it)                                         Encoder.forward, modules.py:264      */
+int vae_normalize_rows(const float* x, int64_t ldx, int64_t B, int64_t G, float* mean, float* xn, int64_t ld_xn,
+                       void* stream);
 
 /* out = LayerNorm(GELU(pre)) * gamma + beta, eps 1e-5; saves per-row mean / rstd of GELU(pre)
  *                                                           FCLayers, modules.py:112-114          */

@@ -23,6 +23,8 @@ def _rand(shape, seed, scale=1.0):
 GEMM_SHAPES = [
     # (M, N, K)  -- ragged on purpose, plus split-K shapes (skinny M,N with long K)
     (8, 16, 64), (5, 31, 30), (129, 130, 33), (512, 384, 2000), (96, 257, 4101), (300, 40, 7), (1, 1, 1),
+    # K % 32 == 0 and 16-byte rows: the LDS-DMA pipeline (ragged tiles, split-K slabs, single pass)
+    (132, 260, 4096), (130, 262, 4096), (640, 1280, 256), (1024, 2048, 128), (512, 384, 2048),
 ]
 
 
@@ -75,6 +77,19 @@ def test_gemm_normalised_counts(ops, layout):
         ref = dy.t() @ xn
         out = ops.gemm(ops.TN, dy.float().cuda(), x.cuda(), x_mean=mean)
     assert rel_err(out.cpu().numpy(), ref.numpy()) < 5e-6
+
+
+@pytest.mark.parametrize("B,G", [(37, 1003), (8, 20000), (3, 64)])
+def test_normalize_rows_is_bit_exact(ops, B, G):
+    """x / mean - 1 with IEEE division, as torch evaluates Encoder.forward's normalisation."""
+    g = torch.Generator().manual_seed(5)
+    x = torch.poisson(torch.rand(B, G, generator=g) * 3, generator=g)
+    x[:, 0] += 1
+    mean, xn = ops.normalize_rows(x.cuda())
+    ref_mean = x.double().mean(dim=1)
+    assert rel_err(mean.cpu().double().numpy(), ref_mean.numpy()) < 1e-6
+    m32 = mean.cpu()
+    assert torch.equal(xn.cpu(), x / m32[:, None] - 1)
 
 
 def test_gemm_rejects_bad_arguments(ops):

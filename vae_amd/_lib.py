@@ -23,6 +23,7 @@ SIGNATURES = {
     "vae_gemm_workspace_bytes": (_i64, [_i64, _i64, _i64]),
     "vae_gemm": (_i32, [_i32, _i32, _i64, _i64, _i64, _ptr, _i64, _ptr, _i64, _ptr, _i64, _ptr, _ptr, _i32, _ptr, _i64, _ptr]),
     "vae_row_mean": (_i32, [_ptr, _i64, _i64, _i64, _ptr, _ptr]),
+    "vae_normalize_rows": (_i32, [_ptr, _i64, _i64, _i64, _ptr, _ptr, _i64, _ptr]),
     "vae_gelu_ln_fwd": (_i32, [_ptr, _i64, _ptr, _ptr, _i64, _i64, _ptr, _i64, _ptr, _ptr, _ptr]),
     "vae_gelu_ln_bwd": (_i32, [_ptr, _i64, _ptr, _i64, _ptr, _ptr, _ptr, _i64, _i64, _ptr, _i64, _ptr, _ptr, _ptr, _ptr]),
     "vae_reparam_kl_fwd": (_i32, [_ptr, _i64, _ptr, _i64, _i64, _i64, _f32, _f32, _ptr, _ptr, _i64, _ptr, _ptr]),

@@ -45,7 +45,7 @@ struct GemmArgs {
   int split;
   int vecA, vecB;      // 16-byte vector loads allowed
   int accumulate;      // C += (only when split == 1)
-  int tiles_n;
+  int tiles_m, tiles_n;
 };
 
 // ---- global -> register tile loaders (R*8/256 float4 per thread per operand, R = 64 or 128) ----
@@ -306,6 +306,215 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// fp32 pipeline with LDS-DMA staging (global_load_lds_dwordx4): no staging registers, no ds_write
+// pass, two LDS stages, one barrier per K-tile.  Tile 128x128x32, 4 waves as 2x2.
+//   KC operand image: [128 rows][8 x 16 B], 16-byte slot = chunk ^ ((row >> 1) & 7) -- the swizzle
+//     is applied to the SOURCE address (the DMA destination is lane-linear) and again on the read;
+//     fragments are ds_read_b128 (4 k per lane), conflict-free over the b128 lane groups.
+//   RC operand image: [32 k][128 rows], fragments are ds_read_b32.
+// The contraction order inside a K-tile is permuted (step j, lane half h -> k = 8(j/4)+4h+(j%4))
+// identically for A and B, so a 16-byte fragment feeds four consecutive MFMAs.
+// Requirements (checked on the host; otherwise the register-staged kernel above runs):
+// K % 32 == 0, 16-byte aligned rows, RC extents % 4 == 0.  Rows beyond M / N are clamped to a
+// valid row on the load side (their products are never stored).
+// ---------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void* lds_void_ptr;
+typedef const __attribute__((address_space(1))) void* global_void_ptr;
+
+// One wave-instruction: lane i copies 16 bytes from its own `src` to LDS byte `lds_wave_base + 16 i`.
+// Issued through inline asm so that the compiler does not count it: hipcc would otherwise drain
+// vmcnt before the next ds_read (it cannot tell which LDS stage the DMA writes).  The kernel waits
+// for the DMA itself (dma_wait) before the barrier that publishes a stage.
+__device__ __forceinline__ void dma16(const float* src, uint32_t lds_wave_base) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(src), "s"(lds_wave_base)
+               : "memory");
+}
+__device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// BM x BN = 128x128 (waves 2x2, 2x2 accumulators each), 128x160 (waves 4x1, 1x5) or 160x128
+// (waves 1x4, 5x1): the 160-wide shapes exist so that the tile count of the 40000-row decoder
+// head GEMMs lands just under a multiple of the 512 resident workgroups.
+template <int LAYOUT, int BM, int BN, int WAVES_M>
+__global__ __launch_bounds__(256, 2) void gemm32_dma_kernel(GemmArgs g) {
+  constexpr bool A_KC = (LAYOUT != TN);
+  constexpr bool B_KC = (LAYOUT == NT);
+  constexpr int WAVES_N = 4 / WAVES_M;
+  constexpr int TM = BM / (32 * WAVES_M), TNN = BN / (32 * WAVES_N);  // accumulators per wave
+  constexpr int PA = BM / 32, PB = BN / 32;                           // DMA pieces per wave
+  constexpr int OPA = 32 * BM, OPB = 32 * BN;                         // floats per operand per stage
+  constexpr int STAGE = OPA + OPB;
+  __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];  // 64-72 KB: two workgroups per CU
+
+  // XCD-aware placement: consecutive logical ids share an XCD (hardware deals blockIdx round-robin
+  // over the 8 XCDs), and the tiles that share the large operand are consecutive.
+  const int nwg = gridDim.x;
+  const int xcd = blockIdx.x & 7, q8 = nwg >> 3, r8 = nwg & 7;
+  const int id = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3);
+  const int tiles_m = g.tiles_m, tiles_n = g.tiles_n;
+  const int per_split = tiles_m * tiles_n;
+  const int s = id / per_split, t = id - s * per_split;
+  int tm, tn;
+  if (tiles_m <= tiles_n) { tm = t % tiles_m; tn = t / tiles_m; }
+  else                    { tn = t % tiles_n; tm = t / tiles_n; }
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int kbeg = s * g.k_per_split;
+  const int kend = min(g.K, kbeg + g.k_per_split);
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  const int l31 = lane & 31, h = lane >> 5;
+
+  // ---- per-lane DMA source pointers: one 1 KB piece per wave-instruction ----
+  const float* pa[PA];
+  const float* pb[PB];
+#pragma unroll
+  for (int i = 0; i < PA; ++i) {
+    const int piece = wave * PA + i;
+    if (A_KC) {
+      const int row = piece * 8 + (lane >> 3);
+      const int c8 = (lane & 7) ^ ((row >> 1) & 7);
+      pa[i] = g.A + (int64_t)min(m0 + row, g.M - 1) * g.lda + kbeg + 4 * c8;
+    } else {
+      const int c = piece * 64 + lane, k = c / (BM / 4), r4 = c % (BM / 4);
+      pa[i] = g.A + (int64_t)(kbeg + k) * g.lda + min(m0 + 4 * r4, g.M - 4);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < PB; ++i) {
+    const int piece = wave * PB + i;
+    if (B_KC) {
+      const int row = piece * 8 + (lane >> 3);
+      const int c8 = (lane & 7) ^ ((row >> 1) & 7);
+      pb[i] = g.B + (int64_t)min(n0 + row, g.N - 1) * g.ldb + kbeg + 4 * c8;
+    } else {
+      const int c = piece * 64 + lane, k = c / (BN / 4), r4 = c % (BN / 4);
+      pb[i] = g.B + (int64_t)(kbeg + k) * g.ldb + min(n0 + 4 * r4, g.N - 4);
+    }
+  }
+  const int64_t step_a = A_KC ? 32 : 32 * g.lda;
+  const int64_t step_b = B_KC ? 32 : 32 * g.ldb;
+
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void_ptr)smem;
+  auto issue = [&](int stage) {  // stage index is wave-uniform
+    const uint32_t base_a = lds0 + (uint32_t)stage * (STAGE * 4u) + (uint32_t)wave * (PA * 1024u);
+    const uint32_t base_b = lds0 + (uint32_t)stage * (STAGE * 4u) + OPA * 4u + (uint32_t)wave * (PB * 1024u);
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+      dma16(pa[i], base_a + i * 1024u);
+      pa[i] += step_a;
+    }
+#pragma unroll
+    for (int i = 0; i < PB; ++i) {
+      dma16(pb[i], base_b + i * 1024u);
+      pb[i] += step_b;
+    }
+  };
+
+  // ---- fragment addressing ----
+  const int ra = wm * (32 * TM) + l31, rb = wn * (32 * TNN) + l31;  // first 32-row block of the wave
+  const int ea = (h ^ ((ra >> 1) & 7)), eb = (h ^ ((rb >> 1) & 7));
+  const int kc_a = ra * 32, kc_b = rb * 32;                    // KC: + t*1024 + (((2p)^e) << 2)
+  const int rc_a = 4 * h * BM + ra, rc_b = 4 * h * BN + rb;    // RC: + (8p+i)*BM + 32t
+
+  f32x16 acc[TM][TNN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TNN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  auto frag_a = [&](const float* sx, int p, float (&f)[TM][4]) {
+#pragma unroll
+    for (int tt = 0; tt < TM; ++tt) {
+      if (A_KC) {
+        const float4 v = *reinterpret_cast<const float4*>(sx + kc_a + tt * 1024 + (((2 * p) ^ ea) << 2));
+        f[tt][0] = v.x; f[tt][1] = v.y; f[tt][2] = v.z; f[tt][3] = v.w;
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) f[tt][i] = sx[rc_a + (8 * p + i) * BM + 32 * tt];
+      }
+    }
+  };
+  auto frag_b = [&](const float* sx, int p, float (&f)[TNN][4]) {
+#pragma unroll
+    for (int tt = 0; tt < TNN; ++tt) {
+      if (B_KC) {
+        const float4 v = *reinterpret_cast<const float4*>(sx + kc_b + tt * 1024 + (((2 * p) ^ eb) << 2));
+        f[tt][0] = v.x; f[tt][1] = v.y; f[tt][2] = v.z; f[tt][3] = v.w;
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) f[tt][i] = sx[rc_b + (8 * p + i) * BN + 32 * tt];
+      }
+    }
+  };
+
+  auto multiply = [&](const float* stage) {
+    const float* sa = stage;
+    const float* sb = stage + OPA;
+    float a[2][TM][4], b[2][TNN][4];  // [buffer][32-row block][k]
+    frag_a(sa, 0, a[0]);
+    frag_b(sb, 0, b[0]);
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int cur = p & 1;
+      if (p + 1 < 4) {  // next group's fragments are in flight during this group's MFMAs
+        frag_a(sa, p + 1, a[cur ^ 1]);
+        frag_b(sb, p + 1, b[cur ^ 1]);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int ti = 0; ti < TM; ++ti)
+#pragma unroll
+          for (int tj = 0; tj < TNN; ++tj)
+            acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][ti][i], b[cur][tj][i], acc[ti][tj], 0, 0, 0);
+    }
+  };
+
+  if (kbeg < kend) issue(0);
+  dma_wait();
+  __syncthreads();  // stage 0 published
+  int cur = 0;
+  for (int k0 = kbeg; k0 < kend; k0 += BK) {
+    if (k0 + BK < kend) issue(cur ^ 1);  // lands during the MFMAs below
+    multiply(smem + cur * STAGE);
+    dma_wait();
+    __syncthreads();  // next stage published; every wave is done reading this one
+    cur ^= 1;
+  }
+
+  float* out = g.C;
+  int64_t ldc = g.ldc;
+  if (g.split > 1) {
+    out = g.C + (int64_t)s * g.M * g.N;
+    ldc = g.N;
+  }
+#pragma unroll
+  for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < TNN; ++ni) {
+      const int n = n0 + wn * (32 * TNN) + ni * 32 + l31;
+      if (n >= g.N) continue;
+      const float bv = (g.split == 1 && g.bias) ? g.bias[n] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * (32 * TM) + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (m < g.M) {
+          float* p = out + (int64_t)m * ldc + n;
+          float v = acc[mi][ni][r] + bv;
+          if (g.split == 1 && g.accumulate) v += *p;
+          *p = v;
+        }
+      }
+    }
+}
+
 // Sums the split-K slabs in slab order, adds the bias, writes (or accumulates into) C.
 // VEC: N % 4 == 0, ldc % 4 == 0, 16-byte aligned pointers -> 16 B per lane, 4 slabs in flight.
 template <bool VEC>
@@ -380,10 +589,46 @@ Plan make_plan(int M, int N, int K) {
   return p;
 }
 
+// Plan of the LDS-DMA pipeline: tile shape and K split that minimise a makespan model -- two
+// workgroups per CU (512 slots) run in generations; a split pays for writing and summing its slabs.
+struct DmaPlan { int bm, bn, split; };
+DmaPlan make_dma_plan(int M, int N, int K) {
+  static const int force = getenv("VAE_GEMM_DMA_TILE") ? atoi(getenv("VAE_GEMM_DMA_TILE")) : 0;  // 0 | 128 | 160
+  const int shapes[3][2] = {{128, 128}, {128, 160}, {160, 128}};
+  const int ktiles = K / BK;
+  DmaPlan best = {128, 128, 1};
+  double best_us = 1e30;
+  for (int c = 0; c < 3; ++c) {
+    const int bm = shapes[c][0], bn = shapes[c][1];
+    if (force == 128 && c != 0) continue;
+    if (force == 160 && c == 0 && (M > 2048 || N > 2048)) continue;
+    const int tiles = ((M + bm - 1) / bm) * ((N + bn - 1) / bn);
+    const int max_split = ktiles / 4 > 0 ? (ktiles / 4 < 64 ? ktiles / 4 : 64) : 1;
+    for (int split = 1; split <= max_split; ++split) {
+      const int kt = (ktiles + split - 1) / split;
+      const int nsplit = (ktiles + kt - 1) / kt;
+      if (nsplit != split) continue;  // same slab count as a smaller request
+      const double gens = (double)((tiles * split + 511) / 512);
+      // a generation of paired 128x128x32 K-tiles takes ~3.9 us; ~3 us of prologue + epilogue per generation
+      double us = gens * (kt * 3.9 * (bm * bn / 16384.0) + 3.0);
+      if (tiles * split <= 256) us = kt * 2.2 * (bm * bn / 16384.0) + 3.0;  // one workgroup per CU
+      if (split > 1) us += 3.0 + split * (double)M * N * 4.0 / 5.0e6;  // the reduce pass reads the slabs at ~5 TB/s
+      if (us < best_us) { best_us = us; best = {bm, bn, split}; }
+    }
+  }
+  static const int force_split = getenv("VAE_GEMM_DMA_SPLIT") ? atoi(getenv("VAE_GEMM_DMA_SPLIT")) : 0;  // tuning knob
+  if (force_split > 0 && ktiles / 4 > 1) {
+    const int cap = ktiles / 4 < 64 ? ktiles / 4 : 64;
+    best.split = force_split < cap ? force_split : cap;
+  }
+  return best;
+}
+
 template <int LAYOUT, int PREC, int TW>
 void launch(const GemmArgs& g, bool norm, dim3 grid, hipStream_t st) {
-  if (norm) hipLaunchKernelGGL((gemm_kernel<LAYOUT, PREC, true, TW>), grid, dim3(256), 0, st, g);
-  else      hipLaunchKernelGGL((gemm_kernel<LAYOUT, PREC, false, TW>), grid, dim3(256), 0, st, g);
+  static const int pad = getenv("VAE_GEMM_LDS_PAD") ? atoi(getenv("VAE_GEMM_LDS_PAD")) : 0;  // tuning knob
+  if (norm) hipLaunchKernelGGL((gemm_kernel<LAYOUT, PREC, true, TW>), grid, dim3(256), pad, st, g);
+  else      hipLaunchKernelGGL((gemm_kernel<LAYOUT, PREC, false, TW>), grid, dim3(256), pad, st, g);
 }
 template <int LAYOUT, int PREC>
 void launch_t(const GemmArgs& g, bool norm, dim3 grid, hipStream_t st, int tile) {
@@ -395,7 +640,12 @@ void launch_t(const GemmArgs& g, bool norm, dim3 grid, hipStream_t st, int tile)
 
 extern "C" int64_t vae_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K) {
   const Plan p = make_plan((int)M, (int)N, (int)K);
-  return p.split > 1 ? (int64_t)p.split * M * N * (int64_t)sizeof(float) : 0;
+  int split = p.split;
+  if (K % BK == 0 && p.tile == 128) {  // whichever pipeline the operands' alignment selects at run time
+    const DmaPlan d = make_dma_plan((int)M, (int)N, (int)K);
+    if (d.split > split) split = d.split;
+  }
+  return split > 1 ? (int64_t)split * M * N * (int64_t)sizeof(float) : 0;
 }
 
 extern "C" int vae_gemm(int layout, int precision, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
@@ -419,9 +669,19 @@ extern "C" int vae_gemm(int layout, int precision, int64_t M, int64_t N, int64_t
   g.vecA = (lda % 4 == 0) && vae_aligned16(A);
   g.vecB = (ldb % 4 == 0) && vae_aligned16(B);
   const Plan plan = make_plan(g.M, g.N, g.K);
-  const int tiles_m = (g.M + plan.tile - 1) / plan.tile;
-  g.tiles_n = (g.N + plan.tile - 1) / plan.tile;
-  int split = plan.split;
+  static const int no_dma = getenv("VAE_GEMM_NO_DMA") ? atoi(getenv("VAE_GEMM_NO_DMA")) : 0;  // tuning knob
+  const bool norm = x_mean != nullptr;
+  const bool a_rc = layout == TN, b_rc = layout != NT;
+  const bool dma_ok = precision == 0 && !norm && plan.tile == 128 && !no_dma && K % BK == 0 && g.vecA && g.vecB &&
+                      (!a_rc || M % 4 == 0) && (!b_rc || N % 4 == 0) && M >= 4 && N >= 4;
+  int bm = plan.tile, bn = plan.tile, split = plan.split;
+  if (dma_ok) {
+    const DmaPlan d = make_dma_plan(g.M, g.N, g.K);
+    bm = d.bm; bn = d.bn; split = d.split;
+  }
+  const int tiles_m = (g.M + bm - 1) / bm;
+  g.tiles_m = tiles_m;
+  g.tiles_n = (g.N + bn - 1) / bn;
   const int ktiles = (g.K + BK - 1) / BK;
   const int tiles_per_split = (ktiles + split - 1) / split;
   g.k_per_split = tiles_per_split * BK;
@@ -436,8 +696,19 @@ extern "C" int vae_gemm(int layout, int precision, int64_t M, int64_t N, int64_t
     g.C = workspace;
   }
   dim3 grid(tiles_m * g.tiles_n, split);
-  const bool norm = x_mean != nullptr;
-  if (precision == 0) {
+  if (dma_ok) {
+    dim3 grid1(tiles_m * g.tiles_n * split);
+#define VAE_DMA_LAUNCH(LAY)                                                                              \
+    do {                                                                                                   \
+      if (bm == 128 && bn == 128) hipLaunchKernelGGL((gemm32_dma_kernel<LAY, 128, 128, 2>), grid1, dim3(256), 0, st, g); \
+      else if (bn == 160)         hipLaunchKernelGGL((gemm32_dma_kernel<LAY, 128, 160, 4>), grid1, dim3(256), 0, st, g); \
+      else                        hipLaunchKernelGGL((gemm32_dma_kernel<LAY, 160, 128, 1>), grid1, dim3(256), 0, st, g); \
+    } while (0)
+    if (layout == NT) VAE_DMA_LAUNCH(NT);
+    else if (layout == NN) VAE_DMA_LAUNCH(NN);
+    else VAE_DMA_LAUNCH(TN);
+#undef VAE_DMA_LAUNCH
+  } else if (precision == 0) {
     if (layout == NT) launch_t<NT, 0>(g, norm, grid, st, plan.tile);
     else if (layout == NN) launch_t<NN, 0>(g, false, grid, st, plan.tile);
     else launch_t<TN, 0>(g, norm, grid, st, plan.tile);

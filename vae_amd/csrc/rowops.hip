@@ -38,6 +38,34 @@ __global__ __launch_bounds__(256) void row_mean_kernel(const float* __restrict__
   if (threadIdx.x == 0) mean[b] = s / (float)G;
 }
 
+// Row mean AND the normalised counts xn = x / mean - 1 (Encoder.forward, modules.py:264) in one
+// launch: the row is summed from HBM, then re-read (L2-resident: one row is G*4 bytes) and written
+// normalised.  The encoder GEMMs (forward and wgrad) then stream xn with plain LDS-DMA loads.
+__global__ __launch_bounds__(256) void normalize_rows_kernel(const float* __restrict__ x, int64_t ld, int B, int G,
+                                                             int vec, float* __restrict__ mean,
+                                                             float* __restrict__ xn, int64_t ld_xn) {
+  __shared__ float red[4];
+  const int b = blockIdx.x;
+  const float* row = x + (int64_t)b * ld;
+  float* orow = xn + (int64_t)b * ld_xn;
+  float s = 0.f;
+  const int n4 = vec ? (G >> 2) : 0;
+  for (int i = threadIdx.x; i < n4; i += 256) {
+    const float4 v = reinterpret_cast<const float4*>(row)[i];
+    s += (v.x + v.y) + (v.z + v.w);
+  }
+  for (int i = (n4 << 2) + threadIdx.x; i < G; i += 256) s += row[i];
+  s = block_sum<4>(s, red);
+  const float m = s / (float)G;
+  if (threadIdx.x == 0) mean[b] = m;
+  for (int i = threadIdx.x; i < n4; i += 256) {
+    float4 v = reinterpret_cast<const float4*>(row)[i];
+    v.x = v.x / m - 1.f; v.y = v.y / m - 1.f; v.z = v.z / m - 1.f; v.w = v.w / m - 1.f;
+    reinterpret_cast<float4*>(orow)[i] = v;
+  }
+  for (int i = (n4 << 2) + threadIdx.x; i < G; i += 256) orow[i] = row[i] / m - 1.f;
+}
+
 // ---------------------------------------------------------------------------------------
 // GELU(erf) -> LayerNorm(eps 1e-5, affine) forward (FCLayers, modules.py:112-114).
 // `pre` = Linear output incl. bias.  Saves mean / rstd of the GELU output per row.
@@ -297,6 +325,16 @@ extern "C" int vae_row_mean(const float* x, int64_t ldx, int64_t B, int64_t G, f
   hipLaunchKernelGGL(row_mean_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, x, ldx, (int)B, (int)G, vec,
                      mean);
   VAE_CHECK_LAUNCH("vae_row_mean");
+  return VAE_OK;
+}
+
+extern "C" int vae_normalize_rows(const float* x, int64_t ldx, int64_t B, int64_t G, float* mean, float* xn,
+                                  int64_t ld_xn, void* stream) {
+  VAE_REQUIRE(x && mean && xn && B > 0 && G > 0 && ldx >= G && ld_xn >= G, "vae_normalize_rows: bad arguments");
+  const int vec = (ldx % 4 == 0) && (ld_xn % 4 == 0) && vae_aligned16(x) && vae_aligned16(xn);
+  hipLaunchKernelGGL(normalize_rows_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, x, ldx, (int)B, (int)G,
+                     vec, mean, xn, ld_xn);
+  VAE_CHECK_LAUNCH("vae_normalize_rows");
   return VAE_OK;
 }
 

@@ -11,7 +11,7 @@ namespace {
 
 struct Layout {
   // offsets in floats into the workspace
-  int64_t mean, pre_enc0, h_enc0, ln_mz[VAE_MAX_LAYERS], ln_rz[VAE_MAX_LAYERS], ln_ml, ln_rl;
+  int64_t mean, xn, ld_xn, pre_enc0, h_enc0, ln_mz[VAE_MAX_LAYERS], ln_rz[VAE_MAX_LAYERS], ln_ml, ln_rl;
   int64_t encz_pre[VAE_MAX_LAYERS], encz_h[VAE_MAX_LAYERS];  // layers >= 1
   int64_t heads_z, heads_l, qz_v, z, kl_z, ql_v, library, kl_l;
   int64_t dec_pre[VAE_MAX_LAYERS], dec_h[VAE_MAX_LAYERS], ln_md[VAE_MAX_LAYERS], ln_rd[VAE_MAX_LAYERS];
@@ -33,6 +33,8 @@ bool make_layout(const vae_step_config& c, Layout* lo) {
   const int64_t B = c.B, G = c.G, H = c.H, Hl = c.Hl, L = c.L, Hd = c.Hd;
   const int64_t NH = c.zinb ? 2 * G : G;
   lo->mean = take(B);
+  lo->ld_xn = up4(G);            // normalised counts x/mean - 1, rows padded to 16 bytes
+  lo->xn = take(B * lo->ld_xn);
   lo->pre_enc0 = take(B * (H + Hl));
   lo->h_enc0 = take(B * (H + Hl));
   for (int n = 0; n < c.n_layers; ++n) { lo->ln_mz[n] = take(B); lo->ln_rz[n] = take(B); }
@@ -137,8 +139,8 @@ extern "C" int vae_elbo_step_forward(const vae_step_config* cfg, const vae_step_
   const int64_t NH = c.zinb ? 2 * G : G;
 
   // encoders: x/mean-1 -> Linear(G, H+Hl) -> GELU -> LayerNorm (z and library halves)
-  TRY(vae_row_mean(x, ldx, B, G, ws + lo.mean, stream));
-  TRY(k.gemm(VAE_NT, B, HE, G, x, ldx, p->enc_w0, G, ws + lo.pre_enc0, HE, p->enc_b0, ws + lo.mean, 0));
+  TRY(vae_normalize_rows(x, ldx, B, G, ws + lo.mean, ws + lo.xn, lo.ld_xn, stream));
+  TRY(k.gemm(VAE_NT, B, HE, G, ws + lo.xn, lo.ld_xn, p->enc_w0, G, ws + lo.pre_enc0, HE, p->enc_b0, nullptr, 0));
   TRY(vae_gelu_ln_fwd(ws + lo.pre_enc0, HE, p->encz_ln_g[0], p->encz_ln_b[0], B, H, ws + lo.h_enc0, HE,
                       ws + lo.ln_mz[0], ws + lo.ln_rz[0], stream));
   TRY(vae_gelu_ln_fwd(ws + lo.pre_enc0 + H, HE, p->encl_ln_g, p->encl_ln_b, B, Hl, ws + lo.h_enc0 + H, HE,
@@ -253,6 +255,6 @@ extern "C" int vae_elbo_step_backward(const vae_step_config* cfg, const vae_step
                       ws + lo.dpre_enc0, HE, g->encz_ln_g[0], g->encz_ln_b[0], g->enc_b0, stream));
   TRY(vae_gelu_ln_bwd(ws + lo.dpre_enc0 + H, HE, ws + lo.pre_enc0 + H, HE, ws + lo.ln_ml, ws + lo.ln_rl, p->encl_ln_g, B,
                       Hl, ws + lo.dpre_enc0 + H, HE, g->encl_ln_g, g->encl_ln_b, g->enc_b0 + H, stream));
-  TRY(k.gemm(VAE_TN, HE, G, B, ws + lo.dpre_enc0, HE, x, ldx, g->enc_w0, G, nullptr, ws + lo.mean, 0));
+  TRY(k.gemm(VAE_TN, HE, G, B, ws + lo.dpre_enc0, HE, ws + lo.xn, lo.ld_xn, g->enc_w0, G, nullptr, nullptr, 0));
   return VAE_OK;
 }

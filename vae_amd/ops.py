@@ -104,6 +104,17 @@ def row_mean(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def normalize_rows(x: torch.Tensor):
+    """-> (mean (B,), xn = x / mean - 1 (B,G)): Encoder.forward's input normalisation (modules.py:264)."""
+    lib = _lib.load()
+    _chk2d(x, "x")
+    mean = torch.empty(x.shape[0], dtype=torch.float32, device=x.device)
+    xn = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    _lib.check(lib.vae_normalize_rows(_p(x), _ld(x), x.shape[0], x.shape[1], _p(mean), _p(xn), _ld(xn), _stream()),
+               "normalize_rows")
+    return mean, xn
+
+
 def gelu_ln_fwd(pre: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor,
                 out: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
     lib = _lib.load()
