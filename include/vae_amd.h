@@ -53,6 +53,13 @@ int vae_gemm(int layout, int precision, int64_t M, int64_t N, int64_t K, const f
              int64_t ldb, float* C, int64_t ldc, const float* bias, const float* x_mean, int accumulate,
              float* workspace, int64_t workspace_bytes, void* stream);
 
+/* The same product left as *n_slabs partial (M,N) slabs (row stride N, slab stride M*N) in the
+ * workspace: no reduce pass, no bias.  For a consumer that sums the split-K slabs while it reads
+ * them (the fused encoder-tail / decoder-head kernels of vae_elbo_step_*).                       */
+int64_t vae_gemm_slabs_workspace_bytes(int64_t M, int64_t N, int64_t K);
+int vae_gemm_slabs(int layout, int precision, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
+                   const float* B, int64_t ldb, float* workspace, int64_t workspace_bytes, int* n_slabs, void* stream);
+
 /* ---- row kernels ----------------------------------------------------------------------------- */
 /* mean[b] = mean_g x[b,g]                                   Encoder.forward, modules.py:264      */
 int vae_row_mean(const float* x, int64_t ldx, int64_t B, int64_t G, float* mean, void* stream);

@@ -648,14 +648,17 @@ extern "C" int64_t vae_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K) {
   return split > 1 ? (int64_t)split * M * N * (int64_t)sizeof(float) : 0;
 }
 
-extern "C" int vae_gemm(int layout, int precision, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
-                        const float* B, int64_t ldb, float* C, int64_t ldc, const float* bias, const float* x_mean,
-                        int accumulate, float* workspace, int64_t workspace_bytes, void* stream) {
+namespace {
+// slabs_out != null: leave the product as *slabs_out partial (M,N) slabs (ld N) in the workspace
+// -- no reduce pass, no bias -- for a consumer kernel that sums them while it reads.
+int gemm_impl(int layout, int precision, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B,
+              int64_t ldb, float* C, int64_t ldc, const float* bias, const float* x_mean, int accumulate,
+              float* workspace, int64_t workspace_bytes, void* stream, int* slabs_out) {
   VAE_REQUIRE(layout >= 0 && layout <= 2, "vae_gemm: layout must be 0 (NT), 1 (NN) or 2 (TN), got %d", layout);
   VAE_REQUIRE(precision == 0 || precision == 1, "vae_gemm: precision must be 0 (fp32) or 1 (bf16), got %d", precision);
   VAE_REQUIRE(M > 0 && N > 0 && K > 0 && M < (1 << 30) && N < (1 << 30) && K < (1 << 30),
               "vae_gemm: bad shape M=%lld N=%lld K=%lld", (long long)M, (long long)N, (long long)K);
-  VAE_REQUIRE(A && B && C, "vae_gemm: null operand");
+  VAE_REQUIRE(A && B && (C || slabs_out), "vae_gemm: null operand");
   const int64_t a_min = layout == TN ? M : K, b_min = layout == NT ? K : N;
   VAE_REQUIRE(lda >= a_min && ldb >= b_min && ldc >= N, "vae_gemm: leading dimension too small (lda=%lld ldb=%lld ldc=%lld)",
               (long long)lda, (long long)ldb, (long long)ldc);
@@ -688,7 +691,15 @@ extern "C" int vae_gemm(int layout, int precision, int64_t M, int64_t N, int64_t
   split = (ktiles + tiles_per_split - 1) / tiles_per_split;  // drop empty slabs
   g.split = split;
   hipStream_t st = (hipStream_t)stream;
-  if (split > 1) {
+  if (slabs_out) {
+    VAE_REQUIRE(workspace && workspace_bytes >= (int64_t)split * M * N * (int64_t)sizeof(float) && vae_aligned16(workspace),
+                "vae_gemm_slabs: workspace too small or misaligned: need %lld bytes", (long long)((int64_t)split * M * N * 4));
+    g.C = workspace;
+    g.ldc = N;
+    g.bias = nullptr;
+    g.accumulate = 0;
+    *slabs_out = split;
+  } else if (split > 1) {
     VAE_REQUIRE(workspace && workspace_bytes >= (int64_t)split * M * N * (int64_t)sizeof(float),
                 "vae_gemm: workspace too small: need %lld bytes (see vae_gemm_workspace_bytes)",
                 (long long)((int64_t)split * M * N * 4));
@@ -718,7 +729,7 @@ extern "C" int vae_gemm(int layout, int precision, int64_t M, int64_t N, int64_t
     else launch_t<TN, 1>(g, norm, grid, st, plan.tile);
   }
   VAE_CHECK_LAUNCH("vae_gemm");
-  if (split > 1) {
+  if (split > 1 && !slabs_out) {
     const int64_t total = M * N;
     const bool vec = (N % 4 == 0) && (ldc % 4 == 0) && vae_aligned16(C) && (!bias || vae_aligned16(bias)) &&
                      (total % 4 == 0);
@@ -733,4 +744,25 @@ extern "C" int vae_gemm(int layout, int precision, int64_t M, int64_t N, int64_t
     VAE_CHECK_LAUNCH("vae_gemm(splitk_reduce)");
   }
   return VAE_OK;
+}
+}  // namespace
+
+extern "C" int vae_gemm(int layout, int precision, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
+                        const float* B, int64_t ldb, float* C, int64_t ldc, const float* bias, const float* x_mean,
+                        int accumulate, float* workspace, int64_t workspace_bytes, void* stream) {
+  return gemm_impl(layout, precision, M, N, K, A, lda, B, ldb, C, ldc, bias, x_mean, accumulate, workspace,
+                   workspace_bytes, stream, nullptr);
+}
+
+extern "C" int64_t vae_gemm_slabs_workspace_bytes(int64_t M, int64_t N, int64_t K) {
+  const int64_t b = vae_gemm_workspace_bytes(M, N, K);
+  return b > 0 ? b : M * N * (int64_t)sizeof(float);
+}
+
+extern "C" int vae_gemm_slabs(int layout, int precision, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
+                              const float* B, int64_t ldb, float* workspace, int64_t workspace_bytes, int* n_slabs,
+                              void* stream) {
+  VAE_REQUIRE(n_slabs, "vae_gemm_slabs: n_slabs is null");
+  return gemm_impl(layout, precision, M, N, K, A, lda, B, ldb, nullptr, N, nullptr, nullptr, 0, workspace,
+                   workspace_bytes, stream, n_slabs);
 }

@@ -1,0 +1,632 @@
+// The "middle" of the single-hidden-layer training step (gfx950): everything between the two
+// gene-sized GEMM groups, fused into one launch per direction plus one launch for the small
+// parameter gradients.
+//
+//   forward  (Encoder.forward modules.py:262-270, FCLayers :111-114, DecoderSCVI.forward :394-399):
+//     split-K slabs of the first encoder Linear -> +bias -> GELU -> LayerNorm (z and library halves)
+//     -> [mean; var] heads -> softplus, reparameterised sample, Gaussian KL (task.py:188-198)
+//     -> first decoder Linear (latent -> hidden) -> GELU -> LayerNorm.
+//   backward: the exact reverse, from the split-K slabs of the decoder-head dgrad down to the
+//     gradient of the encoder pre-activations (the operand of the gene-sized wgrad GEMM).
+//   small_wgrad_batch: every parameter gradient that is a sum over cells of per-cell quantities
+//     (weight gradients of the three small Linears as outer products, all bias / LayerNorm
+//     gradients as column sums), one launch, fixed summation order, no float atomics.
+//
+// One 256-thread workgroup owns one cell: the hidden vectors (<= 1024 wide) live in registers,
+// element e of a vector belongs to thread e % 256.  Per-cell quantities needed for cross-cell
+// sums are written as rows and reduced by small_wgrad_batch.
+#include "middle.h"
+#include "common.h"
+
+#include <stdlib.h>
+
+namespace {
+
+constexpr int T = 256;   // threads per workgroup
+constexpr int ME = 4;    // elements per thread: hidden widths up to 1024
+
+__device__ __forceinline__ float gelu_f(float v) { return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_grad(float v) {
+  const float cdf = 0.5f * (1.f + erff(v * 0.70710678118654752440f));
+  const float pdf = 0.39894228040143267794f * expf(-0.5f * v * v);
+  return cdf + v * pdf;
+}
+
+// sum_{i<n} a[i*sa] * w[i*sw] with the global loads of w issued U at a time (a is LDS / cached).
+template <int U>
+__device__ __forceinline__ float dot_batched(const float* a, int sa, const float* __restrict__ w, int64_t sw, int n) {
+  float acc = 0.f;
+  for (int i = 0; i < n; i += U) {  // the last batch is masked, not serialised
+    float wv[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) wv[u] = (i + u < n) ? w[(int64_t)(i + u) * sw] : 0.f;
+#pragma unroll
+    for (int u = 0; u < U; ++u) acc = fmaf((i + u < n) ? a[(i + u) * sa] : 0.f, wv[u], acc);
+  }
+  return acc;
+}
+
+// Sums the nslab split-K partials of ME elements per thread (element e = t + T*i < W), slab order,
+// with the loads of eight slabs of every element in flight together.
+__device__ __forceinline__ void slab_sum(const float* __restrict__ base, int nslab, int64_t stride, int W, float (&v)[4]) {
+  const int t = threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) v[i] = 0.f;
+  for (int s = 0; s < nslab; s += 8) {
+    float w[4][8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        w[i][u] = (t + T * i < W && s + u < nslab) ? base[(int64_t)(s + u) * stride + t + T * i] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[i] += w[i][u];
+  }
+}
+
+// Sums N values over the workgroup (4 waves); red holds >= 4*N floats.  Every thread gets all sums.
+template <int N>
+__device__ __forceinline__ void block_sums(float (&v)[N], float* red) {
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] = wave_sum(v[i]);
+  __syncthreads();
+  if (l == 0) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) red[i * 4 + w] = v[i];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] = (red[i * 4 + 0] + red[i * 4 + 1]) + (red[i * 4 + 2] + red[i * 4 + 3]);
+}
+
+// LayerNorm statistics of g[] over two adjacent segments [0,W0) and [W0,W0+W1) (W1 may be 0).
+__device__ __forceinline__ void ln_stats2(const float (&g)[ME], int W0, int W1, float* red, float (&mu)[2],
+                                          float (&rs)[2]) {
+  float s[2] = {0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < ME; ++i) {
+    const int e = threadIdx.x + T * i;
+    if (e < W0) s[0] += g[i];
+    else if (e < W0 + W1) s[1] += g[i];
+  }
+  block_sums<2>(s, red);
+  mu[0] = s[0] / (float)W0;
+  mu[1] = W1 > 0 ? s[1] / (float)W1 : 0.f;
+  float q[2] = {0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < ME; ++i) {
+    const int e = threadIdx.x + T * i;
+    if (e < W0) { const float d = g[i] - mu[0]; q[0] += d * d; }
+    else if (e < W0 + W1) { const float d = g[i] - mu[1]; q[1] += d * d; }
+  }
+  block_sums<2>(q, red);
+  rs[0] = 1.f / sqrtf(q[0] / (float)W0 + 1e-5f);
+  rs[1] = W1 > 0 ? 1.f / sqrtf(q[1] / (float)W1 + 1e-5f) : 0.f;
+}
+
+struct MidFwd {
+  const float* slabs; int nslab; int64_t slab_stride;   // [nslab][B][H+Hl] partial pre-activations
+  const float* enc_b0;
+  const float *gz, *bz, *gl, *bl;                        // LayerNorm affine, z / library encoder
+  const float *hz_w, *hz_b, *hl_w, *hl_b;               // heads: (L+1,H),(L+1) and (2,Hl),(2)
+  const float *eps_z, *eps_l;
+  const float *d_w, *d_b, *gd, *bd;                      // decoder layer 0: (Hd,L), (Hd), LayerNorm affine
+  float l_mean, l_var;
+  int B, H, Hl, L, Hd;
+  float *pre_enc0, *h_enc0;                              // (B, H+Hl)
+  float *ln_mz, *ln_rz, *ln_ml, *ln_rl;
+  float *heads_z, *heads_l, *qz_v, *z, *kl_z, *ql_v, *library, *kl_l;
+  float *dec_pre, *dec_h, *ln_md, *ln_rd;
+};
+
+// softplus variance, sample and KL for one encoder, executed by ONE wave (lane j = latent j).
+// hd[0:L] = q_m, hd[L] = variance pre-activation (LDS).  Mirrors reparam_kl_fwd_kernel (rowops.hip).
+__device__ __forceinline__ void reparam_wave(const float* hd, int L, const float* eps_row, float pm, float pv, int lane,
+                                             float* z_row, float* z_lds, float* qv_out, float* kl_out) {
+  const float v = softplus20(hd[L]) + 1e-4f;
+  const float sq = sqrtf(v), sp = sqrtf(pv);
+  const float r0 = sq / sp;
+  const float r = r0 * r0;
+  const float lr = logf(r);
+  float acc = 0.f;
+  if (lane < L) {
+    const float m = hd[lane];
+    const float t = (m - pm) / sp;
+    acc = 0.5f * (r + t * t - 1.f - lr);
+    const float zz = m + eps_row[lane] * sq;
+    z_row[lane] = zz;
+    if (z_lds) z_lds[lane] = zz;
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) {
+    *qv_out = v;
+    *kl_out = acc;
+  }
+}
+
+// Copies the first decoder weight (Hd, L) into LDS with an odd row stride LP (coalesced loads; the
+// per-row reads that follow are conflict-free).  Completed by the caller's next __syncthreads().
+__device__ __forceinline__ void stage_dec_w(const float* __restrict__ w, int Hd, int L, int LP, float* ws) {
+  const int total = Hd * L;
+  for (int i0 = 0; i0 < total; i0 += T * 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = i0 + threadIdx.x + T * u;
+      v[u] = i < total ? w[i] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = i0 + threadIdx.x + T * u;
+      if (i < total) ws[(i / L) * LP + (i % L)] = v[u];
+    }
+  }
+}
+
+__global__ __launch_bounds__(T) void mid_fwd_kernel(MidFwd a) {
+  extern __shared__ __attribute__((aligned(16))) float dyn[];  // decoder weight, Hd x LP
+  __shared__ float hs[ME * T];   // LayerNorm outputs of both encoders (H+Hl)
+  __shared__ float hd[72];       // head outputs: [0:L] q_m z, [L] var z, [L+1] q_m l, [L+2] var l
+  __shared__ float zs[64];
+  __shared__ float red[16];
+  const int t = threadIdx.x, b = blockIdx.x;
+  const int lane = t & 63, wave = t >> 6;
+  const int H = a.H, Hl = a.Hl, HE = a.H + a.Hl, L = a.L, Hd = a.Hd;
+  const int LP = L | 1;
+
+  // parameters this thread needs later: requested now, so their latency hides behind the slab sums
+  float eb[ME], gam[ME], bet[ME], db[ME], dgam[ME], dbet[ME];
+#pragma unroll
+  for (int i = 0; i < ME; ++i) {
+    const int e = t + T * i;
+    const bool zh = e < H;
+    eb[i] = e < HE ? a.enc_b0[e] : 0.f;
+    gam[i] = e < HE ? (zh ? a.gz[e] : a.gl[e - H]) : 0.f;
+    bet[i] = e < HE ? (zh ? a.bz[e] : a.bl[e - H]) : 0.f;
+    db[i] = e < Hd ? a.d_b[e] : 0.f;
+    dgam[i] = e < Hd ? a.gd[e] : 0.f;
+    dbet[i] = e < Hd ? a.bd[e] : 0.f;
+  }
+  stage_dec_w(a.d_w, Hd, L, LP, dyn);
+
+  // 1. sum the split-K slabs, add the bias: pre-activation of both first layers
+  float pre[ME], g[ME];
+  slab_sum(a.slabs + (int64_t)b * HE, a.nslab, a.slab_stride, HE, pre);
+#pragma unroll
+  for (int i = 0; i < ME; ++i) {
+    const int e = t + T * i;
+    if (e < HE) {
+      pre[i] += eb[i];
+      a.pre_enc0[(int64_t)b * HE + e] = pre[i];
+    }
+    g[i] = e < HE ? gelu_f(pre[i]) : 0.f;
+  }
+  // 2. LayerNorm of the two halves
+  float mu[2], rs[2];
+  ln_stats2(g, H, Hl, red, mu, rs);
+#pragma unroll
+  for (int i = 0; i < ME; ++i) {
+    const int e = t + T * i;
+    if (e < HE) {
+      const bool zh = e < H;
+      const float h = (g[i] - (zh ? mu[0] : mu[1])) * (zh ? rs[0] : rs[1]) * gam[i] + bet[i];
+      hs[e] = h;
+      a.h_enc0[(int64_t)b * HE + e] = h;
+    }
+  }
+  if (t == 0) {
+    a.ln_mz[b] = mu[0]; a.ln_rz[b] = rs[0];
+    a.ln_ml[b] = mu[1]; a.ln_rl[b] = rs[1];
+  }
+  __syncthreads();
+  // 3. heads: output o <= L -> z heads over H, o = L+1, L+2 -> library heads over Hl.  A wave owns
+  //    four outputs at a time; its lanes run along k, so every weight load is a coalesced row read.
+  {
+    const int nmax = max(H, Hl);
+    for (int base = wave; base < L + 3; base += 16) {
+      float acc[4] = {0.f, 0.f, 0.f, 0.f};
+      for (int c = 0; c < nmax; c += 256) {
+        float wv[4][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int o = base + 4 * r;
+          const bool zo = o <= L;
+          const float* w = zo ? a.hz_w + (int64_t)o * H : a.hl_w + (int64_t)(o - L - 1) * Hl;
+          const int n = o < L + 3 ? (zo ? H : Hl) : 0;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int k = c + lane + 64 * i;
+            wv[r][i] = k < n ? w[k] : 0.f;
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int o = base + 4 * r;
+          const bool zo = o <= L;
+          const int n = o < L + 3 ? (zo ? H : Hl) : 0;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int k = c + lane + 64 * i;
+            if (k < n) acc[r] = fmaf(hs[(zo ? 0 : H) + k], wv[r][i], acc[r]);
+          }
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int o = base + 4 * r;
+        const float v = wave_sum(acc[r]);
+        if (lane == 0 && o < L + 3) hd[o] = v + (o <= L ? a.hz_b[o] : a.hl_b[o - L - 1]);
+      }
+    }
+  }
+  __syncthreads();
+  // 4. reparameterised samples + KL: wave 0 -> z, wave 1 -> library
+  if (wave == 0) {
+    if (lane <= L) a.heads_z[(int64_t)b * (L + 1) + lane] = hd[lane];
+    reparam_wave(hd, L, a.eps_z + (int64_t)b * L, 0.f, 1.f, lane, a.z + (int64_t)b * L, zs, a.qz_v + b, a.kl_z + b);
+  } else if (wave == 1) {
+    if (lane < 2) a.heads_l[(int64_t)b * 2 + lane] = hd[L + 1 + lane];
+    reparam_wave(hd + L + 1, 1, a.eps_l + b, a.l_mean, a.l_var, lane, a.library + b, nullptr, a.ql_v + b, a.kl_l + b);
+  }
+  __syncthreads();
+  // 5. first decoder layer: Linear(L -> Hd) + GELU + LayerNorm, weight rows from LDS
+  float gd[ME];
+#pragma unroll
+  for (int i = 0; i < ME; ++i) {
+    const int n = t + T * i;
+    float v = 0.f;
+    if (n < Hd) {
+      const float* w = dyn + n * LP;
+      for (int j = 0; j < L; ++j) v = fmaf(zs[j], w[j], v);
+      v += db[i];
+      a.dec_pre[(int64_t)b * Hd + n] = v;
+    }
+    gd[i] = n < Hd ? gelu_f(v) : 0.f;
+  }
+  ln_stats2(gd, Hd, 0, red, mu, rs);
+#pragma unroll
+  for (int i = 0; i < ME; ++i) {
+    const int n = t + T * i;
+    if (n < Hd) a.dec_h[(int64_t)b * Hd + n] = (gd[i] - mu[0]) * rs[0] * dgam[i] + dbet[i];
+  }
+  if (t == 0) {
+    a.ln_md[b] = mu[0];
+    a.ln_rd[b] = rs[0];
+  }
+}
+
+struct MidBwd {
+  const float* slabs; int nslab; int64_t slab_stride;   // [nslab][B][Hd] partial d(loss)/d(dec_h)
+  const float *dec_pre, *ln_md, *ln_rd, *gd;
+  const float* d_w;                                      // (Hd, L)
+  const float* dz_extra;                                 // (B, L) or null: gradient from the cell heads
+  const float *heads_z, *heads_l, *eps_z, *eps_l, *qz_v, *ql_v, *dlibrary;
+  float g_kl, l_mean, l_var;
+  const float *hz_w, *hl_w;
+  const float *pre_enc0, *ln_mz, *ln_rz, *ln_ml, *ln_rl, *gz, *gl;
+  int B, H, Hl, L, Hd;
+  float *dbet_d, *dgam_d, *dpre_d;                       // (B, Hd) rows
+  float *dq_z, *dq_l;                                    // (B, L+1), (B, 2)
+  float *dbet_e, *dgam_e, *dpre_e;                       // (B, H+Hl) rows
+};
+
+// Backward of reparam_wave, by one wave.  Mirrors reparam_kl_bwd_kernel (rowops.hip).
+__device__ __forceinline__ void reparam_bwd_wave(const float* dz_lds, const float* hrow, const float* eps_row, float v,
+                                                 float gk, int L, float pm, float pv, int lane, float* dq_row,
+                                                 float* dq_lds) {
+  const float sq = sqrtf(v);
+  float dv = 0.f;
+  if (lane < L) {
+    const float d = dz_lds[lane];
+    const float o = d + gk * (hrow[lane] - pm) / pv;
+    dq_row[lane] = o;
+    dq_lds[lane] = o;
+    dv = d * eps_row[lane];
+  }
+  dv = wave_sum(dv);
+  dv = dv * 0.5f / sq + gk * (float)L * 0.5f * (1.f / pv - 1.f / v);
+  const float o = dv * softplus20_grad(hrow[L]);
+  if (lane == 0) {
+    dq_row[L] = o;
+    dq_lds[L] = o;
+  }
+}
+
+__global__ __launch_bounds__(T) void mid_bwd_kernel(MidBwd a) {
+  extern __shared__ __attribute__((aligned(16))) float dyn[];  // decoder weight, Hd x LP
+  __shared__ float ds[ME * T];   // d pre-activation of the decoder layer
+  __shared__ float dzs[64];
+  __shared__ float dq[72];       // [0:L+1] z heads, [L+1:L+3] library heads
+  __shared__ float red[16];
+  const int t = threadIdx.x, b = blockIdx.x;
+  const int H = a.H, Hl = a.Hl, HE = a.H + a.Hl, L = a.L, Hd = a.Hd;
+
+  const int LP = L | 1;
+  stage_dec_w(a.d_w, Hd, L, LP, dyn);
+  // 1. d(dec_h): sum of the dgrad slabs; LayerNorm + GELU backward of the decoder layer
+  const float mud = a.ln_md[b], rsd = a.ln_rd[b];
+  const float mu0 = a.ln_mz[b], rs0 = a.ln_rz[b], mu1 = a.ln_ml[b], rs1 = a.ln_rl[b];
+  float pd[ME], gdv[ME], pe[ME], gev[ME];  // requested now, used after the slab sums
+#pragma unroll
+  for (int i = 0; i < ME; ++i) {
+    const int e = t + T * i;
+    pd[i] = e < Hd ? a.dec_pre[(int64_t)b * Hd + e] : 0.f;
+    gdv[i] = e < Hd ? a.gd[e] : 0.f;
+    pe[i] = e < HE ? a.pre_enc0[(int64_t)b * HE + e] : 0.f;
+    gev[i] = e < HE ? (e < H ? a.gz[e] : a.gl[e - H]) : 0.f;
+  }
+  float dx[ME], xh[ME], pv[ME], dyv[ME];
+  float s[2] = {0.f, 0.f};
+  slab_sum(a.slabs + (int64_t)b * Hd, a.nslab, a.slab_stride, Hd, dyv);
+#pragma unroll
+  for (int i = 0; i < ME; ++i) {
+    const int n = t + T * i;
+    dx[i] = xh[i] = pv[i] = 0.f;
+    if (n < Hd) {
+      const float dy = dyv[i];
+      pv[i] = pd[i];
+      xh[i] = (gelu_f(pv[i]) - mud) * rsd;
+      dx[i] = dy * gdv[i];
+      a.dbet_d[(int64_t)b * Hd + n] = dy;
+      a.dgam_d[(int64_t)b * Hd + n] = dy * xh[i];
+      s[0] += dx[i];
+      s[1] += dx[i] * xh[i];
+    }
+  }
+  block_sums<2>(s, red);
+  s[0] /= (float)Hd;
+  s[1] /= (float)Hd;
+#pragma unroll
+  for (int i = 0; i < ME; ++i) {
+    const int n = t + T * i;
+    if (n < Hd) {
+      const float dg = rsd * (dx[i] - s[0] - xh[i] * s[1]);
+      const float v = dg * gelu_grad(pv[i]);
+      ds[n] = v;
+      a.dpre_d[(int64_t)b * Hd + n] = v;
+    }
+  }
+  __syncthreads();
+  // 2. dz[j] = sum_n dpre_d[n] W[n][j] (+ cell-head gradient); 8 threads per output
+  {
+    const int part = t & 7;
+    for (int j = t >> 3; j < L; j += T / 8) {
+      float acc = 0.f;
+      for (int n = part; n < Hd; n += 8) acc = fmaf(ds[n], dyn[n * LP + j], acc);
+      acc += __shfl_xor(acc, 1, WAVE);
+      acc += __shfl_xor(acc, 2, WAVE);
+      acc += __shfl_xor(acc, 4, WAVE);
+      if (part == 0) dzs[j] = acc + (a.dz_extra ? a.dz_extra[(int64_t)b * L + j] : 0.f);
+    }
+  }
+  __syncthreads();
+  // 3. reparameterisation / KL backward: wave 0 -> z heads, wave 1 -> library heads
+  {
+    const int lane = t & 63, wave = t >> 6;
+    if (wave == 0) {
+      reparam_bwd_wave(dzs, a.heads_z + (int64_t)b * (L + 1), a.eps_z + (int64_t)b * L, a.qz_v[b], a.g_kl, L, 0.f, 1.f,
+                       lane, a.dq_z + (int64_t)b * (L + 1), dq);
+    } else if (wave == 1) {
+      __shared__ float dlib[1];
+      if (lane == 0) dlib[0] = a.dlibrary[b];
+      reparam_bwd_wave(dlib, a.heads_l + (int64_t)b * 2, a.eps_l + b, a.ql_v[b], a.g_kl, 1, a.l_mean, a.l_var, lane,
+                       a.dq_l + (int64_t)b * 2, dq + L + 1);
+    }
+  }
+  __syncthreads();
+  // 4. gradient at the LayerNorm outputs of both encoders, then LayerNorm + GELU backward
+  float q4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < ME; ++i) {
+    const int e = t + T * i;
+    dx[i] = xh[i] = pv[i] = 0.f;
+    if (e < HE) {
+      const bool zh = e < H;
+      float dy = 0.f;
+      if (zh) {
+        dy = dot_batched<16>(dq, 1, a.hz_w + e, H, L + 1);
+      } else {
+        dy = dq[L + 1] * a.hl_w[e - H];
+        dy = fmaf(dq[L + 2], a.hl_w[Hl + e - H], dy);
+      }
+      pv[i] = pe[i];
+      xh[i] = (gelu_f(pv[i]) - (zh ? mu0 : mu1)) * (zh ? rs0 : rs1);
+      dx[i] = dy * gev[i];
+      a.dbet_e[(int64_t)b * HE + e] = dy;
+      a.dgam_e[(int64_t)b * HE + e] = dy * xh[i];
+      q4[zh ? 0 : 2] += dx[i];
+      q4[zh ? 1 : 3] += dx[i] * xh[i];
+    }
+  }
+  block_sums<4>(q4, red);
+  q4[0] /= (float)H; q4[1] /= (float)H;
+  q4[2] /= (float)Hl; q4[3] /= (float)Hl;
+#pragma unroll
+  for (int i = 0; i < ME; ++i) {
+    const int e = t + T * i;
+    if (e < HE) {
+      const bool zh = e < H;
+      const float dg = (zh ? rs0 : rs1) * (dx[i] - (zh ? q4[0] : q4[2]) - xh[i] * (zh ? q4[1] : q4[3]));
+      a.dpre_e[(int64_t)b * HE + e] = dg * gelu_grad(pv[i]);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// out[p*sp + q*sq] = sum_b U[b][p] * V[b][q]   (U null: column sums of V), for a table of tasks.
+// A workgroup owns 8 p x 64 q outputs of one task: 128 cells at a time are staged in LDS (all the
+// global loads of a round in flight together); thread (q = t%64, r = t/64) sums the cells
+// b = r (mod 4) in ascending order, the four partial sums are combined r = 0..3: deterministic.
+// ---------------------------------------------------------------------------------------
+constexpr int MAX_TASKS = 16;
+constexpr int PT = 8;
+struct WgradTask {
+  const float* U; int ldU, P;
+  const float* V; int ldV, Q;
+  float* out; int sp, sq;
+  int tile0;  // first workgroup of this task
+};
+struct WgradBatch {
+  WgradTask task[MAX_TASKS];
+  int ntask, B;
+};
+
+__global__ __launch_bounds__(T) void small_wgrad_kernel(WgradBatch wb) {
+  constexpr int RC = 128;                 // cells staged per round
+  __shared__ float Vs[RC][64];            // V[b0+row][q0+col]
+  __shared__ float Us[RC][PT];            // U[b0+row][p0+i] (ones for a column sum)
+  __shared__ float comb[4][PT][64];
+  int k = 0;
+#pragma unroll
+  for (int i = 1; i < MAX_TASKS; ++i) k += (i < wb.ntask && (int)blockIdx.x >= wb.task[i].tile0) ? 1 : 0;
+  const WgradTask tk = wb.task[k];
+  const int tile = blockIdx.x - tk.tile0;
+  const int qtiles = (tk.Q + 63) / 64;
+  const int p0 = (tile / qtiles) * PT, q0 = (tile % qtiles) * 64;
+  const int l = threadIdx.x & 63, r = threadIdx.x >> 6;
+  const int np = min(PT, tk.P - p0);
+  const bool qok = q0 + l < tk.Q;
+  float acc[PT];
+#pragma unroll
+  for (int i = 0; i < PT; ++i) acc[i] = 0.f;
+
+  float vreg[RC / 4], ureg[RC * PT / T];
+  auto fetch = [&](int b0) {  // thread (l, r) loads column l of rows r, r+4, ...: coalesced, all in flight
+    const int rows = min(RC, wb.B - b0);
+#pragma unroll
+    for (int j = 0; j < RC / 4; ++j) {
+      const int row = r + 4 * j;
+      vreg[j] = (row < rows && qok) ? tk.V[(int64_t)(b0 + row) * tk.ldV + q0 + l] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < RC * PT / T; ++j) {
+      const int idx = threadIdx.x + T * j, row = idx / PT, i = idx % PT;
+      float u = 0.f;
+      if (row < rows && i < np) u = tk.U ? tk.U[(int64_t)(b0 + row) * tk.ldU + p0 + i] : 1.f;
+      ureg[j] = u;
+    }
+  };
+  fetch(0);
+  for (int b0 = 0; b0 < wb.B; b0 += RC) {
+    const int rows = min(RC, wb.B - b0);
+    __syncthreads();  // previous round's reads are done
+#pragma unroll
+    for (int j = 0; j < RC / 4; ++j) Vs[r + 4 * j][l] = vreg[j];
+#pragma unroll
+    for (int j = 0; j < RC * PT / T; ++j) {
+      const int idx = threadIdx.x + T * j;
+      Us[idx / PT][idx % PT] = ureg[j];
+    }
+    __syncthreads();
+    if (b0 + RC < wb.B) fetch(b0 + RC);  // next round's loads fly during this round's sums
+    // thread (l, r) accumulates rows r, r+4, ... in ascending order
+    for (int row = r; row < rows; row += 4) {
+      const float v = Vs[row][l];
+      const float4 u0 = *reinterpret_cast<const float4*>(&Us[row][0]);
+      const float4 u1 = *reinterpret_cast<const float4*>(&Us[row][4]);
+      acc[0] = fmaf(u0.x, v, acc[0]); acc[1] = fmaf(u0.y, v, acc[1]);
+      acc[2] = fmaf(u0.z, v, acc[2]); acc[3] = fmaf(u0.w, v, acc[3]);
+      acc[4] = fmaf(u1.x, v, acc[4]); acc[5] = fmaf(u1.y, v, acc[5]);
+      acc[6] = fmaf(u1.z, v, acc[6]); acc[7] = fmaf(u1.w, v, acc[7]);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < PT; ++i) comb[r][i][l] = acc[i];
+  __syncthreads();
+  if (r == 0 && qok) {
+    for (int i = 0; i < np; ++i)
+      tk.out[(int64_t)(p0 + i) * tk.sp + (int64_t)(q0 + l) * tk.sq] =
+          ((comb[0][i][l] + comb[1][i][l]) + comb[2][i][l]) + comb[3][i][l];
+  }
+}
+
+}  // namespace
+
+// ---- internal entry points used by step.hip (not part of the public C ABI) -----------------
+bool vae_mid_supported(const vae_step_config& c) {
+  static const bool off = getenv("VAE_NO_FUSED_MIDDLE") != nullptr;  // A/B knob: run the unfused launch sequence
+  if (off) return false;
+  return c.n_layers == 1 && c.H + c.Hl <= ME * T && c.Hd <= ME * T && c.L + 3 <= 64 && c.L >= 1 &&
+         c.Hd * (c.L | 1) * 4 <= 48 * 1024;  // the first decoder weight is staged in LDS
+}
+
+int vae_mid_forward(const vae_step_config& c, const vae_step_tensors* p, const float* slabs, int nslab, const float* eps_z,
+                    const float* eps_l, float* pre_enc0, float* h_enc0, float* ln_mz, float* ln_rz, float* ln_ml,
+                    float* ln_rl, float* heads_z, float* heads_l, float* qz_v, float* z, float* kl_z, float* ql_v,
+                    float* library, float* kl_l, float* dec_pre, float* dec_h, float* ln_md, float* ln_rd, void* stream) {
+  MidFwd a;
+  a.slabs = slabs; a.nslab = nslab; a.slab_stride = c.B * (c.H + c.Hl);
+  a.enc_b0 = p->enc_b0;
+  a.gz = p->encz_ln_g[0]; a.bz = p->encz_ln_b[0]; a.gl = p->encl_ln_g; a.bl = p->encl_ln_b;
+  a.hz_w = p->hz_w; a.hz_b = p->hz_b; a.hl_w = p->hl_w; a.hl_b = p->hl_b;
+  a.eps_z = eps_z; a.eps_l = eps_l;
+  a.d_w = p->dec_w[0]; a.d_b = p->dec_b[0]; a.gd = p->dec_ln_g[0]; a.bd = p->dec_ln_b[0];
+  a.l_mean = c.l_mean; a.l_var = c.l_var;
+  a.B = (int)c.B; a.H = (int)c.H; a.Hl = (int)c.Hl; a.L = (int)c.L; a.Hd = (int)c.Hd;
+  a.pre_enc0 = pre_enc0; a.h_enc0 = h_enc0;
+  a.ln_mz = ln_mz; a.ln_rz = ln_rz; a.ln_ml = ln_ml; a.ln_rl = ln_rl;
+  a.heads_z = heads_z; a.heads_l = heads_l; a.qz_v = qz_v; a.z = z; a.kl_z = kl_z;
+  a.ql_v = ql_v; a.library = library; a.kl_l = kl_l;
+  a.dec_pre = dec_pre; a.dec_h = dec_h; a.ln_md = ln_md; a.ln_rd = ln_rd;
+  hipLaunchKernelGGL(mid_fwd_kernel, dim3((unsigned)c.B), dim3(T), (size_t)(c.Hd * (c.L | 1) * 4), (hipStream_t)stream, a);
+  VAE_CHECK_LAUNCH("vae_elbo_step_forward(mid)");
+  return VAE_OK;
+}
+
+int vae_mid_backward(const vae_step_config& c, const vae_step_tensors* p, const vae_step_tensors* g, const float* slabs,
+                     int nslab, const float* eps_z, const float* eps_l, const float* dz_extra, float g_kl,
+                     const float* dec_pre, const float* ln_md, const float* ln_rd, const float* heads_z,
+                     const float* heads_l, const float* qz_v, const float* ql_v, const float* dlibrary,
+                     const float* pre_enc0, const float* ln_mz, const float* ln_rz, const float* ln_ml,
+                     const float* ln_rl, const float* z, const float* h_enc0, float* dbet_d, float* dgam_d,
+                     float* dpre_d, float* dq_z, float* dq_l, float* dbet_e, float* dgam_e, float* dpre_e, void* stream) {
+  MidBwd a;
+  a.slabs = slabs; a.nslab = nslab; a.slab_stride = c.B * c.Hd;
+  a.dec_pre = dec_pre; a.ln_md = ln_md; a.ln_rd = ln_rd; a.gd = p->dec_ln_g[0];
+  a.d_w = p->dec_w[0];
+  a.dz_extra = dz_extra;
+  a.heads_z = heads_z; a.heads_l = heads_l; a.eps_z = eps_z; a.eps_l = eps_l; a.qz_v = qz_v; a.ql_v = ql_v;
+  a.dlibrary = dlibrary;
+  a.g_kl = g_kl; a.l_mean = c.l_mean; a.l_var = c.l_var;
+  a.hz_w = p->hz_w; a.hl_w = p->hl_w;
+  a.pre_enc0 = pre_enc0; a.ln_mz = ln_mz; a.ln_rz = ln_rz; a.ln_ml = ln_ml; a.ln_rl = ln_rl;
+  a.gz = p->encz_ln_g[0]; a.gl = p->encl_ln_g;
+  a.B = (int)c.B; a.H = (int)c.H; a.Hl = (int)c.Hl; a.L = (int)c.L; a.Hd = (int)c.Hd;
+  a.dbet_d = dbet_d; a.dgam_d = dgam_d; a.dpre_d = dpre_d;
+  a.dq_z = dq_z; a.dq_l = dq_l;
+  a.dbet_e = dbet_e; a.dgam_e = dgam_e; a.dpre_e = dpre_e;
+  hipLaunchKernelGGL(mid_bwd_kernel, dim3((unsigned)c.B), dim3(T), (size_t)(c.Hd * (c.L | 1) * 4), (hipStream_t)stream, a);
+  VAE_CHECK_LAUNCH("vae_elbo_step_backward(mid)");
+
+  // every small parameter gradient of the step, one launch
+  const int B = (int)c.B, H = (int)c.H, Hl = (int)c.Hl, HE = H + Hl, L = (int)c.L, Hd = (int)c.Hd;
+  WgradBatch wb;
+  int n = 0, tiles = 0;
+  auto add = [&](const float* U, int ldU, int P, const float* V, int ldV, int Q, float* out, int sp, int sq) {
+    WgradTask& k = wb.task[n++];
+    k.U = U; k.ldU = ldU; k.P = P; k.V = V; k.ldV = ldV; k.Q = Q; k.out = out; k.sp = sp; k.sq = sq;
+    k.tile0 = tiles;
+    tiles += ((P + PT - 1) / PT) * ((Q + 63) / 64);
+  };
+  add(z, L, L, dpre_d, Hd, Hd, g->dec_w[0], 1, L);              // dW_dec0[n][j] = sum_b dpre_d[b][n] z[b][j]
+  add(dq_z, L + 1, L + 1, h_enc0, HE, H, g->hz_w, H, 1);         // dW_heads_z[j][k] = sum_b dq_z[b][j] h_z[b][k]
+  add(dq_l, 2, 2, h_enc0 + H, HE, Hl, g->hl_w, Hl, 1);           // dW_heads_l
+  add(nullptr, 0, 1, dpre_d, Hd, Hd, g->dec_b[0], 0, 1);
+  add(nullptr, 0, 1, dgam_d, Hd, Hd, g->dec_ln_g[0], 0, 1);
+  add(nullptr, 0, 1, dbet_d, Hd, Hd, g->dec_ln_b[0], 0, 1);
+  add(nullptr, 0, 1, dq_z, L + 1, L + 1, g->hz_b, 0, 1);
+  add(nullptr, 0, 1, dq_l, 2, 2, g->hl_b, 0, 1);
+  add(nullptr, 0, 1, dgam_e, HE, H, g->encz_ln_g[0], 0, 1);
+  add(nullptr, 0, 1, dgam_e + H, HE, Hl, g->encl_ln_g, 0, 1);
+  add(nullptr, 0, 1, dbet_e, HE, H, g->encz_ln_b[0], 0, 1);
+  add(nullptr, 0, 1, dbet_e + H, HE, Hl, g->encl_ln_b, 0, 1);
+  add(nullptr, 0, 1, dpre_e, HE, HE, g->enc_b0, 0, 1);
+  wb.ntask = n;
+  wb.B = B;
+  hipLaunchKernelGGL(small_wgrad_kernel, dim3((unsigned)tiles), dim3(T), 0, (hipStream_t)stream, wb);
+  VAE_CHECK_LAUNCH("vae_elbo_step_backward(small wgrad)");
+  return VAE_OK;
+}

@@ -41,13 +41,44 @@ __global__ __launch_bounds__(256) void row_mean_kernel(const float* __restrict__
 // Row mean AND the normalised counts xn = x / mean - 1 (Encoder.forward, modules.py:264) in one
 // launch: the row is summed from HBM, then re-read (L2-resident: one row is G*4 bytes) and written
 // normalised.  The encoder GEMMs (forward and wgrad) then stream xn with plain LDS-DMA loads.
+// REG: the whole row (G <= 256*4*EPT, 16-byte aligned) is held in registers: one HBM pass with
+// every load of the row in flight.
+template <bool REG>
 __global__ __launch_bounds__(256) void normalize_rows_kernel(const float* __restrict__ x, int64_t ld, int B, int G,
                                                              int vec, float* __restrict__ mean,
                                                              float* __restrict__ xn, int64_t ld_xn) {
+  constexpr int EPT = 20;
   __shared__ float red[4];
   const int b = blockIdx.x;
   const float* row = x + (int64_t)b * ld;
   float* orow = xn + (int64_t)b * ld_xn;
+  if (REG) {
+    const int n4 = G >> 2;
+    float4 v[EPT];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) {
+      const int i = threadIdx.x + 256 * j;
+      v[j] = i < n4 ? reinterpret_cast<const float4*>(row)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+    for (int i = (n4 << 2) + threadIdx.x; i < G; i += 256) s += row[i];
+    s = block_sum<4>(s, red);
+    const float m = s / (float)G;
+    if (threadIdx.x == 0) mean[b] = m;
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) {
+      const int i = threadIdx.x + 256 * j;
+      if (i < n4) {
+        float4 o;
+        o.x = v[j].x / m - 1.f; o.y = v[j].y / m - 1.f; o.z = v[j].z / m - 1.f; o.w = v[j].w / m - 1.f;
+        reinterpret_cast<float4*>(orow)[i] = o;
+      }
+    }
+    for (int i = (n4 << 2) + threadIdx.x; i < G; i += 256) orow[i] = row[i] / m - 1.f;
+    return;
+  }
   float s = 0.f;
   const int n4 = vec ? (G >> 2) : 0;
   for (int i = threadIdx.x; i < n4; i += 256) {
@@ -332,8 +363,12 @@ extern "C" int vae_normalize_rows(const float* x, int64_t ldx, int64_t B, int64_
                                   int64_t ld_xn, void* stream) {
   VAE_REQUIRE(x && mean && xn && B > 0 && G > 0 && ldx >= G && ld_xn >= G, "vae_normalize_rows: bad arguments");
   const int vec = (ldx % 4 == 0) && (ld_xn % 4 == 0) && vae_aligned16(x) && vae_aligned16(xn);
-  hipLaunchKernelGGL(normalize_rows_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, x, ldx, (int)B, (int)G,
-                     vec, mean, xn, ld_xn);
+  if (vec && G <= 256 * 4 * 20)
+    hipLaunchKernelGGL(normalize_rows_kernel<true>, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, x, ldx, (int)B,
+                       (int)G, vec, mean, xn, ld_xn);
+  else
+    hipLaunchKernelGGL(normalize_rows_kernel<false>, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, x, ldx, (int)B,
+                       (int)G, vec, mean, xn, ld_xn);
   VAE_CHECK_LAUNCH("vae_normalize_rows");
   return VAE_OK;
 }

@@ -4,6 +4,7 @@
 // No allocation, no host synchronisation: safe to replay in a tight loop (or to capture).
 #include "../../include/vae_amd.h"
 #include "common.h"
+#include "middle.h"
 
 #include <string.h>
 
@@ -17,6 +18,7 @@ struct Layout {
   int64_t dec_pre[VAE_MAX_LAYERS], dec_h[VAE_MAX_LAYERS], ln_md[VAE_MAX_LAYERS], ln_rd[VAE_MAX_LAYERS];
   int64_t logits, table, ll, rowmax, rowsum, S, scalars;
   int64_t dz_extra, dlibrary, dheads_z, dheads_l, dpre_enc0, dh, dpx, dz;
+  int64_t dbet_d, dgam_d, dbet_e, dgam_e;  // per-cell LayerNorm-gradient rows of the fused middle
   int64_t scratch;        // split-K slabs / column-sum slabs (shared, used by one launch at a time)
   int64_t scratch_floats;
   int64_t total;
@@ -52,6 +54,8 @@ bool make_layout(const vae_step_config& c, Layout* lo) {
   lo->dz_extra = take(B * L); lo->dlibrary = take(B);
   lo->dheads_z = take(B * (L + 1)); lo->dheads_l = take(B * 2);
   lo->dpre_enc0 = take(B * (H + Hl)); lo->dh = take(B * H); lo->dpx = take(B * Hd); lo->dz = take(B * L);
+  lo->dbet_d = take(B * Hd); lo->dgam_d = take(B * Hd);
+  lo->dbet_e = take(B * (H + Hl)); lo->dgam_e = take(B * (H + Hl));
   // scratch: the largest split-K / column-slab need of any launch in the step
   int64_t s = 0;
   auto gw = [&](int64_t M, int64_t N, int64_t K) { s = maxi(s, vae_gemm_workspace_bytes(M, N, K)); };
@@ -62,6 +66,8 @@ bool make_layout(const vae_step_config& c, Layout* lo) {
   gw(B, Hd, L); gw(Hd, L, B); gw(B, L, Hd);                 // decoder first layer
   gw(B, Hd, Hd); gw(Hd, Hd, B);                             // deeper decoder layers
   gw(B, NH, Hd); gw(NH, Hd, B); gw(B, Hd, NH);              // decoder heads
+  s = maxi(s, vae_gemm_slabs_workspace_bytes(B, H + Hl, G));  // slabs consumed by the fused middle
+  s = maxi(s, vae_gemm_slabs_workspace_bytes(B, Hd, NH));
   s = maxi(s, vae_nbzinb_bwd_workspace_bytes(B, G));
   lo->scratch_floats = up4(s / 4 + 4);
   lo->scratch = take(lo->scratch_floats);
@@ -140,35 +146,48 @@ extern "C" int vae_elbo_step_forward(const vae_step_config* cfg, const vae_step_
 
   // encoders: x/mean-1 -> Linear(G, H+Hl) -> GELU -> LayerNorm (z and library halves)
   TRY(vae_normalize_rows(x, ldx, B, G, ws + lo.mean, ws + lo.xn, lo.ld_xn, stream));
-  TRY(k.gemm(VAE_NT, B, HE, G, ws + lo.xn, lo.ld_xn, p->enc_w0, G, ws + lo.pre_enc0, HE, p->enc_b0, nullptr, 0));
-  TRY(vae_gelu_ln_fwd(ws + lo.pre_enc0, HE, p->encz_ln_g[0], p->encz_ln_b[0], B, H, ws + lo.h_enc0, HE,
-                      ws + lo.ln_mz[0], ws + lo.ln_rz[0], stream));
-  TRY(vae_gelu_ln_fwd(ws + lo.pre_enc0 + H, HE, p->encl_ln_g, p->encl_ln_b, B, Hl, ws + lo.h_enc0 + H, HE,
-                      ws + lo.ln_ml, ws + lo.ln_rl, stream));
-  const float* hz = ws + lo.h_enc0;
-  int64_t ld_hz = HE;
-  for (int n = 1; n < c.n_layers; ++n) {
-    TRY(k.gemm(VAE_NT, B, H, H, hz, ld_hz, p->encz_w[n], H, ws + lo.encz_pre[n], H, p->encz_b[n], nullptr, 0));
-    TRY(vae_gelu_ln_fwd(ws + lo.encz_pre[n], H, p->encz_ln_g[n], p->encz_ln_b[n], B, H, ws + lo.encz_h[n], H,
-                        ws + lo.ln_mz[n], ws + lo.ln_rz[n], stream));
-    hz = ws + lo.encz_h[n];
-    ld_hz = H;
-  }
-  // latent heads + reparameterisation + KL
-  TRY(k.gemm(VAE_NT, B, L + 1, H, hz, ld_hz, p->hz_w, H, ws + lo.heads_z, L + 1, p->hz_b, nullptr, 0));
-  TRY(k.gemm(VAE_NT, B, 2, Hl, ws + lo.h_enc0 + H, HE, p->hl_w, Hl, ws + lo.heads_l, 2, p->hl_b, nullptr, 0));
-  TRY(vae_reparam_kl_fwd(ws + lo.heads_z, L + 1, eps_z, L, B, L, 0.f, 1.f, ws + lo.qz_v, ws + lo.z, L, ws + lo.kl_z, stream));
-  TRY(vae_reparam_kl_fwd(ws + lo.heads_l, 2, eps_l, 1, B, 1, c.l_mean, c.l_var, ws + lo.ql_v, ws + lo.library, 1,
-                         ws + lo.kl_l, stream));
-  // decoder hidden layers
-  const float* px = ws + lo.z;
-  int64_t kin = L;
-  for (int n = 0; n < c.n_layers; ++n) {
-    TRY(k.gemm(VAE_NT, B, Hd, kin, px, kin, p->dec_w[n], kin, ws + lo.dec_pre[n], Hd, p->dec_b[n], nullptr, 0));
-    TRY(vae_gelu_ln_fwd(ws + lo.dec_pre[n], Hd, p->dec_ln_g[n], p->dec_ln_b[n], B, Hd, ws + lo.dec_h[n], Hd,
-                        ws + lo.ln_md[n], ws + lo.ln_rd[n], stream));
-    px = ws + lo.dec_h[n];
-    kin = Hd;
+  const float* px;
+  if (vae_mid_supported(c)) {
+    // one launch from the encoder slabs to the decoder hidden layer
+    int nslab = 0;
+    TRY(vae_gemm_slabs(VAE_NT, c.precision, B, HE, G, ws + lo.xn, lo.ld_xn, p->enc_w0, G, ws + lo.scratch,
+                       lo.scratch_floats * 4, &nslab, stream));
+    TRY(vae_mid_forward(c, p, ws + lo.scratch, nslab, eps_z, eps_l, ws + lo.pre_enc0, ws + lo.h_enc0, ws + lo.ln_mz[0],
+                        ws + lo.ln_rz[0], ws + lo.ln_ml, ws + lo.ln_rl, ws + lo.heads_z, ws + lo.heads_l, ws + lo.qz_v,
+                        ws + lo.z, ws + lo.kl_z, ws + lo.ql_v, ws + lo.library, ws + lo.kl_l, ws + lo.dec_pre[0],
+                        ws + lo.dec_h[0], ws + lo.ln_md[0], ws + lo.ln_rd[0], stream));
+    px = ws + lo.dec_h[0];
+  } else {
+    TRY(k.gemm(VAE_NT, B, HE, G, ws + lo.xn, lo.ld_xn, p->enc_w0, G, ws + lo.pre_enc0, HE, p->enc_b0, nullptr, 0));
+    TRY(vae_gelu_ln_fwd(ws + lo.pre_enc0, HE, p->encz_ln_g[0], p->encz_ln_b[0], B, H, ws + lo.h_enc0, HE,
+                        ws + lo.ln_mz[0], ws + lo.ln_rz[0], stream));
+    TRY(vae_gelu_ln_fwd(ws + lo.pre_enc0 + H, HE, p->encl_ln_g, p->encl_ln_b, B, Hl, ws + lo.h_enc0 + H, HE,
+                        ws + lo.ln_ml, ws + lo.ln_rl, stream));
+    const float* hz = ws + lo.h_enc0;
+    int64_t ld_hz = HE;
+    for (int n = 1; n < c.n_layers; ++n) {
+      TRY(k.gemm(VAE_NT, B, H, H, hz, ld_hz, p->encz_w[n], H, ws + lo.encz_pre[n], H, p->encz_b[n], nullptr, 0));
+      TRY(vae_gelu_ln_fwd(ws + lo.encz_pre[n], H, p->encz_ln_g[n], p->encz_ln_b[n], B, H, ws + lo.encz_h[n], H,
+                          ws + lo.ln_mz[n], ws + lo.ln_rz[n], stream));
+      hz = ws + lo.encz_h[n];
+      ld_hz = H;
+    }
+    // latent heads + reparameterisation + KL
+    TRY(k.gemm(VAE_NT, B, L + 1, H, hz, ld_hz, p->hz_w, H, ws + lo.heads_z, L + 1, p->hz_b, nullptr, 0));
+    TRY(k.gemm(VAE_NT, B, 2, Hl, ws + lo.h_enc0 + H, HE, p->hl_w, Hl, ws + lo.heads_l, 2, p->hl_b, nullptr, 0));
+    TRY(vae_reparam_kl_fwd(ws + lo.heads_z, L + 1, eps_z, L, B, L, 0.f, 1.f, ws + lo.qz_v, ws + lo.z, L, ws + lo.kl_z, stream));
+    TRY(vae_reparam_kl_fwd(ws + lo.heads_l, 2, eps_l, 1, B, 1, c.l_mean, c.l_var, ws + lo.ql_v, ws + lo.library, 1,
+                           ws + lo.kl_l, stream));
+    // decoder hidden layers
+    px = ws + lo.z;
+    int64_t kin = L;
+    for (int n = 0; n < c.n_layers; ++n) {
+      TRY(k.gemm(VAE_NT, B, Hd, kin, px, kin, p->dec_w[n], kin, ws + lo.dec_pre[n], Hd, p->dec_b[n], nullptr, 0));
+      TRY(vae_gelu_ln_fwd(ws + lo.dec_pre[n], Hd, p->dec_ln_g[n], p->dec_ln_b[n], B, Hd, ws + lo.dec_h[n], Hd,
+                          ws + lo.ln_md[n], ws + lo.ln_rd[n], stream));
+      px = ws + lo.dec_h[n];
+      kin = Hd;
+    }
   }
   // decoder heads -> fused softmax / library scale / NB-ZINB / row sum -> ELBO scalars
   TRY(k.gemm(VAE_NT, B, NH, Hd, px, Hd, p->heads_w, Hd, ws + lo.logits, NH, p->heads_b, nullptr, 0));
@@ -205,56 +224,68 @@ extern "C" int vae_elbo_step_backward(const vae_step_config* cfg, const vae_step
     if (hipEventRecord((hipEvent_t)event_heads_ready, (hipStream_t)stream) != hipSuccess)
       return vae_set_error(VAE_ERR_LAUNCH, "vae_elbo_step_backward: hipEventRecord failed");
   }
-  TRY(k.gemm(VAE_NN, B, Hd, NH, logits, NH, p->heads_w, Hd, ws + lo.dpx, Hd, nullptr, nullptr, 0));
+  if (vae_mid_supported(c)) {
+    int nslab = 0;
+    TRY(vae_gemm_slabs(VAE_NN, c.precision, B, Hd, NH, logits, NH, p->heads_w, Hd, ws + lo.scratch, lo.scratch_floats * 4,
+                       &nslab, stream));
+    TRY(vae_mid_backward(c, p, g, ws + lo.scratch, nslab, eps_z, eps_l, use_dz_extra ? ws + lo.dz_extra : nullptr, g_kl,
+                         ws + lo.dec_pre[0], ws + lo.ln_md[0], ws + lo.ln_rd[0], ws + lo.heads_z, ws + lo.heads_l,
+                         ws + lo.qz_v, ws + lo.ql_v, ws + lo.dlibrary, ws + lo.pre_enc0, ws + lo.ln_mz[0], ws + lo.ln_rz[0],
+                         ws + lo.ln_ml, ws + lo.ln_rl, ws + lo.z, ws + lo.h_enc0, ws + lo.dbet_d, ws + lo.dgam_d,
+                         ws + lo.dpx, ws + lo.dheads_z, ws + lo.dheads_l, ws + lo.dbet_e, ws + lo.dgam_e,
+                         ws + lo.dpre_enc0, stream));
+  } else {
+    TRY(k.gemm(VAE_NN, B, Hd, NH, logits, NH, p->heads_w, Hd, ws + lo.dpx, Hd, nullptr, nullptr, 0));
 
-  // decoder hidden layers
-  float* dcur = ws + lo.dpx;
-  for (int n = c.n_layers - 1; n >= 0; --n) {
-    const float* inp = n == 0 ? ws + lo.z : ws + lo.dec_h[n - 1];
-    const int64_t kin = n == 0 ? L : Hd;
-    TRY(vae_gelu_ln_bwd(dcur, Hd, ws + lo.dec_pre[n], Hd, ws + lo.ln_md[n], ws + lo.ln_rd[n], p->dec_ln_g[n], B, Hd, dcur,
-                        Hd, g->dec_ln_g[n], g->dec_ln_b[n], g->dec_b[n], stream));
-    TRY(k.gemm(VAE_TN, Hd, kin, B, dcur, Hd, inp, kin, g->dec_w[n], kin, nullptr, nullptr, 0));
-    if (n > 0) {
-      // dgrad into the scratch-free buffer of the layer below: reuse dec_pre[n] (no longer needed)
-      float* nxt = ws + lo.dec_pre[n];
-      TRY(k.gemm(VAE_NN, B, Hd, Hd, dcur, Hd, p->dec_w[n], Hd, nxt, Hd, nullptr, nullptr, 0));
-      dcur = nxt;
-    } else {
-      TRY(k.gemm(VAE_NN, B, L, Hd, dcur, Hd, p->dec_w[0], L, ws + lo.dz, L, nullptr, nullptr, 0));
+    // decoder hidden layers
+    float* dcur = ws + lo.dpx;
+    for (int n = c.n_layers - 1; n >= 0; --n) {
+      const float* inp = n == 0 ? ws + lo.z : ws + lo.dec_h[n - 1];
+      const int64_t kin = n == 0 ? L : Hd;
+      TRY(vae_gelu_ln_bwd(dcur, Hd, ws + lo.dec_pre[n], Hd, ws + lo.ln_md[n], ws + lo.ln_rd[n], p->dec_ln_g[n], B, Hd, dcur,
+                          Hd, g->dec_ln_g[n], g->dec_ln_b[n], g->dec_b[n], stream));
+      TRY(k.gemm(VAE_TN, Hd, kin, B, dcur, Hd, inp, kin, g->dec_w[n], kin, nullptr, nullptr, 0));
+      if (n > 0) {
+        // dgrad into the scratch-free buffer of the layer below: reuse dec_pre[n] (no longer needed)
+        float* nxt = ws + lo.dec_pre[n];
+        TRY(k.gemm(VAE_NN, B, Hd, Hd, dcur, Hd, p->dec_w[n], Hd, nxt, Hd, nullptr, nullptr, 0));
+        dcur = nxt;
+      } else {
+        TRY(k.gemm(VAE_NN, B, L, Hd, dcur, Hd, p->dec_w[0], L, ws + lo.dz, L, nullptr, nullptr, 0));
+      }
     }
-  }
-  // reparameterisation / KL backward (cell-head gradient enters through dz_extra)
-  const float* dz = ws + lo.dz;
-  if (use_dz_extra) TRY(vae_add_inplace(ws + lo.dz_extra, ws + lo.dz, B * L, stream));
-  TRY(vae_reparam_kl_bwd(dz, L, nullptr, g_kl, ws + lo.heads_z, L + 1, eps_z, L, ws + lo.qz_v, B, L, 0.f, 1.f,
-                         ws + lo.dheads_z, L + 1, g->hz_b, stream));
-  TRY(vae_reparam_kl_bwd(ws + lo.dlibrary, 1, nullptr, g_kl, ws + lo.heads_l, 2, eps_l, 1, ws + lo.ql_v, B, 1, c.l_mean,
-                         c.l_var, ws + lo.dheads_l, 2, g->hl_b, stream));
-  const float* hz = c.n_layers > 1 ? ws + lo.encz_h[c.n_layers - 1] : ws + lo.h_enc0;
-  const int64_t ld_hz = c.n_layers > 1 ? H : HE;
-  TRY(k.gemm(VAE_TN, L + 1, H, B, ws + lo.dheads_z, L + 1, hz, ld_hz, g->hz_w, H, nullptr, nullptr, 0));
-  TRY(k.gemm(VAE_TN, 2, Hl, B, ws + lo.dheads_l, 2, ws + lo.h_enc0 + H, HE, g->hl_w, Hl, nullptr, nullptr, 0));
-  TRY(k.gemm(VAE_NN, B, H, L + 1, ws + lo.dheads_z, L + 1, p->hz_w, H, ws + lo.dh, H, nullptr, nullptr, 0));
-  TRY(k.gemm(VAE_NN, B, Hl, 2, ws + lo.dheads_l, 2, p->hl_w, Hl, ws + lo.dpre_enc0 + H, HE, nullptr, nullptr, 0));
+    // reparameterisation / KL backward (cell-head gradient enters through dz_extra)
+    const float* dz = ws + lo.dz;
+    if (use_dz_extra) TRY(vae_add_inplace(ws + lo.dz_extra, ws + lo.dz, B * L, stream));
+    TRY(vae_reparam_kl_bwd(dz, L, nullptr, g_kl, ws + lo.heads_z, L + 1, eps_z, L, ws + lo.qz_v, B, L, 0.f, 1.f,
+                           ws + lo.dheads_z, L + 1, g->hz_b, stream));
+    TRY(vae_reparam_kl_bwd(ws + lo.dlibrary, 1, nullptr, g_kl, ws + lo.heads_l, 2, eps_l, 1, ws + lo.ql_v, B, 1, c.l_mean,
+                           c.l_var, ws + lo.dheads_l, 2, g->hl_b, stream));
+    const float* hz = c.n_layers > 1 ? ws + lo.encz_h[c.n_layers - 1] : ws + lo.h_enc0;
+    const int64_t ld_hz = c.n_layers > 1 ? H : HE;
+    TRY(k.gemm(VAE_TN, L + 1, H, B, ws + lo.dheads_z, L + 1, hz, ld_hz, g->hz_w, H, nullptr, nullptr, 0));
+    TRY(k.gemm(VAE_TN, 2, Hl, B, ws + lo.dheads_l, 2, ws + lo.h_enc0 + H, HE, g->hl_w, Hl, nullptr, nullptr, 0));
+    TRY(k.gemm(VAE_NN, B, H, L + 1, ws + lo.dheads_z, L + 1, p->hz_w, H, ws + lo.dh, H, nullptr, nullptr, 0));
+    TRY(k.gemm(VAE_NN, B, Hl, 2, ws + lo.dheads_l, 2, p->hl_w, Hl, ws + lo.dpre_enc0 + H, HE, nullptr, nullptr, 0));
 
-  // deeper z-encoder layers
-  float* dh = ws + lo.dh;
-  for (int n = c.n_layers - 1; n >= 1; --n) {
-    const float* inp = n == 1 ? ws + lo.h_enc0 : ws + lo.encz_h[n - 1];
-    const int64_t ld_in = n == 1 ? HE : H;
-    TRY(vae_gelu_ln_bwd(dh, H, ws + lo.encz_pre[n], H, ws + lo.ln_mz[n], ws + lo.ln_rz[n], p->encz_ln_g[n], B, H, dh, H,
-                        g->encz_ln_g[n], g->encz_ln_b[n], g->encz_b[n], stream));
-    TRY(k.gemm(VAE_TN, H, H, B, dh, H, inp, ld_in, g->encz_w[n], H, nullptr, nullptr, 0));
-    float* nxt = ws + lo.encz_pre[n];  // free from here on
-    TRY(k.gemm(VAE_NN, B, H, H, dh, H, p->encz_w[n], H, nxt, H, nullptr, nullptr, 0));
-    dh = nxt;
+    // deeper z-encoder layers
+    float* dh = ws + lo.dh;
+    for (int n = c.n_layers - 1; n >= 1; --n) {
+      const float* inp = n == 1 ? ws + lo.h_enc0 : ws + lo.encz_h[n - 1];
+      const int64_t ld_in = n == 1 ? HE : H;
+      TRY(vae_gelu_ln_bwd(dh, H, ws + lo.encz_pre[n], H, ws + lo.ln_mz[n], ws + lo.ln_rz[n], p->encz_ln_g[n], B, H, dh, H,
+                          g->encz_ln_g[n], g->encz_ln_b[n], g->encz_b[n], stream));
+      TRY(k.gemm(VAE_TN, H, H, B, dh, H, inp, ld_in, g->encz_w[n], H, nullptr, nullptr, 0));
+      float* nxt = ws + lo.encz_pre[n];  // free from here on
+      TRY(k.gemm(VAE_NN, B, H, H, dh, H, p->encz_w[n], H, nxt, H, nullptr, nullptr, 0));
+      dh = nxt;
+    }
+    // first encoder layer: GELU/LayerNorm backward of both halves, then ONE wgrad over the counts
+    TRY(vae_gelu_ln_bwd(dh, H, ws + lo.pre_enc0, HE, ws + lo.ln_mz[0], ws + lo.ln_rz[0], p->encz_ln_g[0], B, H,
+                        ws + lo.dpre_enc0, HE, g->encz_ln_g[0], g->encz_ln_b[0], g->enc_b0, stream));
+    TRY(vae_gelu_ln_bwd(ws + lo.dpre_enc0 + H, HE, ws + lo.pre_enc0 + H, HE, ws + lo.ln_ml, ws + lo.ln_rl, p->encl_ln_g, B,
+                        Hl, ws + lo.dpre_enc0 + H, HE, g->encl_ln_g, g->encl_ln_b, g->enc_b0 + H, stream));
   }
-  // first encoder layer: GELU/LayerNorm backward of both halves, then ONE wgrad over the counts
-  TRY(vae_gelu_ln_bwd(dh, H, ws + lo.pre_enc0, HE, ws + lo.ln_mz[0], ws + lo.ln_rz[0], p->encz_ln_g[0], B, H,
-                      ws + lo.dpre_enc0, HE, g->encz_ln_g[0], g->encz_ln_b[0], g->enc_b0, stream));
-  TRY(vae_gelu_ln_bwd(ws + lo.dpre_enc0 + H, HE, ws + lo.pre_enc0 + H, HE, ws + lo.ln_ml, ws + lo.ln_rl, p->encl_ln_g, B,
-                      Hl, ws + lo.dpre_enc0 + H, HE, g->encl_ln_g, g->encl_ln_b, g->enc_b0 + H, stream));
   TRY(k.gemm(VAE_TN, HE, G, B, ws + lo.dpre_enc0, HE, ws + lo.xn, lo.ld_xn, g->enc_w0, G, nullptr, nullptr, 0));
   return VAE_OK;
 }
