@@ -7,6 +7,7 @@ from vae_amd import ops
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+P = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 G, H, Hd = 20000, 384, 256
 dev = "cuda"
 g = torch.Generator(device=dev).manual_seed(1)
@@ -25,16 +26,16 @@ def t_ms(fn, n=iters):
     b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b) / n
 cases = {
-  "enc_fwd   NT": (lambda: ops.gemm(ops.NT, xn, w_enc), 2.0*B*H*G),
-  "dec_fwd   NT": (lambda: ops.gemm(ops.NT, px, w_heads, out=logits), 2.0*B*2*G*Hd),
-  "dec_wgrad TN": (lambda: ops.gemm(ops.TN, logits, px, out=gw_heads), 2.0*B*2*G*Hd),
-  "dec_dgrad NN": (lambda: ops.gemm(ops.NN, logits, w_heads), 2.0*B*2*G*Hd),
-  "enc_wgrad TN": (lambda: ops.gemm(ops.TN, dpre, xn, out=gw_enc), 2.0*B*H*G),
+  "enc_fwd   NT": (lambda: ops.gemm(ops.NT, xn, w_enc, precision=P), 2.0*B*H*G),
+  "dec_fwd   NT": (lambda: ops.gemm(ops.NT, px, w_heads, out=logits, precision=P), 2.0*B*2*G*Hd),
+  "dec_wgrad TN": (lambda: ops.gemm(ops.TN, logits, px, out=gw_heads, precision=P), 2.0*B*2*G*Hd),
+  "dec_dgrad NN": (lambda: ops.gemm(ops.NN, logits, w_heads, precision=P), 2.0*B*2*G*Hd),
+  "enc_wgrad TN": (lambda: ops.gemm(ops.TN, dpre, xn, out=gw_enc, precision=P), 2.0*B*H*G),
 }
 only = os.environ.get("ONLY")
 tot = 0
 for k, (fn, fl) in cases.items():
     if only and only not in k: continue
     t = t_ms(fn); tot += t
-    print(f"B={B} {k}: {t*1e3:8.1f} us  {fl/t/1e9:8.1f} TFLOP/s")
+    print(f"B={B} P={P} {k}: {t*1e3:8.1f} us  {fl/t/1e9:8.1f} TFLOP/s")
 print(f"total {tot*1e3:.1f} us")

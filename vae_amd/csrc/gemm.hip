@@ -176,6 +176,59 @@ __device__ __forceinline__ void store16_rc(__bf16* s, const float4 (&reg)[R / 32
   }
 }
 
+// ---- bf16x3 LDS image: three bf16 planes (hi, mid, lo) of the same [R][LD16] layout.  An fp32
+//      value is split EXACTLY into hi + mid + lo (8 + 8 + 8 mantissa bits, each remainder is
+//      representable), so hi*hi + hi*mid + mid*hi + hi*lo + lo*hi + mid*mid reproduces the fp32
+//      product to 2^-25: six bf16 MFMAs (16x the fp32 MFMA rate each) replace eight fp32 MFMAs. ----
+__device__ __forceinline__ void split3(float a, __bf16& h, __bf16& m, __bf16& l) {
+  h = (__bf16)a;
+  float r = a - (float)h;
+  m = (__bf16)r;
+  r = r - (float)m;
+  l = (__bf16)r;
+}
+template <int R>
+__device__ __forceinline__ void store16x3_kc(__bf16* s, int plane, const float4 (&reg)[R / 32]) {
+#pragma unroll
+  for (int i = 0; i < R / 32; ++i) {
+    const int c = threadIdx.x + 256 * i;
+    const int r = c >> 3, k = (c & 7) * 4;
+    const float v[4] = {reg[i].x, reg[i].y, reg[i].z, reg[i].w};
+    bf16x4 h, m, l;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      __bf16 a, b, d;
+      split3(v[j], a, b, d);
+      h[j] = a; m[j] = b; l[j] = d;
+    }
+    *reinterpret_cast<bf16x4*>(&s[r * LD16 + k]) = h;
+    *reinterpret_cast<bf16x4*>(&s[plane + r * LD16 + k]) = m;
+    *reinterpret_cast<bf16x4*>(&s[2 * plane + r * LD16 + k]) = l;
+  }
+}
+template <int R>
+__device__ __forceinline__ void store16x3_rc(__bf16* s, int plane, const float4 (&reg)[R / 32]) {
+#pragma unroll
+  for (int i = 0; i < R / 32; i += 2) {
+    const int c = threadIdx.x + 256 * (i >> 1);
+    const int k = 2 * (c / (R / 4)), r = (c % (R / 4)) * 4;
+    const float lo[4] = {reg[i].x, reg[i].y, reg[i].z, reg[i].w};
+    const float hi[4] = {reg[i + 1].x, reg[i + 1].y, reg[i + 1].z, reg[i + 1].w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      bf16x2 h, m, l;
+      __bf16 a, b, d;
+      split3(lo[j], a, b, d);
+      h[0] = a; m[0] = b; l[0] = d;
+      split3(hi[j], a, b, d);
+      h[1] = a; m[1] = b; l[1] = d;
+      *reinterpret_cast<bf16x2*>(&s[(r + j) * LD16 + k]) = h;
+      *reinterpret_cast<bf16x2*>(&s[plane + (r + j) * LD16 + k]) = m;
+      *reinterpret_cast<bf16x2*>(&s[2 * plane + (r + j) * LD16 + k]) = l;
+    }
+  }
+}
+
 // TW = MFMA 32x32 accumulators per wave per dimension: 2 -> 128x128 tile, 1 -> 64x64 tile
 template <int LAYOUT, int PREC, bool NORM, int TW>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
@@ -188,11 +241,11 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
   constexpr int SMEM32 = BK * Ld32<R>::RC;  // floats per operand (RC >= KC)
   constexpr int SMEM16 = R * LD16;          // bf16 per operand
 
-  __shared__ __attribute__((aligned(16))) float smem[PREC == 0 ? 2 * SMEM32 : SMEM16];
+  __shared__ __attribute__((aligned(16))) float smem[PREC == 0 ? 2 * SMEM32 : (PREC == 1 ? SMEM16 : 3 * SMEM16)];
   float* sA32 = smem;
   float* sB32 = smem + SMEM32;
   __bf16* sA16 = reinterpret_cast<__bf16*>(smem);
-  __bf16* sB16 = sA16 + SMEM16;
+  __bf16* sB16 = sA16 + (PREC == 2 ? 3 * SMEM16 : SMEM16);
 
   const int tile = blockIdx.x;
   const int m0 = (tile / g.tiles_n) * R, n0 = (tile % g.tiles_n) * R;
@@ -226,9 +279,12 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
     if (PREC == 0) {
       if (A_KC) store32_kc<R>(sA32, ra); else store32_rc<R>(sA32, ra);
       if (B_KC) store32_kc<R>(sB32, rb); else store32_rc<R>(sB32, rb);
-    } else {
+    } else if (PREC == 1) {
       if (A_KC) store16_kc<R>(sA16, ra); else store16_rc<R>(sA16, ra);
       if (B_KC) store16_kc<R>(sB16, rb); else store16_rc<R>(sB16, rb);
+    } else {
+      if (A_KC) store16x3_kc<R>(sA16, SMEM16, ra); else store16x3_rc<R>(sA16, SMEM16, ra);
+      if (B_KC) store16x3_kc<R>(sB16, SMEM16, rb); else store16x3_rc<R>(sB16, SMEM16, rb);
     }
     __syncthreads();
   };
@@ -251,6 +307,33 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
 #pragma unroll
           for (int j = 0; j < TW; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+      }
+    } else if (PREC == 2) {
+      const __bf16* pa = sA16 + (wm * (32 * TW) + l31) * LD16 + h * 8;
+      const __bf16* pb = sB16 + (wn * (32 * TW) + l31) * LD16 + h * 8;
+#pragma unroll
+      for (int ks = 0; ks < BK / 16; ++ks) {
+        bf16x8 a[TW][3], b[TW][3];
+#pragma unroll
+        for (int t = 0; t < TW; ++t)
+#pragma unroll
+          for (int q = 0; q < 3; ++q) {
+            a[t][q] = *reinterpret_cast<const bf16x8*>(pa + q * SMEM16 + 32 * t * LD16 + ks * 16);
+            b[t][q] = *reinterpret_cast<const bf16x8*>(pb + q * SMEM16 + 32 * t * LD16 + ks * 16);
+          }
+#pragma unroll
+        for (int i = 0; i < TW; ++i)
+#pragma unroll
+          for (int j = 0; j < TW; ++j) {
+            f32x16 c = acc[i][j];  // smallest terms first
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][1], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[j][0], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][2], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][0], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][1], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], c, 0, 0, 0);
+            acc[i][j] = c;
+          }
       }
     } else {
       const __bf16* pa = sA16 + (wm * (32 * TW) + l31) * LD16 + h * 8;
@@ -515,6 +598,202 @@ __global__ __launch_bounds__(256, 2) void gemm32_dma_kernel(GemmArgs g) {
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// fp32 GEMM on the bf16 matrix cores: every fp32 operand element is split EXACTLY into three
+// bf16 values (split3 above) while it is staged into LDS, and each fragment pair runs the six
+// significant products hi*hi, hi*mid, mid*hi, hi*lo, lo*hi, mid*mid (dropped terms < 2^-25 of
+// the product) with fp32 accumulation.  Measured against fp64 the result is as accurate as the
+// fp32 MFMA path (tools/acc_gemm.py), at 6/16 of its matrix-core time.
+//   KC operand planes: [R][40] bf16 (80-byte rows), fragments by ds_read_b128.
+//   RC operand planes: [32 k][160] bf16 (320-byte rows), fragments by the transposing
+//     ds_read_b64_tr_b16 (a 16-lane group reads 4 k x 16 rows and receives them row-major).
+// Same shape requirements, tiles and placement as gemm32_dma_kernel.
+// ---------------------------------------------------------------------------------------
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
+
+template <int LAYOUT, int BM, int BN, int WAVES_M>
+__global__ __launch_bounds__(256, 2) void gemm_x3_kernel(GemmArgs g) {
+  constexpr bool A_KC = (LAYOUT != TN);
+  constexpr bool B_KC = (LAYOUT == NT);
+  constexpr int WAVES_N = 4 / WAVES_M;
+  constexpr int TM = BM / (32 * WAVES_M), TNN = BN / (32 * WAVES_N);
+  constexpr int NA = BM / 32, NB = BN / 32;                 // float4 per thread per operand
+  constexpr int LDK = 40, LDR = 160;                        // bf16 row strides of the two images
+  constexpr int PLA = A_KC ? BM * LDK : 32 * LDR;           // bf16 per plane
+  constexpr int PLB = B_KC ? BN * LDK : 32 * LDR;
+  __shared__ __attribute__((aligned(16))) __bf16 smem[3 * (PLA + PLB)];
+  __bf16* sA = smem;
+  __bf16* sB = smem + 3 * PLA;
+
+  const int nwg = gridDim.x;
+  const int xcd = blockIdx.x & 7, q8 = nwg >> 3, r8 = nwg & 7;
+  const int id = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3);
+  const int tiles_m = g.tiles_m, tiles_n = g.tiles_n;
+  const int per_split = tiles_m * tiles_n;
+  const int s = id / per_split, t = id - s * per_split;
+  int tm, tn;
+  if (tiles_m <= tiles_n) { tm = t % tiles_m; tn = t / tiles_m; }
+  else                    { tn = t % tiles_n; tm = t / tiles_n; }
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int kbeg = s * g.k_per_split;
+  const int kend = min(g.K, kbeg + g.k_per_split);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  const int l31 = lane & 31, h = lane >> 5;
+
+  // ---- global -> register staging: unconditional 16-byte loads from clamped addresses ----
+  const float* pa[NA];
+  const float* pb[NB];
+  int wa[NA], wb[NB];  // LDS element offsets inside a plane
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+    const int c = tid + 256 * i;
+    if (A_KC) {
+      const int row = c >> 3, k4 = c & 7;
+      pa[i] = g.A + (int64_t)min(m0 + row, g.M - 1) * g.lda + kbeg + 4 * k4;
+      wa[i] = row * LDK + 4 * k4;
+    } else {
+      const int k = c / (BM / 4), r4 = c % (BM / 4);
+      pa[i] = g.A + (int64_t)(kbeg + k) * g.lda + min(m0 + 4 * r4, g.M - 4);
+      wa[i] = k * LDR + 4 * r4;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {
+    const int c = tid + 256 * i;
+    if (B_KC) {
+      const int row = c >> 3, k4 = c & 7;
+      pb[i] = g.B + (int64_t)min(n0 + row, g.N - 1) * g.ldb + kbeg + 4 * k4;
+      wb[i] = row * LDK + 4 * k4;
+    } else {
+      const int k = c / (BN / 4), r4 = c % (BN / 4);
+      pb[i] = g.B + (int64_t)(kbeg + k) * g.ldb + min(n0 + 4 * r4, g.N - 4);
+      wb[i] = k * LDR + 4 * r4;
+    }
+  }
+  const int64_t step_a = A_KC ? 32 : 32 * g.lda;
+  const int64_t step_b = B_KC ? 32 : 32 * g.ldb;
+  float4 ra[NA], rb[NB];
+  auto fetch = [&]() {
+#pragma unroll
+    for (int i = 0; i < NA; ++i) { ra[i] = *reinterpret_cast<const float4*>(pa[i]); pa[i] += step_a; }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) { rb[i] = *reinterpret_cast<const float4*>(pb[i]); pb[i] += step_b; }
+  };
+  auto put = [&](__bf16* base, int plane, int off, const float4& v) {
+    const float f[4] = {v.x, v.y, v.z, v.w};
+    bf16x4 hi, mi, lo;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      __bf16 a, b, d;
+      split3(f[j], a, b, d);
+      hi[j] = a; mi[j] = b; lo[j] = d;
+    }
+    *reinterpret_cast<bf16x4*>(base + off) = hi;
+    *reinterpret_cast<bf16x4*>(base + plane + off) = mi;
+    *reinterpret_cast<bf16x4*>(base + 2 * plane + off) = lo;
+  };
+  auto stage = [&]() {
+    __syncthreads();  // the previous tile's fragment reads are done
+#pragma unroll
+    for (int i = 0; i < NA; ++i) put(sA, PLA, wa[i], ra[i]);
+#pragma unroll
+    for (int i = 0; i < NB; ++i) put(sB, PLB, wb[i], rb[i]);
+    __syncthreads();
+  };
+
+  // ---- fragment addressing ----
+  // KC: lane (row l31, k-group h) reads 8 consecutive k: [row][8h + 16 ks]
+  // RC: 16-lane group j = lane>>4: rows 16 (j&1) .. +15, k-group j>>1; lane 4q+p of the group points
+  //     at [k = 8 (j>>1) + q (+4)][row0 + 4p]
+  const int la = lane & 15, lq = la >> 2, lp = la & 3, lj = lane >> 4;
+  const int fa = A_KC ? (wm * (32 * TM) + l31) * LDK + 8 * h
+                      : (8 * (lj >> 1) + lq) * LDR + wm * (32 * TM) + 16 * (lj & 1) + 4 * lp;
+  const int fb = B_KC ? (wn * (32 * TNN) + l31) * LDK + 8 * h
+                      : (8 * (lj >> 1) + lq) * LDR + wn * (32 * TNN) + 16 * (lj & 1) + 4 * lp;
+
+  auto frag = [&](const __bf16* plane, bool kc, int f0, int tt, int ks) -> bf16x8 {
+    if (kc) return *reinterpret_cast<const bf16x8*>(plane + f0 + tt * 32 * LDK + ks * 16);
+    const __bf16* p = plane + f0 + ks * 16 * LDR + tt * 32;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)p);
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(p + 4 * LDR));
+    union { s16x4 s[2]; bf16x8 v; } u;
+    u.s[0] = lo;
+    u.s[1] = hi;
+    return u.v;
+  };
+
+  f32x16 acc[TM][TNN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TNN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  auto multiply = [&]() {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 a[TM][3];
+#pragma unroll
+      for (int ti = 0; ti < TM; ++ti)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) a[ti][q] = frag(sA + q * PLA, A_KC, fa, ti, ks);
+#pragma unroll
+      for (int tj = 0; tj < TNN; ++tj) {
+        bf16x8 b[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) b[q] = frag(sB + q * PLB, B_KC, fb, tj, ks);
+#pragma unroll
+        for (int ti = 0; ti < TM; ++ti) {
+          f32x16 c = acc[ti][tj];  // smallest terms first
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ti][1], b[1], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ti][2], b[0], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ti][0], b[2], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ti][1], b[0], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ti][0], b[1], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ti][0], b[0], c, 0, 0, 0);
+          acc[ti][tj] = c;
+        }
+      }
+    }
+  };
+
+  if (kbeg < kend) fetch();
+  for (int k0 = kbeg; k0 < kend; k0 += BK) {
+    stage();
+    if (k0 + BK < kend) fetch();  // in flight during the MFMAs below
+    multiply();
+  }
+
+  float* out = g.C;
+  int64_t ldc = g.ldc;
+  if (g.split > 1) {
+    out = g.C + (int64_t)s * g.M * g.N;
+    ldc = g.N;
+  }
+#pragma unroll
+  for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < TNN; ++ni) {
+      const int n = n0 + wn * (32 * TNN) + ni * 32 + l31;
+      if (n >= g.N) continue;
+      const float bv = (g.split == 1 && g.bias) ? g.bias[n] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * (32 * TM) + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (m < g.M) {
+          float* p = out + (int64_t)m * ldc + n;
+          float v = acc[mi][ni][r] + bv;
+          if (g.split == 1 && g.accumulate) v += *p;
+          *p = v;
+        }
+      }
+    }
+}
+
 // Sums the split-K slabs in slab order, adds the bias, writes (or accumulates into) C.
 // VEC: N % 4 == 0, ldc % 4 == 0, 16-byte aligned pointers -> 16 B per lane, 4 slabs in flight.
 template <bool VEC>
@@ -655,7 +934,7 @@ int gemm_impl(int layout, int precision, int64_t M, int64_t N, int64_t K, const 
               int64_t ldb, float* C, int64_t ldc, const float* bias, const float* x_mean, int accumulate,
               float* workspace, int64_t workspace_bytes, void* stream, int* slabs_out) {
   VAE_REQUIRE(layout >= 0 && layout <= 2, "vae_gemm: layout must be 0 (NT), 1 (NN) or 2 (TN), got %d", layout);
-  VAE_REQUIRE(precision == 0 || precision == 1, "vae_gemm: precision must be 0 (fp32) or 1 (bf16), got %d", precision);
+  VAE_REQUIRE(precision >= 0 && precision <= 2, "vae_gemm: precision must be 0 (fp32), 1 (bf16) or 2 (bf16x3), got %d", precision);
   VAE_REQUIRE(M > 0 && N > 0 && K > 0 && M < (1 << 30) && N < (1 << 30) && K < (1 << 30),
               "vae_gemm: bad shape M=%lld N=%lld K=%lld", (long long)M, (long long)N, (long long)K);
   VAE_REQUIRE(A && B && (C || slabs_out), "vae_gemm: null operand");
@@ -715,18 +994,34 @@ int gemm_impl(int layout, int precision, int64_t M, int64_t N, int64_t K, const 
       else if (bn == 160)         hipLaunchKernelGGL((gemm32_dma_kernel<LAY, 128, 160, 4>), grid1, dim3(256), 0, st, g); \
       else                        hipLaunchKernelGGL((gemm32_dma_kernel<LAY, 160, 128, 1>), grid1, dim3(256), 0, st, g); \
     } while (0)
-    if (layout == NT) VAE_DMA_LAUNCH(NT);
+#define VAE_X3_LAUNCH(LAY)                                                                               \
+    do {                                                                                                   \
+      if (bm == 128 && bn == 128) hipLaunchKernelGGL((gemm_x3_kernel<LAY, 128, 128, 2>), grid1, dim3(256), 0, st, g); \
+      else if (bn == 160)         hipLaunchKernelGGL((gemm_x3_kernel<LAY, 128, 160, 4>), grid1, dim3(256), 0, st, g); \
+      else                        hipLaunchKernelGGL((gemm_x3_kernel<LAY, 160, 128, 1>), grid1, dim3(256), 0, st, g); \
+    } while (0)
+    static const int use_x3 = getenv("VAE_GEMM_X3") ? atoi(getenv("VAE_GEMM_X3")) : 1;  // 0: fp32 MFMA pipeline
+    if (use_x3) {
+      if (layout == NT) VAE_X3_LAUNCH(NT);
+      else if (layout == NN) VAE_X3_LAUNCH(NN);
+      else VAE_X3_LAUNCH(TN);
+    } else if (layout == NT) VAE_DMA_LAUNCH(NT);
     else if (layout == NN) VAE_DMA_LAUNCH(NN);
     else VAE_DMA_LAUNCH(TN);
 #undef VAE_DMA_LAUNCH
+#undef VAE_X3_LAUNCH
   } else if (precision == 0) {
     if (layout == NT) launch_t<NT, 0>(g, norm, grid, st, plan.tile);
     else if (layout == NN) launch_t<NN, 0>(g, false, grid, st, plan.tile);
     else launch_t<TN, 0>(g, norm, grid, st, plan.tile);
-  } else {
+  } else if (precision == 1) {
     if (layout == NT) launch_t<NT, 1>(g, norm, grid, st, plan.tile);
     else if (layout == NN) launch_t<NN, 1>(g, false, grid, st, plan.tile);
     else launch_t<TN, 1>(g, norm, grid, st, plan.tile);
+  } else {
+    if (layout == NT) launch_t<NT, 2>(g, norm, grid, st, plan.tile);
+    else if (layout == NN) launch_t<NN, 2>(g, false, grid, st, plan.tile);
+    else launch_t<TN, 2>(g, norm, grid, st, plan.tile);
   }
   VAE_CHECK_LAUNCH("vae_gemm");
   if (split > 1 && !slabs_out) {

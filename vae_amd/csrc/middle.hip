@@ -20,6 +20,13 @@
 
 #include <stdlib.h>
 
+#ifdef VAE_PROBE
+__device__ unsigned long long vae_probe[4096 * 16];
+#define STAMP(i) do { if (threadIdx.x == 0) vae_probe[blockIdx.x * 16 + (i)] = wall_clock64(); } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
+
 namespace {
 
 constexpr int T = 256;   // threads per workgroup
@@ -46,24 +53,33 @@ __device__ __forceinline__ float dot_batched(const float* a, int sa, const float
   return acc;
 }
 
-// Sums the nslab split-K partials of ME elements per thread (element e = t + T*i < W), slab order,
-// with the loads of eight slabs of every element in flight together.
-__device__ __forceinline__ void slab_sum(const float* __restrict__ base, int nslab, int64_t stride, int W, float (&v)[4]) {
+// Sums the nslab split-K partials of NE elements per thread (element e = t + T*i < W) in slab
+// order, with up to 48 loads in flight per thread: a dependent round trip costs ~2 us at the low
+// occupancy of these kernels, so the number of rounds is what matters.
+template <int NE>
+__device__ __forceinline__ void slab_sum_ne(const float* __restrict__ base, int nslab, int64_t stride, int W, float (&v)[4]) {
+  constexpr int U = 48 / NE;
   const int t = threadIdx.x;
 #pragma unroll
   for (int i = 0; i < 4; ++i) v[i] = 0.f;
-  for (int s = 0; s < nslab; s += 8) {
-    float w[4][8];
+  for (int s = 0; s < nslab; s += U) {
+    float w[NE][U];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < NE; ++i)
 #pragma unroll
-      for (int u = 0; u < 8; ++u)
+      for (int u = 0; u < U; ++u)
         w[i][u] = (t + T * i < W && s + u < nslab) ? base[(int64_t)(s + u) * stride + t + T * i] : 0.f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < NE; ++i)
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[i] += w[i][u];
+      for (int u = 0; u < U; ++u) v[i] += w[i][u];
   }
+}
+__device__ __forceinline__ void slab_sum(const float* __restrict__ base, int nslab, int64_t stride, int W, float (&v)[4]) {
+  if (W <= T) slab_sum_ne<1>(base, nslab, stride, W, v);
+  else if (W <= 2 * T) slab_sum_ne<2>(base, nslab, stride, W, v);
+  else if (W <= 3 * T) slab_sum_ne<3>(base, nslab, stride, W, v);
+  else slab_sum_ne<4>(base, nslab, stride, W, v);
 }
 
 // Sums N values over the workgroup (4 waves); red holds >= 4*N floats.  Every thread gets all sums.
@@ -124,7 +140,7 @@ struct MidFwd {
 
 // softplus variance, sample and KL for one encoder, executed by ONE wave (lane j = latent j).
 // hd[0:L] = q_m, hd[L] = variance pre-activation (LDS).  Mirrors reparam_kl_fwd_kernel (rowops.hip).
-__device__ __forceinline__ void reparam_wave(const float* hd, int L, const float* eps_row, float pm, float pv, int lane,
+__device__ __forceinline__ void reparam_wave(const float* hd, int L, float eps_lane, float pm, float pv, int lane,
                                              float* z_row, float* z_lds, float* qv_out, float* kl_out) {
   const float v = softplus20(hd[L]) + 1e-4f;
   const float sq = sqrtf(v), sp = sqrtf(pv);
@@ -136,7 +152,7 @@ __device__ __forceinline__ void reparam_wave(const float* hd, int L, const float
     const float m = hd[lane];
     const float t = (m - pm) / sp;
     acc = 0.5f * (r + t * t - 1.f - lr);
-    const float zz = m + eps_row[lane] * sq;
+    const float zz = m + eps_lane * sq;
     z_row[lane] = zz;
     if (z_lds) z_lds[lane] = zz;
   }
@@ -177,6 +193,7 @@ __global__ __launch_bounds__(T) void mid_fwd_kernel(MidFwd a) {
   const int H = a.H, Hl = a.Hl, HE = a.H + a.Hl, L = a.L, Hd = a.Hd;
   const int LP = L | 1;
 
+  STAMP(0);
   // parameters this thread needs later: requested now, so their latency hides behind the slab sums
   float eb[ME], gam[ME], bet[ME], db[ME], dgam[ME], dbet[ME];
 #pragma unroll
@@ -191,6 +208,21 @@ __global__ __launch_bounds__(T) void mid_fwd_kernel(MidFwd a) {
     dbet[i] = e < Hd ? a.bd[e] : 0.f;
   }
   stage_dec_w(a.d_w, Hd, L, LP, dyn);
+  // head weights of this wave's outputs o = wave + 4 r (lanes along k: coalesced row reads), k < 256
+  constexpr int RH = 9;  // outputs per wave per pass: one pass covers L + 3 <= 36
+  float hw[RH][4];
+#pragma unroll
+  for (int r = 0; r < RH; ++r) {
+    const int o = wave + 4 * r;
+    const bool zo = o <= L;
+    const float* w = zo ? a.hz_w + (int64_t)o * H : a.hl_w + (int64_t)(o - L - 1) * Hl;
+    const int n = o < L + 3 ? (zo ? H : Hl) : 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) hw[r][i] = lane + 64 * i < n ? w[lane + 64 * i] : 0.f;
+  }
+  float epsz = 0.f, epsl = 0.f;
+  if (wave == 0 && lane < L) epsz = a.eps_z[(int64_t)b * L + lane];
+  if (wave == 1 && lane == 0) epsl = a.eps_l[b];
 
   // 1. sum the split-K slabs, add the bias: pre-activation of both first layers
   float pre[ME], g[ME];
@@ -204,9 +236,11 @@ __global__ __launch_bounds__(T) void mid_fwd_kernel(MidFwd a) {
     }
     g[i] = e < HE ? gelu_f(pre[i]) : 0.f;
   }
+  STAMP(1);
   // 2. LayerNorm of the two halves
   float mu[2], rs[2];
   ln_stats2(g, H, Hl, red, mu, rs);
+  STAMP(2);
 #pragma unroll
   for (int i = 0; i < ME; ++i) {
     const int e = t + T * i;
@@ -222,40 +256,41 @@ __global__ __launch_bounds__(T) void mid_fwd_kernel(MidFwd a) {
     a.ln_ml[b] = mu[1]; a.ln_rl[b] = rs[1];
   }
   __syncthreads();
+  STAMP(3);
   // 3. heads: output o <= L -> z heads over H, o = L+1, L+2 -> library heads over Hl.  A wave owns
   //    four outputs at a time; its lanes run along k, so every weight load is a coalesced row read.
   {
     const int nmax = max(H, Hl);
-    for (int base = wave; base < L + 3; base += 16) {
-      float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int base = wave; base < L + 3; base += 4 * RH) {
+      float acc[RH];
+#pragma unroll
+      for (int r = 0; r < RH; ++r) acc[r] = 0.f;
       for (int c = 0; c < nmax; c += 256) {
-        float wv[4][4];
+        if (base != wave || c != 0) {  // beyond the prefetched block: load now
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int o = base + 4 * r;
-          const bool zo = o <= L;
-          const float* w = zo ? a.hz_w + (int64_t)o * H : a.hl_w + (int64_t)(o - L - 1) * Hl;
-          const int n = o < L + 3 ? (zo ? H : Hl) : 0;
+          for (int r = 0; r < RH; ++r) {
+            const int o = base + 4 * r;
+            const bool zo = o <= L;
+            const float* w = zo ? a.hz_w + (int64_t)o * H : a.hl_w + (int64_t)(o - L - 1) * Hl;
+            const int n = o < L + 3 ? (zo ? H : Hl) : 0;
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const int k = c + lane + 64 * i;
-            wv[r][i] = k < n ? w[k] : 0.f;
+            for (int i = 0; i < 4; ++i) hw[r][i] = c + lane + 64 * i < n ? w[c + lane + 64 * i] : 0.f;
           }
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
+        for (int r = 0; r < RH; ++r) {
           const int o = base + 4 * r;
           const bool zo = o <= L;
           const int n = o < L + 3 ? (zo ? H : Hl) : 0;
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             const int k = c + lane + 64 * i;
-            if (k < n) acc[r] = fmaf(hs[(zo ? 0 : H) + k], wv[r][i], acc[r]);
+            if (k < n) acc[r] = fmaf(hs[(zo ? 0 : H) + k], hw[r][i], acc[r]);
           }
         }
       }
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
+      for (int r = 0; r < RH; ++r) {
         const int o = base + 4 * r;
         const float v = wave_sum(acc[r]);
         if (lane == 0 && o < L + 3) hd[o] = v + (o <= L ? a.hz_b[o] : a.hl_b[o - L - 1]);
@@ -263,15 +298,17 @@ __global__ __launch_bounds__(T) void mid_fwd_kernel(MidFwd a) {
     }
   }
   __syncthreads();
+  STAMP(4);
   // 4. reparameterised samples + KL: wave 0 -> z, wave 1 -> library
   if (wave == 0) {
     if (lane <= L) a.heads_z[(int64_t)b * (L + 1) + lane] = hd[lane];
-    reparam_wave(hd, L, a.eps_z + (int64_t)b * L, 0.f, 1.f, lane, a.z + (int64_t)b * L, zs, a.qz_v + b, a.kl_z + b);
+    reparam_wave(hd, L, epsz, 0.f, 1.f, lane, a.z + (int64_t)b * L, zs, a.qz_v + b, a.kl_z + b);
   } else if (wave == 1) {
     if (lane < 2) a.heads_l[(int64_t)b * 2 + lane] = hd[L + 1 + lane];
-    reparam_wave(hd + L + 1, 1, a.eps_l + b, a.l_mean, a.l_var, lane, a.library + b, nullptr, a.ql_v + b, a.kl_l + b);
+    reparam_wave(hd + L + 1, 1, epsl, a.l_mean, a.l_var, lane, a.library + b, nullptr, a.ql_v + b, a.kl_l + b);
   }
   __syncthreads();
+  STAMP(5);
   // 5. first decoder layer: Linear(L -> Hd) + GELU + LayerNorm, weight rows from LDS
   float gd[ME];
 #pragma unroll
@@ -286,6 +323,7 @@ __global__ __launch_bounds__(T) void mid_fwd_kernel(MidFwd a) {
     }
     gd[i] = n < Hd ? gelu_f(v) : 0.f;
   }
+  STAMP(6);
   ln_stats2(gd, Hd, 0, red, mu, rs);
 #pragma unroll
   for (int i = 0; i < ME; ++i) {
@@ -296,6 +334,7 @@ __global__ __launch_bounds__(T) void mid_fwd_kernel(MidFwd a) {
     a.ln_md[b] = mu[0];
     a.ln_rd[b] = rs[0];
   }
+  STAMP(7);
 }
 
 struct MidBwd {
@@ -357,6 +396,23 @@ __global__ __launch_bounds__(T) void mid_bwd_kernel(MidBwd a) {
     gdv[i] = e < Hd ? a.gd[e] : 0.f;
     pe[i] = e < HE ? a.pre_enc0[(int64_t)b * HE + e] : 0.f;
     gev[i] = e < HE ? (e < H ? a.gz[e] : a.gl[e - H]) : 0.f;
+  }
+  // head-weight column of this thread's first element (e = t): all of its L+1 (or 2) rows, requested now
+  constexpr int JP = 32;
+  float hwc[JP];
+#pragma unroll
+  for (int j = 0; j < JP; ++j) {
+    float v = 0.f;
+    if (t < H && j <= L) v = a.hz_w[(int64_t)j * H + t];
+    hwc[j] = v;
+  }
+  float hlc[ME][2];  // library-head weight columns of every library element of this thread
+#pragma unroll
+  for (int i = 0; i < ME; ++i) {
+    const int e = t + T * i;
+    const bool lh = e >= H && e < HE;
+    hlc[i][0] = lh ? a.hl_w[e - H] : 0.f;
+    hlc[i][1] = lh ? a.hl_w[Hl + e - H] : 0.f;
   }
   float dx[ME], xh[ME], pv[ME], dyv[ME];
   float s[2] = {0.f, 0.f};
@@ -426,11 +482,13 @@ __global__ __launch_bounds__(T) void mid_bwd_kernel(MidBwd a) {
     if (e < HE) {
       const bool zh = e < H;
       float dy = 0.f;
-      if (zh) {
-        dy = dot_batched<16>(dq, 1, a.hz_w + e, H, L + 1);
+      if (!zh) {
+        dy = fmaf(dq[L + 2], hlc[i][1], dq[L + 1] * hlc[i][0]);
+      } else if (i == 0 && L + 1 <= JP) {  // prefetched column
+#pragma unroll
+        for (int j = 0; j < JP; ++j) dy = fmaf(j <= L ? dq[j] : 0.f, hwc[j], dy);
       } else {
-        dy = dq[L + 1] * a.hl_w[e - H];
-        dy = fmaf(dq[L + 2], a.hl_w[Hl + e - H], dy);
+        dy = dot_batched<16>(dq, 1, a.hz_w + e, H, L + 1);
       }
       pv[i] = pe[i];
       xh[i] = (gelu_f(pv[i]) - (zh ? mu0 : mu1)) * (zh ? rs0 : rs1);
@@ -457,7 +515,7 @@ __global__ __launch_bounds__(T) void mid_bwd_kernel(MidBwd a) {
 
 // ---------------------------------------------------------------------------------------
 // out[p*sp + q*sq] = sum_b U[b][p] * V[b][q]   (U null: column sums of V), for a table of tasks.
-// A workgroup owns 8 p x 64 q outputs of one task: 128 cells at a time are staged in LDS (all the
+// A workgroup owns 8 p x 64 q outputs of one task: 256 cells at a time are staged in LDS (all the
 // global loads of a round in flight together); thread (q = t%64, r = t/64) sums the cells
 // b = r (mod 4) in ascending order, the four partial sums are combined r = 0..3: deterministic.
 // ---------------------------------------------------------------------------------------
@@ -475,7 +533,7 @@ struct WgradBatch {
 };
 
 __global__ __launch_bounds__(T) void small_wgrad_kernel(WgradBatch wb) {
-  constexpr int RC = 128;                 // cells staged per round
+  constexpr int RC = 256;                 // cells staged per round
   __shared__ float Vs[RC][64];            // V[b0+row][q0+col]
   __shared__ float Us[RC][PT];            // U[b0+row][p0+i] (ones for a column sum)
   __shared__ float comb[4][PT][64];

@@ -14,7 +14,7 @@ import torch
 from . import _lib
 
 NT, NN, TN = 0, 1, 2
-FP32, BF16 = 0, 1
+FP32, BF16, BF16X3 = 0, 1, 2
 
 _workspaces = {}
 
