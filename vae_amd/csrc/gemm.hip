@@ -181,11 +181,15 @@ __device__ __forceinline__ void store16_rc(__bf16* s, const float4 (&reg)[R / 32
 //      representable), so hi*hi + hi*mid + mid*hi + hi*lo + lo*hi + mid*mid reproduces the fp32
 //      product to 2^-25: six bf16 MFMAs (16x the fp32 MFMA rate each) replace eight fp32 MFMAs. ----
 __device__ __forceinline__ void split3(float a, __bf16& h, __bf16& m, __bf16& l) {
+  // hi is rounded to nearest (|a - hi| <= 2^-9 |a|, sign random); mid and lo are the next two
+  // 8-bit slices by truncation (bit masks run at the full VALU rate, conversions do not):
+  // every remainder is exact, and the dropped cross terms stay below 2^-24 of the product
   h = (__bf16)a;
   float r = a - (float)h;
-  m = (__bf16)r;
-  r = r - (float)m;
-  l = (__bf16)r;
+  const unsigned rb = __float_as_uint(r) & 0xffff0000u;
+  m = __builtin_bit_cast(__bf16, (unsigned short)(rb >> 16));
+  r = r - __uint_as_float(rb);
+  l = __builtin_bit_cast(__bf16, (unsigned short)(__float_as_uint(r) >> 16));
 }
 template <int R>
 __device__ __forceinline__ void store16x3_kc(__bf16* s, int plane, const float4 (&reg)[R / 32]) {
