@@ -33,7 +33,12 @@ CONFIGS = {
                  cells=131_072, desc="20k genes, 2-layer encoder/decoder, batch 4096 per GPU, data parallel"),
 }
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s
-MFMA_PEAK = {"fp32": 157.3, "bf16": 2500.0}  # dense TFLOP/s
+# dense TFLOP/s.  fp32 GEMMs run as six bf16 MFMA products per fp32 multiply-add (exact 3-way operand
+# split, gemm.hip), so their ceiling in ALGORITHMIC fp32 flops is the bf16 peak / 6 -- above the
+# 157.3 TFLOP/s of the fp32 MFMA instruction that the first version of the path used.
+MFMA_PEAK = {"fp32": 2500.0 / 6.0, "bf16": 2500.0}
+MFMA_BASIS = {"fp32": "bf16 dense 2500 TFLOP/s / 6 products per fp32 multiply-add (bf16x3 split); the fp32 MFMA peak is 157.3",
+              "bf16": "bf16 dense 2500 TFLOP/s"}
 
 
 def synth_counts_device(n, G, device, seed, zero_inflate):
@@ -241,7 +246,8 @@ def main():
             "metric": "training cells/sec (fwd+bwd ELBO, 20k genes)" if G == 20000 else f"training cells/sec (fwd+bwd ELBO, {G} genes)",
             "value": value, "unit": "cells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if cfg["precision"] == "fp32" else "bf16 GEMM operands, f32 accumulate and likelihood",
+            "dtype": ("f32 (GEMM operands split exactly into 3 bf16 terms, 6 bf16 MFMA products, f32 accumulate; everything else f32)"
+                      if cfg["precision"] == "fp32" else "bf16 GEMM operands, f32 accumulate and likelihood"),
             "data": "synthetic",
             "config": {"workload": f"{args.config}: {cfg['desc']}", "batch_per_gpu": B, "global_batch": B * world,
                        "genes": G, "likelihood": cfg["likelihood"], "n_layers": cfg["n_layers"],
@@ -257,7 +263,8 @@ def main():
         else:
             ach, peak, unit = work / (t_ms * 1e-3) / 1e12, MFMA_PEAK[cfg["precision"]], "TFLOP/s"
         result["roofline"] = {"kernel": name, "bound": bound, "achieved": ach, "peak": peak, "unit": unit,
-                              "frac": ach / peak, "traffic": None, "avg_launch_ms": t_ms}
+                              "frac": ach / peak, "traffic": None, "avg_launch_ms": t_ms,
+                              "peak_basis": MFMA_BASIS[cfg["precision"]] if bound == "mfma" else "HBM3E 8 TB/s"}
         result["kernels"] = {
             k: {"ms": v[0], "bound": v[1],
                 "achieved": (v[2] / (v[0] * 1e-3) / (1e9 if v[1] == "hbm" else 1e12)),

@@ -99,9 +99,10 @@ int vae_add_inplace(const float* src, float* dst, int64_t n, void* stream);
 int vae_colsum(const float* in, int64_t ld, int64_t M, int64_t N, float* out, void* stream);
 
 /* out5 = { mean(-ll), mean(kl_z), mean(kl_l), gene_loss, gene_loss_coeff*gene_loss },
- * gene_loss = mean(-ll) + kl_weight*mean(kl_l + kl_z)      LitVAE.gene_loss task.py:202, :489      */
+ * gene_loss = mean(-ll) + kl_weight*mean(kl_l + kl_z)      LitVAE.gene_loss task.py:202, :489
+ * recon (nullable, [B]) = -ll, the per-cell reconstruction loss of task.py:155-165              */
 int vae_elbo_reduce(const float* ll, const float* kl_z, const float* kl_l, int64_t B, float kl_weight,
-                    float gene_loss_coeff, float* out5, void* stream);
+                    float gene_loss_coeff, float* out5, float* recon, void* stream);
 
 /* ---- fused decoder epilogue ---------------------------------------------------------------------
  * softmax over genes (modules.py:362,401), px_rate = exp(library)*px_scale (:404),
@@ -121,6 +122,14 @@ int vae_nbzinb_fwd(int zinb, const float* logit_scale, int64_t ld_s, const float
  * float atomics.                                                                                   */
 int64_t vae_nbzinb_bwd_workspace_bytes(int64_t B, int64_t G);
 int vae_nbzinb_bwd(int zinb, const float* logit_scale, int64_t ld_s, const float* logit_dropout, int64_t ld_p,
+                   const float* x, int64_t ld_x, const float* library, const float* gene_table, const float* rowmax,
+                   const float* rowsum, const float* S, const float* g_ll, float g_scalar, int64_t B, int64_t G,
+                   float* dlogit_scale, int64_t ld_ds, float* dlogit_dropout, int64_t ld_dp, float* dlibrary,
+                   float* dpx_r, float* dbias_scale, float* dbias_dropout, float* workspace, int64_t workspace_bytes,
+                   void* stream);
+/* the same with dpx_r, dbias_scale, dbias_dropout OVERWRITTEN (workspace required): no zero-fill
+ * of the gradient arrays is needed before the call                                              */
+int vae_nbzinb_bwd_overwrite(int zinb, const float* logit_scale, int64_t ld_s, const float* logit_dropout, int64_t ld_p,
                    const float* x, int64_t ld_x, const float* library, const float* gene_table, const float* rowmax,
                    const float* rowsum, const float* S, const float* g_ll, float g_scalar, int64_t B, int64_t G,
                    float* dlogit_scale, int64_t ld_ds, float* dlogit_dropout, int64_t ld_dp, float* dlibrary,
@@ -182,6 +191,7 @@ enum { VAE_WS_QZ_HEADS = 0, /* (B, L+1): [:, :L] = qz_m                         
        VAE_WS_LL,      /* (B) log-likelihood row sums; recon = -ll                                 */
        VAE_WS_SCALARS, /* 5 floats, see vae_elbo_reduce                                            */
        VAE_WS_DZ_EXTRA,/* (B, L): written by the CALLER between forward and backward (cell heads)  */
+       VAE_WS_RECON,   /* (B) = -ll                                                                */
        VAE_WS_NSLICES };
 int64_t vae_elbo_step_workspace_bytes(const vae_step_config* cfg);
 int64_t vae_elbo_step_ws_offset(const vae_step_config* cfg, int slice);

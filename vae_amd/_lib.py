@@ -31,13 +31,15 @@ SIGNATURES = {
     "vae_reparam_kl_fwd": (_i32, [_ptr, _i64, _ptr, _i64, _i64, _i64, _f32, _f32, _ptr, _ptr, _i64, _ptr, _ptr]),
     "vae_reparam_kl_bwd": (_i32, [_ptr, _i64, _ptr, _f32, _ptr, _i64, _ptr, _i64, _ptr, _i64, _i64, _f32, _f32, _ptr, _i64, _ptr, _ptr]),
     "vae_colsum": (_i32, [_ptr, _i64, _i64, _i64, _ptr, _ptr]),
-    "vae_elbo_reduce": (_i32, [_ptr, _ptr, _ptr, _i64, _f32, _f32, _ptr, _ptr]),
+    "vae_elbo_reduce": (_i32, [_ptr, _ptr, _ptr, _i64, _f32, _f32, _ptr, _ptr, _ptr]),
     "vae_gene_table_rows": (_i64, []),
     "vae_gene_table": (_i32, [_ptr, _i64, _ptr, _ptr]),
     "vae_nbzinb_max_genes": (_i64, []),
     "vae_nbzinb_fwd": (_i32, [_i32, _ptr, _i64, _ptr, _i64, _ptr, _i64, _ptr, _ptr, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _ptr]),
     "vae_nbzinb_bwd_workspace_bytes": (_i64, [_i64, _i64]),
     "vae_nbzinb_bwd": (_i32, [_i32, _ptr, _i64, _ptr, _i64, _ptr, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _f32, _i64, _i64,
+                              _ptr, _i64, _ptr, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _i64, _ptr]),
+    "vae_nbzinb_bwd_overwrite": (_i32, [_i32, _ptr, _i64, _ptr, _i64, _ptr, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _f32, _i64, _i64,
                               _ptr, _i64, _ptr, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _i64, _ptr]),
     "vae_softmax_rate_fwd": (_i32, [_ptr, _i64, _ptr, _i64, _i64, _ptr, _ptr, _ptr]),
     "vae_softmax_rate_bwd": (_i32, [_ptr, _ptr, _ptr, _ptr, _i64, _i64, _ptr, _i64, _ptr, _ptr]),
@@ -72,7 +74,7 @@ class StepTensors(C.Structure):
                 ("heads_w", _ptr), ("heads_b", _ptr)]
 
 
-WS_SLICES = ("QZ_HEADS", "QZ_V", "Z", "KL_Z", "QL_HEADS", "QL_V", "LIBRARY", "KL_L", "LL", "SCALARS", "DZ_EXTRA")
+WS_SLICES = ("QZ_HEADS", "QZ_V", "Z", "KL_Z", "QL_HEADS", "QL_V", "LIBRARY", "KL_L", "LL", "SCALARS", "DZ_EXTRA", "RECON")
 
 _lib = None
 

@@ -419,10 +419,10 @@ __global__ __launch_bounds__(256) void nbzinb_bwd_kernel(
   }
 }
 
-// out_k[g] += sum_c slab[c][k][g], k = 0 (d px_r), 1 (d bias_scale), 2 (d bias_dropout)
+// out_k[g] (+)= sum_c slab[c][k][g], k = 0 (d px_r), 1 (d bias_scale), 2 (d bias_dropout)
 __global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict__ slab, int chunks, int G, int nk,
                                                         float* __restrict__ o0, float* __restrict__ o1,
-                                                        float* __restrict__ o2) {
+                                                        float* __restrict__ o2, int overwrite) {
   const int g = blockIdx.x * 256 + threadIdx.x;
   const int k = blockIdx.y;
   if (g >= G || k >= nk) return;
@@ -437,7 +437,7 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict_
     s = (((s + a) + b) + d) + e;
   }
   for (; c < chunks; ++c) s += p[c * st];
-  o[g] += s;
+  o[g] = overwrite ? s : o[g] + s;
 }
 
 template <bool ZINB, bool VEC, int EPT, int THREADS>
@@ -528,12 +528,13 @@ extern "C" int64_t vae_nbzinb_bwd_workspace_bytes(int64_t B, int64_t G) {
   return (int64_t)chunks * 3 * G * (int64_t)sizeof(float);
 }
 
-extern "C" int vae_nbzinb_bwd(int zinb, const float* logit_scale, int64_t ld_s, const float* logit_dropout, int64_t ld_p,
-                              const float* x, int64_t ld_x, const float* library, const float* gene_table,
-                              const float* rowmax, const float* rowsum, const float* S, const float* g_ll,
-                              float g_scalar, int64_t B, int64_t G, float* dlogit_scale, int64_t ld_ds,
-                              float* dlogit_dropout, int64_t ld_dp, float* dlibrary, float* dpx_r, float* dbias_scale,
-                              float* dbias_dropout, float* workspace, int64_t workspace_bytes, void* stream) {
+static int nbzinb_bwd_impl(int zinb, const float* logit_scale, int64_t ld_s, const float* logit_dropout, int64_t ld_p,
+                           const float* x, int64_t ld_x, const float* library, const float* gene_table,
+                           const float* rowmax, const float* rowsum, const float* S, const float* g_ll,
+                           float g_scalar, int64_t B, int64_t G, float* dlogit_scale, int64_t ld_ds,
+                           float* dlogit_dropout, int64_t ld_dp, float* dlibrary, float* dpx_r, float* dbias_scale,
+                           float* dbias_dropout, float* workspace, int64_t workspace_bytes, void* stream, int overwrite) {
+  VAE_REQUIRE(!overwrite || workspace, "vae_nbzinb_bwd_overwrite: needs the workspace (deterministic mode)");
   VAE_REQUIRE(logit_scale && x && library && gene_table && rowmax && rowsum && S && dlogit_scale && dpx_r,
               "vae_nbzinb_bwd: null pointer");
   VAE_REQUIRE(!zinb || (logit_dropout && dlogit_dropout), "vae_nbzinb_bwd: ZINB needs the dropout logits and their gradient");
@@ -562,8 +563,31 @@ extern "C" int vae_nbzinb_bwd(int zinb, const float* logit_scale, int64_t ld_s, 
   VAE_CHECK_LAUNCH("vae_nbzinb_bwd");
   if (slab) {
     hipLaunchKernelGGL(colreduce_kernel, dim3((unsigned)((G + 255) / 256), zinb ? 3 : 2), dim3(256), 0, st, workspace,
-                       chunks, (int)G, zinb ? 3 : 2, dpx_r, dbias_scale, dbias_dropout);
+                       chunks, (int)G, zinb ? 3 : 2, dpx_r, dbias_scale, dbias_dropout, overwrite);
     VAE_CHECK_LAUNCH("vae_nbzinb_bwd(colreduce)");
   }
   return VAE_OK;
+}
+
+extern "C" int vae_nbzinb_bwd(int zinb, const float* logit_scale, int64_t ld_s, const float* logit_dropout, int64_t ld_p,
+                              const float* x, int64_t ld_x, const float* library, const float* gene_table,
+                              const float* rowmax, const float* rowsum, const float* S, const float* g_ll,
+                              float g_scalar, int64_t B, int64_t G, float* dlogit_scale, int64_t ld_ds,
+                              float* dlogit_dropout, int64_t ld_dp, float* dlibrary, float* dpx_r, float* dbias_scale,
+                              float* dbias_dropout, float* workspace, int64_t workspace_bytes, void* stream) {
+  return nbzinb_bwd_impl(zinb, logit_scale, ld_s, logit_dropout, ld_p, x, ld_x, library, gene_table, rowmax, rowsum, S, g_ll,
+                         g_scalar, B, G, dlogit_scale, ld_ds, dlogit_dropout, ld_dp, dlibrary, dpx_r, dbias_scale,
+                         dbias_dropout, workspace, workspace_bytes, stream, 0);
+}
+
+extern "C" int vae_nbzinb_bwd_overwrite(int zinb, const float* logit_scale, int64_t ld_s, const float* logit_dropout,
+                                        int64_t ld_p, const float* x, int64_t ld_x, const float* library,
+                                        const float* gene_table, const float* rowmax, const float* rowsum, const float* S,
+                                        const float* g_ll, float g_scalar, int64_t B, int64_t G, float* dlogit_scale,
+                                        int64_t ld_ds, float* dlogit_dropout, int64_t ld_dp, float* dlibrary, float* dpx_r,
+                                        float* dbias_scale, float* dbias_dropout, float* workspace,
+                                        int64_t workspace_bytes, void* stream) {
+  return nbzinb_bwd_impl(zinb, logit_scale, ld_s, logit_dropout, ld_p, x, ld_x, library, gene_table, rowmax, rowsum, S, g_ll,
+                         g_scalar, B, G, dlogit_scale, ld_ds, dlogit_dropout, ld_dp, dlibrary, dpx_r, dbias_scale,
+                         dbias_dropout, workspace, workspace_bytes, stream, 1);
 }

@@ -324,10 +324,12 @@ __global__ void add_inplace_kernel(const float* __restrict__ src, float* __restr
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void elbo_reduce_kernel(const float* __restrict__ ll, const float* __restrict__ kl_z,
                                                           const float* __restrict__ kl_l, int B, float kl_weight,
-                                                          float coeff, float* __restrict__ out) {
+                                                          float coeff, float* __restrict__ out,
+                                                          float* __restrict__ recon) {
   __shared__ float red[4];
   float a = 0.f, b = 0.f, c = 0.f, d = 0.f;
   for (int i = threadIdx.x; i < B; i += 256) {
+    if (recon) recon[i] = -ll[i];
     a -= ll[i];
     b += kl_z[i];
     c += kl_l[i];
@@ -439,10 +441,10 @@ extern "C" int vae_colsum(const float* in, int64_t ld, int64_t M, int64_t N, flo
 }
 
 extern "C" int vae_elbo_reduce(const float* ll, const float* kl_z, const float* kl_l, int64_t B, float kl_weight,
-                               float gene_loss_coeff, float* out5, void* stream) {
+                               float gene_loss_coeff, float* out5, float* recon, void* stream) {
   VAE_REQUIRE(ll && kl_z && kl_l && out5 && B > 0, "vae_elbo_reduce: bad arguments");
   hipLaunchKernelGGL(elbo_reduce_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, ll, kl_z, kl_l, (int)B, kl_weight,
-                     gene_loss_coeff, out5);
+                     gene_loss_coeff, out5, recon);
   VAE_CHECK_LAUNCH("vae_elbo_reduce");
   return VAE_OK;
 }

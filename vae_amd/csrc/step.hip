@@ -16,7 +16,7 @@ struct Layout {
   int64_t encz_pre[VAE_MAX_LAYERS], encz_h[VAE_MAX_LAYERS];  // layers >= 1
   int64_t heads_z, heads_l, qz_v, z, kl_z, ql_v, library, kl_l;
   int64_t dec_pre[VAE_MAX_LAYERS], dec_h[VAE_MAX_LAYERS], ln_md[VAE_MAX_LAYERS], ln_rd[VAE_MAX_LAYERS];
-  int64_t logits, table, ll, rowmax, rowsum, S, scalars;
+  int64_t logits, table, ll, recon, rowmax, rowsum, S, scalars;
   int64_t dz_extra, dlibrary, dheads_z, dheads_l, dpre_enc0, dh, dpx, dz;
   int64_t dbet_d, dgam_d, dbet_e, dgam_e;  // per-cell LayerNorm-gradient rows of the fused middle
   int64_t scratch;        // split-K slabs / column-sum slabs (shared, used by one launch at a time)
@@ -50,7 +50,7 @@ bool make_layout(const vae_step_config& c, Layout* lo) {
   }
   lo->logits = take(B * NH);
   lo->table = take(vae_gene_table_rows() * G);
-  lo->ll = take(B); lo->rowmax = take(B); lo->rowsum = take(B); lo->S = take(B); lo->scalars = take(8);
+  lo->ll = take(B); lo->recon = take(B); lo->rowmax = take(B); lo->rowsum = take(B); lo->S = take(B); lo->scalars = take(8);
   lo->dz_extra = take(B * L); lo->dlibrary = take(B);
   lo->dheads_z = take(B * (L + 1)); lo->dheads_l = take(B * 2);
   lo->dpre_enc0 = take(B * (H + Hl)); lo->dh = take(B * H); lo->dpx = take(B * Hd); lo->dz = take(B * L);
@@ -131,6 +131,7 @@ extern "C" int64_t vae_elbo_step_ws_offset(const vae_step_config* cfg, int slice
     case VAE_WS_LL: return lo.ll;
     case VAE_WS_SCALARS: return lo.scalars;
     case VAE_WS_DZ_EXTRA: return lo.dz_extra;
+    case VAE_WS_RECON: return lo.recon;
     default: return -1;
   }
 }
@@ -194,7 +195,8 @@ extern "C" int vae_elbo_step_forward(const vae_step_config* cfg, const vae_step_
   TRY(vae_gene_table(p->px_r, G, ws + lo.table, stream));
   TRY(vae_nbzinb_fwd(c.zinb, ws + lo.logits, NH, c.zinb ? ws + lo.logits + G : nullptr, NH, x, ldx, ws + lo.library,
                      ws + lo.table, B, G, ws + lo.ll, ws + lo.rowmax, ws + lo.rowsum, ws + lo.S, stream));
-  TRY(vae_elbo_reduce(ws + lo.ll, ws + lo.kl_z, ws + lo.kl_l, B, c.kl_weight, c.gene_loss_coeff, ws + lo.scalars, stream));
+  TRY(vae_elbo_reduce(ws + lo.ll, ws + lo.kl_z, ws + lo.kl_l, B, c.kl_weight, c.gene_loss_coeff, ws + lo.scalars,
+                      ws + lo.recon, stream));
   return VAE_OK;
 }
 
@@ -214,8 +216,8 @@ extern "C" int vae_elbo_step_backward(const vae_step_config* cfg, const vae_step
   float* logits = ws + lo.logits;
   float* lp = c.zinb ? logits + G : nullptr;
 
-  // epilogue backward: logits := dlogits (in place)
-  TRY(vae_nbzinb_bwd(c.zinb, logits, NH, lp, NH, x, ldx, ws + lo.library, ws + lo.table, ws + lo.rowmax, ws + lo.rowsum,
+  // epilogue backward: logits := dlogits (in place); d px_r and the head-bias gradients are overwritten
+  TRY(vae_nbzinb_bwd_overwrite(c.zinb, logits, NH, lp, NH, x, ldx, ws + lo.library, ws + lo.table, ws + lo.rowmax, ws + lo.rowsum,
                      ws + lo.S, nullptr, g_ll, B, G, logits, NH, lp, NH, ws + lo.dlibrary, g->px_r, g->heads_b,
                      c.zinb ? g->heads_b + G : nullptr, ws + lo.scratch, lo.scratch_floats * 4, stream));
   const float* px = ws + lo.dec_h[c.n_layers - 1];
@@ -235,6 +237,18 @@ extern "C" int vae_elbo_step_backward(const vae_step_config* cfg, const vae_step
                          ws + lo.dpx, ws + lo.dheads_z, ws + lo.dheads_l, ws + lo.dbet_e, ws + lo.dgam_e,
                          ws + lo.dpre_enc0, stream));
   } else {
+    // the unfused kernels ACCUMULATE the LayerNorm / bias gradients with atomics: clear them first
+    auto zero = [&](float* q, int64_t n) {
+      return (q && hipMemsetAsync(q, 0, (size_t)n * sizeof(float), (hipStream_t)stream) != hipSuccess)
+                 ? vae_set_error(VAE_ERR_LAUNCH, "vae_elbo_step_backward: hipMemsetAsync failed") : VAE_OK;
+    };
+    for (int n = 0; n < c.n_layers; ++n) {
+      TRY(zero(g->dec_ln_g[n], Hd)); TRY(zero(g->dec_ln_b[n], Hd)); TRY(zero(g->dec_b[n], Hd));
+      TRY(zero(g->encz_ln_g[n], H)); TRY(zero(g->encz_ln_b[n], H));
+      if (n > 0) TRY(zero(g->encz_b[n], H));
+    }
+    TRY(zero(g->encl_ln_g, Hl)); TRY(zero(g->encl_ln_b, Hl)); TRY(zero(g->enc_b0, HE));
+    TRY(zero(g->hz_b, L + 1)); TRY(zero(g->hl_b, 2));
     TRY(k.gemm(VAE_NN, B, Hd, NH, logits, NH, p->heads_w, Hd, ws + lo.dpx, Hd, nullptr, nullptr, 0));
 
     // decoder hidden layers

@@ -200,7 +200,7 @@ def elbo_reduce(ll: torch.Tensor, kl_z: torch.Tensor, kl_l: torch.Tensor, kl_wei
     B = ll.numel()
     _chk1d(ll, B, "ll"); _chk1d(kl_z, B, "kl_z"); _chk1d(kl_l, B, "kl_l")
     out = torch.empty(5, dtype=torch.float32, device=ll.device)
-    _lib.check(lib.vae_elbo_reduce(_p(ll), _p(kl_z), _p(kl_l), B, float(kl_weight), float(coeff), _p(out), _stream()),
+    _lib.check(lib.vae_elbo_reduce(_p(ll), _p(kl_z), _p(kl_l), B, float(kl_weight), float(coeff), _p(out), None, _stream()),
                "elbo_reduce")
     return out
 

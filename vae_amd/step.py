@@ -98,6 +98,7 @@ class ElboStep:
         self.grads = _tensors(a.g, a.gcat, self.n_layers, self.zinb)
         self._plans: Dict[int, tuple] = {}
         self._ev_heads = None
+        self._zero = None
 
     def _plan(self, B: int, loss_scale: float):
         """Config struct, workspace and named views for batch size B (cached)."""
@@ -124,6 +125,7 @@ class ElboStep:
                 ll=ws[off["LL"]:off["LL"] + B],
                 scalars=ws[off["SCALARS"]:off["SCALARS"] + 5],
                 dz_extra=ws[off["DZ_EXTRA"]:off["DZ_EXTRA"] + B * L].view(B, L),
+                recon=ws[off["RECON"]:off["RECON"] + B],
             )
             self._plans[key] = (cfg, ws, nbytes, v)
         cfg, ws, nbytes, v = self._plans[key]
@@ -155,13 +157,11 @@ class ElboStep:
         _lib.check(rc, "elbo_step_forward")
         s = v["scalars"]
         out = dict(qz_m=v["heads_z"][:, :L], qz_v=v["qz_v"], z=v["z"], ql_m=v["heads_l"][:, :1], ql_v=v["ql_v"],
-                   library=v["library"], recon=-v["ll"], kl_z=v["kl_z"], kl_l=v["kl_l"], recon_mean=s[0],
+                   library=v["library"], recon=v["recon"], kl_z=v["kl_z"], kl_l=v["kl_l"], recon_mean=s[0],
                    gene_loss=s[3], scalars=s)
 
         # ---------------- cell heads (tiny; torch autograd on z only) ----------------
         use_extra = 0
-        if backward:
-            a.zero_small_grads()
         if cell_head_fn is not None:
             z_leaf = v["z"].detach().clone().requires_grad_(True)
             with torch.enable_grad():
@@ -173,7 +173,9 @@ class ElboStep:
             out["cell_loss"] = cell_loss.detach()
             out["loss"] = s[4] + out["cell_loss"]
         else:
-            out["cell_loss"] = torch.zeros((), device=x.device)
+            if self._zero is None:
+                self._zero = torch.zeros((), device=x.device)
+            out["cell_loss"] = self._zero
             out["loss"] = s[4]
         if not backward:
             return out
