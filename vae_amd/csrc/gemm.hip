@@ -616,7 +616,7 @@ __global__ __launch_bounds__(256, 2) void gemm32_dma_kernel(GemmArgs g) {
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
 
-template <int LAYOUT, int BM, int BN, int WAVES_M>
+template <int LAYOUT, int BM, int BN, int WAVES_M, int NP>
 __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(GemmArgs g) {
   constexpr bool A_KC = (LAYOUT != TN);
   constexpr bool B_KC = (LAYOUT == NT);
@@ -626,9 +626,9 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(GemmArgs g) {
   constexpr int LDK = 40, LDR = 160;                        // bf16 row strides of the two images
   constexpr int PLA = A_KC ? BM * LDK : 32 * LDR;           // bf16 per plane
   constexpr int PLB = B_KC ? BN * LDK : 32 * LDR;
-  __shared__ __attribute__((aligned(16))) __bf16 smem[3 * (PLA + PLB)];
+  __shared__ __attribute__((aligned(16))) __bf16 smem[NP * (PLA + PLB)];
   __bf16* sA = smem;
-  __bf16* sB = smem + 3 * PLA;
+  __bf16* sB = smem + NP * PLA;
 
   const int nwg = gridDim.x;
   const int xcd = blockIdx.x & 7, q8 = nwg >> 3, r8 = nwg & 7;
@@ -696,8 +696,10 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(GemmArgs g) {
       hi[j] = a; mi[j] = b; lo[j] = d;
     }
     *reinterpret_cast<bf16x4*>(base + off) = hi;
-    *reinterpret_cast<bf16x4*>(base + plane + off) = mi;
-    *reinterpret_cast<bf16x4*>(base + 2 * plane + off) = lo;
+    if (NP == 3) {
+      *reinterpret_cast<bf16x4*>(base + plane + off) = mi;
+      *reinterpret_cast<bf16x4*>(base + 2 * plane + off) = lo;
+    }
   };
   auto stage = [&]() {
     __syncthreads();  // the previous tile's fragment reads are done
@@ -740,24 +742,28 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(GemmArgs g) {
   auto multiply = [&]() {
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 a[TM][3];
+      bf16x8 a[TM][NP];
 #pragma unroll
       for (int ti = 0; ti < TM; ++ti)
 #pragma unroll
-        for (int q = 0; q < 3; ++q) a[ti][q] = frag(sA + q * PLA, A_KC, fa, ti, ks);
+        for (int q = 0; q < NP; ++q) a[ti][q] = frag(sA + q * PLA, A_KC, fa, ti, ks);
 #pragma unroll
       for (int tj = 0; tj < TNN; ++tj) {
-        bf16x8 b[3];
+        bf16x8 b[NP];
 #pragma unroll
-        for (int q = 0; q < 3; ++q) b[q] = frag(sB + q * PLB, B_KC, fb, tj, ks);
+        for (int q = 0; q < NP; ++q) b[q] = frag(sB + q * PLB, B_KC, fb, tj, ks);
 #pragma unroll
         for (int ti = 0; ti < TM; ++ti) {
           f32x16 c = acc[ti][tj];  // smallest terms first
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ti][1], b[1], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ti][2], b[0], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ti][0], b[2], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ti][1], b[0], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ti][0], b[1], c, 0, 0, 0);
+          if (NP == 1) {  // plain bf16 operands (VAE_BF16): one product
+            acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ti][0], b[0], c, 0, 0, 0);
+            continue;
+          }
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ti][NP > 1 ? 1 : 0], b[NP > 1 ? 1 : 0], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ti][NP > 1 ? 2 : 0], b[0], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ti][0], b[NP > 1 ? 2 : 0], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ti][NP > 1 ? 1 : 0], b[0], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ti][0], b[NP > 1 ? 1 : 0], c, 0, 0, 0);
           c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ti][0], b[0], c, 0, 0, 0);
           acc[ti][tj] = c;
         }
@@ -958,7 +964,7 @@ int gemm_impl(int layout, int precision, int64_t M, int64_t N, int64_t K, const 
   static const int no_dma = getenv("VAE_GEMM_NO_DMA") ? atoi(getenv("VAE_GEMM_NO_DMA")) : 0;  // tuning knob
   const bool norm = x_mean != nullptr;
   const bool a_rc = layout == TN, b_rc = layout != NT;
-  const bool dma_ok = precision == 0 && !norm && plan.tile == 128 && !no_dma && K % BK == 0 && g.vecA && g.vecB &&
+  const bool dma_ok = precision <= 1 && !norm && plan.tile == 128 && !no_dma && K % BK == 0 && g.vecA && g.vecB &&
                       (!a_rc || M % 4 == 0) && (!b_rc || N % 4 == 0) && M >= 4 && N >= 4;
   int bm = plan.tile, bn = plan.tile, split = plan.split;
   if (dma_ok) {
@@ -998,17 +1004,21 @@ int gemm_impl(int layout, int precision, int64_t M, int64_t N, int64_t K, const 
       else if (bn == 160)         hipLaunchKernelGGL((gemm32_dma_kernel<LAY, 128, 160, 4>), grid1, dim3(256), 0, st, g); \
       else                        hipLaunchKernelGGL((gemm32_dma_kernel<LAY, 160, 128, 1>), grid1, dim3(256), 0, st, g); \
     } while (0)
-#define VAE_X3_LAUNCH(LAY)                                                                               \
+#define VAE_X3_LAUNCH(LAY, NPL)                                                                               \
     do {                                                                                                   \
-      if (bm == 128 && bn == 128) hipLaunchKernelGGL((gemm_x3_kernel<LAY, 128, 128, 2>), grid1, dim3(256), 0, st, g); \
-      else if (bn == 160)         hipLaunchKernelGGL((gemm_x3_kernel<LAY, 128, 160, 4>), grid1, dim3(256), 0, st, g); \
-      else                        hipLaunchKernelGGL((gemm_x3_kernel<LAY, 160, 128, 1>), grid1, dim3(256), 0, st, g); \
+      if (bm == 128 && bn == 128) hipLaunchKernelGGL((gemm_x3_kernel<LAY, 128, 128, 2, NPL>), grid1, dim3(256), 0, st, g); \
+      else if (bn == 160)         hipLaunchKernelGGL((gemm_x3_kernel<LAY, 128, 160, 4, NPL>), grid1, dim3(256), 0, st, g); \
+      else                        hipLaunchKernelGGL((gemm_x3_kernel<LAY, 160, 128, 1, NPL>), grid1, dim3(256), 0, st, g); \
     } while (0)
     static const int use_x3 = getenv("VAE_GEMM_X3") ? atoi(getenv("VAE_GEMM_X3")) : 1;  // 0: fp32 MFMA pipeline
-    if (use_x3) {
-      if (layout == NT) VAE_X3_LAUNCH(NT);
-      else if (layout == NN) VAE_X3_LAUNCH(NN);
-      else VAE_X3_LAUNCH(TN);
+    if (precision == 1) {
+      if (layout == NT) VAE_X3_LAUNCH(NT, 1);
+      else if (layout == NN) VAE_X3_LAUNCH(NN, 1);
+      else VAE_X3_LAUNCH(TN, 1);
+    } else if (use_x3) {
+      if (layout == NT) VAE_X3_LAUNCH(NT, 3);
+      else if (layout == NN) VAE_X3_LAUNCH(NN, 3);
+      else VAE_X3_LAUNCH(TN, 3);
     } else if (layout == NT) VAE_DMA_LAUNCH(NT);
     else if (layout == NN) VAE_DMA_LAUNCH(NN);
     else VAE_DMA_LAUNCH(TN);
