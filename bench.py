@@ -157,10 +157,15 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the config's)")
     ap.add_argument("--precision", default="", choices=["", "fp32", "bf16"])
     ap.add_argument("--grad-payload", default="fp32", choices=["fp32", "bf16"])
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="collective backend; gloo only to rehearse the N>1 path on a box with fewer GPUs than ranks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-breakdown", action="store_true")
     args = ap.parse_args()
 
+    if os.environ.get("VAE_BENCH_WATCHDOG"):  # dump every thread's stack if the run is still alive after N seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["VAE_BENCH_WATCHDOG"]), exit=True)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -168,11 +173,16 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("bench.py: --gpus N > 1 must be launched through torch.distributed.run (one rank per GPU)")
     import torch.distributed as dist
+    if args.backend == "gloo":
+        local_rank %= max(1, torch.cuda.device_count())  # rehearsal: ranks may share a GPU
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
 
     from vae_amd import ops
     from vae_amd.arena import ParamArena

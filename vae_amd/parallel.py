@@ -31,6 +31,9 @@ class GradAllReducer:
         self.payload = payload
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.on_gpu = arena.flat_grad.is_cuda
+        # RCCL averages in the collective itself (ReduceOp.AVG); gloo has no AVG: sum, then scale
+        self.avg_in_collective = (self.world > 1 and self.on_gpu and payload == "fp32"
+                                  and dist.get_backend(group) == "nccl")
         self.comm_stream = torch.cuda.Stream(device=arena.device) if self.on_gpu else None
         self._pending: List[Tuple[torch.Tensor, Optional[torch.Tensor], object]] = []
         # bucket boundaries (element offsets into flat_grad): decoder-head weights | everything else.
@@ -68,7 +71,8 @@ class GradAllReducer:
             work = dist.all_reduce(wire, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
             self._pending.append((buf, wire, work))
         else:
-            work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            op = dist.ReduceOp.AVG if self.avg_in_collective else dist.ReduceOp.SUM
+            work = dist.all_reduce(buf, op=op, group=self.group, async_op=True)
             self._pending.append((buf, None, work))
 
     def finish(self) -> None:
@@ -82,7 +86,8 @@ class GradAllReducer:
                 work.wait()
                 if wire is not None:
                     buf.copy_(wire)
-                buf.mul_(scale)
+                if not (self.avg_in_collective and wire is None):
+                    buf.mul_(scale)
         self._pending.clear()
         if self.on_gpu:
             torch.cuda.current_stream().wait_stream(self.comm_stream)

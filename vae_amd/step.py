@@ -24,6 +24,8 @@ and the mirror-image backward kernels.
 """
 from __future__ import annotations
 
+import os
+
 import ctypes as C
 from typing import Callable, Dict, Optional
 
@@ -181,7 +183,7 @@ class ElboStep:
             return out
 
         ev = None
-        if reducer is not None and reducer.world > 1:
+        if reducer is not None and reducer.world > 1 and not os.environ.get("VAE_NO_NATIVE_EVENT"):
             if self._ev_heads is None:
                 self._ev_heads = torch.cuda.Event()
                 self._ev_heads.record()  # materialises the hipEvent_t handle
