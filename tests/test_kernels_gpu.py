@@ -47,6 +47,38 @@ def test_gemm_fp32(ops, layout, shape):
 
 
 @pytest.mark.parametrize("layout", [0, 1, 2])
+@pytest.mark.parametrize("shape", [(132, 260, 4096), (640, 1280, 256), (512, 384, 2048), (96, 257, 4101)])
+def test_gemm_split_precision_is_fp32_grade(ops, layout, shape):
+    """precision 2 (and the default fp32 route for aligned shapes): operands split exactly into three
+    bf16 terms, six bf16 MFMA products -- must be as accurate as an fp32 GEMM, on operands with a
+    wide dynamic range (rows scaled by 2^-20 .. 2^20)."""
+    M, N, K = shape
+    g = torch.Generator().manual_seed(31)
+    scale = torch.exp2(torch.randint(-20, 21, (M, 1), generator=g).double())
+    a64 = _rand((M, K), 6) * scale
+    b64 = _rand((K, N), 7, 0.05)
+    A = (a64 if layout != ops.TN else a64.t().contiguous()).float().cuda()
+    Bm = (b64.t().contiguous() if layout == ops.NT else b64).float().cuda()
+    ref = (A.double().cpu() if layout != ops.TN else A.double().cpu().t()) @ (Bm.double().cpu().t() if layout == ops.NT else Bm.double().cpu())
+    mag = (a64.abs() @ b64.abs()).numpy()
+    for prec in (ops.FP32, ops.BF16X3):
+        out = ops.gemm(layout, A, Bm, precision=prec).double().cpu().numpy()
+        assert np.max(np.abs(out - ref.numpy()) / mag) < 4e-7 * max(1.0, np.sqrt(K) / 16), prec
+
+
+@pytest.mark.parametrize("layout", [0, 1, 2])
+@pytest.mark.parametrize("shape", [(512, 384, 2048), (64, 31, 256), (640, 1280, 256)])
+def test_gemm_slabs_sum_to_the_product(ops, layout, shape):
+    M, N, K = shape
+    a64, b64 = _rand((M, K), 8), _rand((K, N), 9)
+    A = (a64 if layout != ops.TN else a64.t().contiguous()).float().cuda()
+    Bm = (b64.t().contiguous() if layout == ops.NT else b64).float().cuda()
+    slabs = ops.gemm_slabs(layout, A, Bm)
+    assert slabs.dim() == 3 and slabs.shape[1:] == (M, N) and slabs.shape[0] >= 1
+    assert rel_err(slabs.double().sum(0).cpu().numpy(), (a64 @ b64).numpy()) < 2e-6 * max(1, np.sqrt(K) / 8)
+
+
+@pytest.mark.parametrize("layout", [0, 1, 2])
 def test_gemm_bf16(ops, layout):
     M, N, K = 130, 200, 1000
     a64, b64 = _rand((M, K), 4), _rand((K, N), 5)

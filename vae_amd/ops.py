@@ -96,6 +96,29 @@ def gemm(layout: int, a: torch.Tensor, b: torch.Tensor, *, out: Optional[torch.T
     return out
 
 
+def gemm_slabs(layout: int, a: torch.Tensor, b: torch.Tensor, precision: int = FP32) -> torch.Tensor:
+    """The product of ``gemm`` left as split-K partial sums: -> (n_slabs, M, N), whose sum over dim 0 is
+    the result (no bias).  What the fused encoder-tail / decoder-head kernels consume."""
+    lib = _lib.load()
+    _chk2d(a, "a"); _chk2d(b, "b")
+    if layout == NT:
+        (M, K), (N, K2) = a.shape, b.shape
+    elif layout == NN:
+        (M, K), (K2, N) = a.shape, b.shape
+    elif layout == TN:
+        (K, M), (K2, N) = a.shape, b.shape
+    else:
+        raise ValueError("layout must be NT, NN or TN")
+    if K != K2:
+        raise ValueError(f"gemm_slabs: inner dimensions differ ({K} vs {K2})")
+    nbytes = lib.vae_gemm_slabs_workspace_bytes(M, N, K)
+    ws = torch.empty(nbytes // 4, dtype=torch.float32, device=a.device)
+    n = C.c_int(0)
+    _lib.check(lib.vae_gemm_slabs(layout, precision, M, N, K, _p(a), _ld(a), _p(b), _ld(b), _p(ws), nbytes, C.byref(n),
+                                  _stream()), "gemm_slabs")
+    return ws[:n.value * M * N].view(n.value, M, N)
+
+
 def row_mean(x: torch.Tensor) -> torch.Tensor:
     lib = _lib.load()
     _chk2d(x, "x")
