@@ -110,25 +110,28 @@ class FCLayers(nn.Module):
 
 
 class GeneDropout(nn.Module):
-    """Expression-frequency-weighted input dropout (modules.py:190-209); identity when not
-    training or p < 1e-6 (all benchmark configurations)."""
+    """Input dropout whose per-gene keep probability follows how often the gene is expressed
+    (role of modules.py:190-209).  An exponential moving average (``alpha``) of the fraction of
+    cells with a non-zero count sets keep_g = clip(p * ema_g / mean(ema), 0, 0.9); kept entries are
+    rescaled by 1 / mean(keep).  Identity in eval mode and for p < 1e-6 (every benchmark config)."""
 
     def __init__(self, p: float = 0.5, alpha: float = 0.95):
         super().__init__()
-        self.p = p
-        self.alpha = alpha
-        self.running_non_zero_means = 0.0
+        self.p, self.alpha = p, alpha
+        self.running_non_zero_means = 0.0   # plain attribute, not a buffer: absent from the state dict
+
+    def _keep_probability(self, counts: torch.Tensor) -> torch.Tensor:
+        expressed = counts.gt(0).float().mean(dim=0, keepdim=True)
+        self.running_non_zero_means = self.alpha * self.running_non_zero_means + (1.0 - self.alpha) * expressed
+        ema = self.running_non_zero_means
+        return (self.p * ema / ema.mean()).clamp(0.0, 0.9)
 
     def forward(self, input: torch.Tensor) -> torch.Tensor:
-        if not self.training or self.p < 1e-6:
+        if self.p < 1e-6 or not self.training:
             return input
-        non_zero_means = (input > 0).to(torch.float32).mean(dim=0, keepdim=True)
-        self.running_non_zero_means = self.alpha * self.running_non_zero_means + (1 - self.alpha) * non_zero_means
-        p = self.p * self.running_non_zero_means / self.running_non_zero_means.mean()
-        p = torch.clip(p, 0.0, 0.9)
-        rand = torch.rand(*input.size()).to(device=input.device)
-        mask = (rand < p).to(torch.float32)
-        return (input * mask) / p.mean()
+        keep = self._keep_probability(input)
+        u = torch.rand(*input.size()).to(device=input.device)   # drawn on the host like the reference (same RNG stream)
+        return input * (u < keep).float() / keep.mean()
 
 
 class Encoder(nn.Module):
@@ -159,7 +162,8 @@ class Encoder(nn.Module):
 
 
 class GroupedEncoder(nn.Module):
-    """One Encoder per cell property, outputs concatenated (modules.py:134-188)."""
+    """A separate Encoder per cell property; means, variances and samples are concatenated along the
+    latent axis in the order of ``cell_properties`` (role of modules.py:134-188)."""
 
     def __init__(self, n_input: int, n_latent: int, cell_properties: Optional[Dict[str, Any]] = None,
                  batch_properties: Optional[Dict[str, Any]] = None, n_layers: int = 1, n_hidden: int = 128,
@@ -167,23 +171,22 @@ class GroupedEncoder(nn.Module):
         super().__init__()
         self.z_enc = nn.ModuleDict()
         self.cell_properties = cell_properties
-        self.cell_predict = nn.ModuleDict()
-        for k in cell_properties.keys():
-            self.z_enc[k] = Encoder(n_input, n_latent, batch_properties=batch_properties, n_layers=n_layers,
-                                    n_hidden=n_hidden, dropout_rate=dropout_rate,
-                                    input_dropout_rate=input_dropout_rate, distribution=latent_distribution)
+        self.cell_predict = nn.ModuleDict()   # empty in the reference too; kept for module-tree parity
+        enc_args = dict(batch_properties=batch_properties, n_layers=n_layers, n_hidden=n_hidden, dropout_rate=dropout_rate,
+                        input_dropout_rate=input_dropout_rate, distribution=latent_distribution)
+        for name in cell_properties:
+            self.z_enc[name] = Encoder(n_input, n_latent, **enc_args)
 
     def forward(self, x: torch.Tensor, batch_labels: torch.Tensor, batch_mask: torch.Tensor):
-        q_m, q_v, latent = [], [], []
-        for k in self.cell_properties.keys():
-            a, b, c = self.z_enc[k](x, batch_labels, batch_mask)
-            q_m.append(a); q_v.append(b); latent.append(c)
-        return torch.cat(q_m, dim=-1), torch.cat(q_v, dim=-1), torch.cat(latent, dim=-1)
+        parts = [self.z_enc[name](x, batch_labels, batch_mask) for name in self.cell_properties]
+        q_m, q_v, latent = (torch.cat(group, dim=-1) for group in zip(*parts))
+        return q_m, q_v, latent
 
 
 class CellDecoder(nn.Module):
-    """Cell-property heads on the latent (modules.py:274-324): gradient reversal for keys in
-    ``grad_reverse_dict``, ``detach`` for stop_grad properties.  Tiny (B x L x n_targets)."""
+    """Cell-property heads on the latent (role of modules.py:274-324).  A property listed in
+    ``grad_reverse_dict`` sees the latent through a gradient-reversal layer (adversarial head), a
+    ``stop_grad`` property sees it detached, the others see it as is.  Tiny: B x L x n_targets."""
 
     def __init__(self, latent_dim: int, cell_properties: Dict[str, Any], grad_reverse_dict: Optional[Dict] = None,
                  use_hidden_layer: bool = True):
@@ -193,26 +196,23 @@ class CellDecoder(nn.Module):
         self.cell_mlp = nn.ModuleDict()
         self.grad_reverse_dict = grad_reverse_dict
         if grad_reverse_dict is not None:
-            self.grad_reverse = nn.ModuleDict()
-            for k, v in grad_reverse_dict.items():
-                self.grad_reverse[k] = GradReverseLayer(v)
-        for k, cell_prop in cell_properties.items():
-            n_targets = 1 if not cell_prop["discrete"] else len(cell_prop["values"])
-            if use_hidden_layer:
-                self.cell_mlp[k] = nn.Sequential(nn.Linear(latent_dim, 2 * latent_dim), nn.GELU(),
-                                                 nn.Linear(2 * latent_dim, n_targets))
+            self.grad_reverse = nn.ModuleDict({k: GradReverseLayer(lam) for k, lam in grad_reverse_dict.items()})
+        for name, prop in cell_properties.items():   # creation order = RNG order = state-dict order
+            width = len(prop["values"]) if prop["discrete"] else 1
+            if not use_hidden_layer:
+                head = nn.Linear(latent_dim, width, bias=True)
             else:
-                self.cell_mlp[k] = nn.Linear(latent_dim, n_targets, bias=True)
+                head = nn.Sequential(nn.Linear(latent_dim, 2 * latent_dim), nn.GELU(), nn.Linear(2 * latent_dim, width))
+            self.cell_mlp[name] = head
+
+    def _view_of_latent(self, name: str, prop: Dict[str, Any], latent: torch.Tensor) -> torch.Tensor:
+        if name in self.grad_reverse_dict.keys():   # a None dict raises here, as the reference does (:317)
+            return self.grad_reverse[name](latent)
+        return latent.detach() if prop["stop_grad"] else latent
 
     def forward(self, latent: torch.Tensor):
-        output = {}
-        for n, (k, cell_prop) in enumerate(self.cell_properties.items()):
-            if k in self.grad_reverse_dict.keys():  # raises on None exactly as the reference does (:317)
-                x = self.grad_reverse[k](latent)
-            else:
-                x = latent.detach() if cell_prop["stop_grad"] else latent
-            output[k] = self.cell_mlp[k](x)
-        return output
+        return {name: self.cell_mlp[name](self._view_of_latent(name, prop, latent))
+                for name, prop in self.cell_properties.items()}
 
 
 class DecoderSCVI(nn.Module):
