@@ -129,3 +129,83 @@ def test_midsize_against_oracle(likelihood):
         if o_grads[k] is None:
             continue
         assert rel_err(v.cpu().numpy(), o_grads[k].numpy()) < TOL_GRAD, k
+
+
+# ------------------------------------------------------------------------------------------------
+# BASELINE.json configs[1] at FULL size (B=512, G=20000, hidden 256/128, latent 30, ZINB, fp32):
+# direct comparison with the fp64 oracle plus size-independent properties of the step.
+# ------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def full_cfg2():
+    from oracle import vae_oracle as O
+    from vae_amd.arena import ParamArena
+    from vae_amd.step import ElboStep
+    B, G, H, Hd, Hl, L = 512, 20000, 256, 256, 128, 30
+    p = O.init_params(G, H, Hd, Hl, L, 1, seed=43)
+    x = O.synthetic_counts(B, G, seed=43, zero_inflate=0.3)
+    g = torch.Generator().manual_seed(44)
+    eps_z, eps_l = torch.randn(B, L, generator=g), torch.randn(B, 1, generator=g)
+    lm, lv = O.library_prior(x)
+    arena = ParamArena(p, 1, "zinb", "cuda")
+    step = ElboStep(arena, l_mean=lm, l_var=lv)
+    return dict(O=O, p=p, x=x, eps_z=eps_z, eps_l=eps_l, lm=lm, lv=lv, arena=arena, step=step, B=B, L=L,
+                xd=x.cuda(), ezd=eps_z.cuda(), eld=eps_l.cuda())
+
+
+def test_full_size_cfg2_against_fp64_oracle(full_cfg2):
+    c = full_cfg2
+    torch.set_num_threads(16)
+    o_out, o_grads = c["O"].training_step_with_grads(
+        {k: v.double() for k, v in c["p"].items()}, c["x"].double(), c["eps_z"].double(), c["eps_l"].double(),
+        n_layers=1, likelihood="zinb", l_mean=c["lm"], l_var=c["lv"])
+    out = c["step"].run(c["xd"], c["ezd"], c["eld"])
+    rec = out["recon"].cpu().double().numpy()
+    assert np.max(np.abs(rec - o_out["recon"].numpy()) / np.abs(o_out["recon"].numpy())) < TOL_CELL
+    for k in ("kl_z", "kl_l", "z", "library"):
+        assert rel_err(out[k].cpu().numpy().reshape(o_out[k].shape), o_out[k].numpy()) < TOL_CELL, k
+    assert abs(float(out["loss"]) - float(o_out["loss"])) < TOL_CELL * abs(float(o_out["loss"]))
+    n = 0
+    for k, v in c["arena"].grads().items():
+        if o_grads[k] is None:
+            continue
+        assert rel_err(v.cpu().numpy(), o_grads[k].numpy()) < TOL_GRAD, k
+        n += 1
+    assert n >= 15
+
+
+def test_full_size_step_is_bit_reproducible(full_cfg2):
+    """No float atomics on the 1-layer path and every gradient overwritten: a second run over a
+    poisoned gradient arena gives identical bits in every gradient tensor of the ELBO path."""
+    c = full_cfg2
+    c["step"].run(c["xd"], c["ezd"], c["eld"])
+    first = {k: v.clone() for k, v in c["arena"].grads().items() if v is not None and not k.startswith("cell_decoder")}
+    c["arena"].flat_grad.fill_(7.0)
+    out = c["step"].run(c["xd"], c["ezd"], c["eld"])
+    l2 = out["loss"].clone()
+    second = c["arena"].grads()
+    assert len(first) >= 15
+    for k, v in first.items():
+        assert torch.equal(v, second[k]), k
+    out = c["step"].run(c["xd"], c["ezd"], c["eld"])
+    assert torch.equal(l2, out["loss"])
+
+
+def test_full_size_cells_are_independent(full_cfg2):
+    """Per-cell terms of the first 64 cells do not depend on the other 448 cells of the batch."""
+    c = full_cfg2
+    full = {k: v.clone() for k, v in c["step"].run(c["xd"], c["ezd"], c["eld"], backward=False).items()
+            if k in ("recon", "kl_z", "kl_l", "z")}
+    part = c["step"].run(c["xd"][:64], c["ezd"][:64].contiguous(), c["eld"][:64].contiguous(), backward=False)
+    for k, v in full.items():
+        assert rel_err(part[k].cpu().numpy(), v[:64].cpu().numpy()) < TOL_CELL, k
+
+
+def test_full_size_loss_scale_is_linear(full_cfg2):
+    """loss_scale = 4 (a power of two) scales every gradient of the ELBO path by 4."""
+    c = full_cfg2
+    c["step"].run(c["xd"], c["ezd"], c["eld"])
+    g1 = {k: v.clone() for k, v in c["arena"].grads().items() if v is not None and not k.startswith("cell_decoder")}
+    c["step"].run(c["xd"], c["ezd"], c["eld"], loss_scale=4.0)
+    g4 = c["arena"].grads()
+    for k, v in g1.items():
+        assert rel_err(g4[k].cpu().numpy(), 4.0 * v.cpu().numpy()) < 1e-6, k
