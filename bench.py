@@ -279,6 +279,17 @@ def main():
             k: {"ms": v[0], "bound": v[1],
                 "achieved": (v[2] / (v[0] * 1e-3) / (1e9 if v[1] == "hbm" else 1e12)),
                 "unit": "GB/s" if v[1] == "hbm" else "TFLOP/s"} for k, v in ks.items()}
+    if rank == 0 and not args.no_breakdown:
+        # the optimiser step is excluded from the headline and reported beside it:
+        # clip-by-global-norm 0.5 + AdamW over every parameter with a gradient, one fused call
+        from vae_amd.optim import FusedAdamW
+        fopt = FusedAdamW(arena, lr=5e-4, weight_decay=0.1, max_grad_norm=0.5)
+        t_opt = time_kernel(fopt.step, iters=10)
+        n_act = sum(e - b for b, e, _ in fopt.ranges)
+        result["optimizer"] = {"kernel": "vae_adamw_step (clip 0.5 + AdamW, fused)", "ms": t_opt, "bound": "hbm",
+                               "achieved": n_act * 32.0 / (t_opt * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "bytes_per_param": 32, "params": n_act,
+                               "cells_per_s_with_optimizer": world * B / ((elapsed / args.steps) + t_opt * 1e-3)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         threads = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16") or 16))
         result["cpu_baseline"] = cpu_baseline(cfg, threads)

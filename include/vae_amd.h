@@ -206,6 +206,25 @@ int vae_elbo_step_backward(const vae_step_config* cfg, const vae_step_tensors* p
                            const float* x, int64_t ldx, const float* eps_z, const float* eps_l, int use_dz_extra,
                            float* workspace, int64_t workspace_bytes, void* event_heads_ready, void* stream);
 
+/* ---- fused optimiser step ------------------------------------------------------
+ * One call = torch.nn.utils.clip_grad_norm_(max_grad_norm) (Trainer(gradient_clip_val=0.5),
+ * train.py:54) followed by torch.optim.AdamW.step() (betas, eps, decoupled per-group weight decay,
+ * bias correction; task.py:534-553) over ranges of the flat arenas.  Elements outside every
+ * segment (parameters without a gradient) are not touched, as torch skips grad=None parameters.
+ * grads are read as grad_scale * grads (1 / loss scale) and are NOT modified (torch scales them
+ * in place when clipping).  lr is the scheduled learning rate of this step
+ * (WarmupConstantAndDecaySchedule, task.py:662-676, evaluated by the host); step counts from 1.
+ * max_grad_norm <= 0 disables clipping.  grad_norm_out (nullable, device): the unclipped norm.   */
+typedef struct {
+  int64_t begin, end;   /* element range [begin, end) of the arenas                                */
+  float weight_decay;   /* of the optimiser group the range belongs to                              */
+} vae_adamw_segment;
+int64_t vae_adamw_workspace_bytes(void);
+int vae_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
+                   const vae_adamw_segment* segments, int n_segments, double lr, double beta1, double beta2, double eps,
+                   int64_t step, double max_grad_norm, double grad_scale, float* workspace, int64_t workspace_bytes,
+                   float* grad_norm_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -236,3 +236,60 @@ def test_likelihood_grid_elementwise(ops, zinb):
         g_ = got.cpu().numpy().ravel().astype(np.float64)
         assert np.all(np.isfinite(g_)), name
         assert np.max(np.abs(g_ - gold[f"f64/{key}_{name}"]) / (eps32 * sc)) < 8.0, name
+
+
+# ------------------------------------------------------------------------------------------------
+# fused optimiser step against torch.nn.utils.clip_grad_norm_ + torch.optim.AdamW,
+# the optimiser the reference configures (task.py:534-553, train.py:54), run on the CPU in fp32.
+# ------------------------------------------------------------------------------------------------
+def _tiny_arena(likelihood="zinb"):
+    from oracle import vae_oracle as O
+    from vae_amd.arena import ParamArena
+    p = O.init_params(77, 12, 10, 6, 3, 1, seed=3)
+    return p, ParamArena(p, 1, likelihood, "cuda")
+
+
+@pytest.mark.parametrize("max_norm,wd", [(0.5, 0.1), (0.0, 0.0), (1e9, 0.05)])
+def test_fused_adamw_matches_torch_trajectory(max_norm, wd):
+    from vae_amd.optim import FusedAdamW, reference_weight_decay
+    p0, arena = _tiny_arena()
+    warm = 4.0
+    lam = lambda s: (warm ** 0.5) * min((s + 1) ** -0.5, (s + 1) * warm ** -1.5)  # noqa: E731
+    skip = [k for k in arena.offsets if k.startswith("cell_decoder")]
+    fused = FusedAdamW(arena, lr=1e-2, weight_decay=wd, max_grad_norm=max_norm, lr_lambda=lam, skip=skip)
+    # torch side: same parameters, same groups, grad=None for what the arena marks unused / skipped
+    names = [k for k in arena.offsets if k not in arena.no_grad and k not in skip]
+    tp = {k: p0[k].clone().float().requires_grad_(True) for k in names}
+    groups = {}
+    for k in names:
+        groups.setdefault(reference_weight_decay(k, wd), []).append(tp[k])
+    opt = torch.optim.AdamW([{"params": v, "weight_decay": w} for w, v in groups.items()], lr=1e-2, betas=(0.9, 0.998), eps=1e-7)
+    sched = torch.optim.lr_scheduler.LambdaLR(opt, lam)
+    before_unused = {k: arena.p(k).clone() for k in arena.offsets if k not in names}
+    g = torch.Generator().manual_seed(11)
+    for it in range(4):
+        for k in names:
+            gr = torch.randn(tp[k].shape, generator=g) * (10.0 if it == 1 else 0.01)   # step 1 gets clipped hard
+            tp[k].grad = gr.clone()
+            arena.g(k).copy_(gr)
+        if max_norm > 0:
+            total = torch.nn.utils.clip_grad_norm_(list(tp.values()), max_norm)
+        opt.step()
+        sched.step()
+        fused.step()
+        torch.cuda.synchronize()
+        if max_norm > 0:
+            assert abs(float(fused.grad_norm) - float(total)) <= 2e-6 * float(total)
+        for k in names:
+            assert rel_err(arena.p(k).cpu().numpy(), tp[k].detach().numpy()) < 2e-6, (it, k)
+    for k, v in before_unused.items():   # parameters without a gradient are never touched
+        assert torch.equal(arena.p(k), v), k
+
+
+def test_fused_adamw_rejects_bad_arguments():
+    from vae_amd.optim import FusedAdamW
+    _, arena = _tiny_arena()
+    opt = FusedAdamW(arena)
+    opt.steps = -1          # -> step 0 reaches the library
+    with pytest.raises(RuntimeError, match="step counts from 1"):
+        opt.step()

@@ -48,12 +48,20 @@ SIGNATURES = {
     "vae_elbo_step_ws_offset": (_i64, [_ptr, _i32]),
     "vae_elbo_step_forward": (_i32, [_ptr, _ptr, _ptr, _i64, _ptr, _ptr, _ptr, _i64, _ptr]),
     "vae_elbo_step_backward": (_i32, [_ptr, _ptr, _ptr, _ptr, _i64, _ptr, _ptr, _i32, _ptr, _i64, _ptr, _ptr]),
+    "vae_adamw_workspace_bytes": (_i64, []),
+    "vae_adamw_step": (_i32, [_ptr, _ptr, _ptr, _ptr, _i64, _ptr, _i32, C.c_double, C.c_double, C.c_double, C.c_double,
+                              _i64, C.c_double, C.c_double, _ptr, _i64, _ptr, _ptr]),
     "vae_loglik_elem_fwd": (_i32, [_i32, _ptr, _i64, _ptr, _i64, _ptr, _i64, _ptr, _i64, _i64, _i64, _ptr, _i64, _ptr]),
     "vae_loglik_elem_bwd": (_i32, [_i32, _ptr, _i64, _ptr, _i64, _ptr, _i64, _ptr, _i64, _ptr, _i64, _i64, _i64, _ptr, _ptr, _ptr, _ptr]),
 }
 
 VAE_MAX_LAYERS = 4
 _fp = C.POINTER(C.c_float)
+
+
+class AdamWSegment(C.Structure):
+    """vae_adamw_segment of include/vae_amd.h"""
+    _fields_ = [("begin", C.c_int64), ("end", C.c_int64), ("weight_decay", C.c_float)]
 
 
 class StepConfig(C.Structure):

@@ -1,0 +1,176 @@
+// Fused optimiser step over the flat parameter / gradient arenas (gfx950):
+//   global-norm gradient clipping  (Trainer(gradient_clip_val=0.5) -> torch clip_grad_norm_, train.py:54)
+//   AdamW, decoupled weight decay per range of the arena, bias correction
+//                                  (torch.optim.AdamW(betas=(0.9, 0.998), eps=1e-7), task.py:534-553)
+// Two launches for all 18 M parameters: (1) per-workgroup partial sums of g^2, (2) every
+// workgroup re-sums the partials in the same fixed order (-> identical clip coefficient in every
+// workgroup, deterministic) and updates its slice.  HBM-bound: 28 bytes per parameter
+// (read p, g, m, v; write p, m, v) plus 4 for the norm pass.
+#include "../../include/vae_amd.h"
+#include "common.h"
+
+#include <math.h>
+
+namespace {
+
+constexpr int MAX_SEG = 16;
+constexpr int NORM_BLOCKS = 1024;
+
+struct Segs {
+  int64_t begin[MAX_SEG], end[MAX_SEG];
+  float decay[MAX_SEG];  // 1 - lr * weight_decay of the range
+  int n;
+};
+
+// index of the active range holding element i, or -1
+__device__ __forceinline__ int seg_of(const Segs& s, int64_t i) {
+  int k = -1;
+#pragma unroll
+  for (int j = 0; j < MAX_SEG; ++j)
+    if (j < s.n && i >= s.begin[j] && i < s.end[j]) k = j;
+  return k;
+}
+
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, int64_t n, Segs s, float gscale,
+                                                    float* __restrict__ partial) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  const int64_t n4 = n >> 2;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    const int64_t e = i << 2;
+    const int k0 = seg_of(s, e), k3 = seg_of(s, e + 3);
+    if (k0 < 0 && k3 < 0 && seg_of(s, e + 1) < 0 && seg_of(s, e + 2) < 0) continue;
+    const float4 v = reinterpret_cast<const float4*>(g)[i];
+    const float f[4] = {v.x * gscale, v.y * gscale, v.z * gscale, v.w * gscale};
+    if (k0 >= 0 && k0 == k3) {
+      acc += (f[0] * f[0] + f[1] * f[1]) + (f[2] * f[2] + f[3] * f[3]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (seg_of(s, e + j) >= 0) acc += f[j] * f[j];
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {  // tail (n is a multiple of 4 for the arena; kept general)
+    const int64_t e = (n4 << 2) + threadIdx.x;
+    if (seg_of(s, e) >= 0) acc += g[e] * gscale * g[e] * gscale;
+  }
+  acc = block_sum<4>(acc, red);
+  if (threadIdx.x == 0) partial[blockIdx.x] = acc;
+}
+
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                    float* __restrict__ m, float* __restrict__ v, int64_t n, Segs s,
+                                                    float gscale, float beta1, float beta2, float eps, float step_size,
+                                                    float bc2_sqrt, float max_norm, const float* __restrict__ partial,
+                                                    int npartial, float* __restrict__ norm_out) {
+  __shared__ float red[4];
+  // clip coefficient: every workgroup sums the same partials in the same order
+  float coef = 1.f;
+  if (max_norm > 0.f) {
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < npartial; i += 256) acc += partial[i];
+    acc = block_sum<4>(acc, red);
+    const float total = sqrtf(acc);
+    coef = fminf(max_norm / (total + 1e-6f), 1.f);  // torch.nn.utils.clip_grad_norm_
+    if (norm_out && blockIdx.x == 0 && threadIdx.x == 0) norm_out[0] = total;
+  }
+  const float gs = gscale * coef;
+  auto upd = [&](float& pw, float gw, float& mw, float& vw, float decay) {
+    const float gg = gw * gs;
+    pw *= decay;                                   // p.mul_(1 - lr * wd)
+    mw = mw + (gg - mw) * (1.f - beta1);           // exp_avg.lerp_(grad, 1 - beta1)
+    vw = vw * beta2 + (1.f - beta2) * gg * gg;     // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+    const float denom = sqrtf(vw) / bc2_sqrt + eps;
+    pw = pw + (-step_size * mw) / denom;           // p.addcdiv_(exp_avg, denom, value=-step_size)
+  };
+  const int64_t n4 = n >> 2;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  // two 16-byte vectors of each of the four arrays in flight per thread and iteration
+  for (int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x; i0 < n4; i0 += 2 * stride) {
+    int64_t idx[2] = {i0, i0 + stride};
+    int kk[2];
+    float4 pv[2], gv[2], mv[2], vv[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      kk[u] = -2;  // -2: past the end, -1: not (entirely) inside one range
+      if (idx[u] < n4) {
+        const int k0 = seg_of(s, idx[u] << 2), k3 = seg_of(s, (idx[u] << 2) + 3);
+        kk[u] = (k0 >= 0 && k0 == k3) ? k0 : -1;
+      }
+      if (kk[u] >= 0) {
+        pv[u] = reinterpret_cast<float4*>(p)[idx[u]];
+        gv[u] = reinterpret_cast<const float4*>(g)[idx[u]];
+        mv[u] = reinterpret_cast<float4*>(m)[idx[u]];
+        vv[u] = reinterpret_cast<float4*>(v)[idx[u]];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      if (kk[u] >= 0) {
+        const float d = s.decay[kk[u]];
+        upd(pv[u].x, gv[u].x, mv[u].x, vv[u].x, d); upd(pv[u].y, gv[u].y, mv[u].y, vv[u].y, d);
+        upd(pv[u].z, gv[u].z, mv[u].z, vv[u].z, d); upd(pv[u].w, gv[u].w, mv[u].w, vv[u].w, d);
+        reinterpret_cast<float4*>(p)[idx[u]] = pv[u];
+        reinterpret_cast<float4*>(m)[idx[u]] = mv[u];
+        reinterpret_cast<float4*>(v)[idx[u]] = vv[u];
+      } else if (kk[u] == -1) {
+        const int64_t e = idx[u] << 2;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int k = seg_of(s, e + j);
+          if (k >= 0) upd(p[e + j], g[e + j], m[e + j], v[e + j], s.decay[k]);
+        }
+      }
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const int64_t e = (n4 << 2) + threadIdx.x;
+    const int k = seg_of(s, e);
+    if (k >= 0) upd(p[e], g[e], m[e], v[e], s.decay[k]);
+  }
+}
+
+}  // namespace
+
+extern "C" int64_t vae_adamw_workspace_bytes(void) { return NORM_BLOCKS * (int64_t)sizeof(float); }
+
+extern "C" int vae_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
+                              const vae_adamw_segment* segments, int n_segments, double lr, double beta1, double beta2,
+                              double eps, int64_t step, double max_grad_norm, double grad_scale, float* workspace,
+                              int64_t workspace_bytes, float* grad_norm_out, void* stream) {
+  VAE_REQUIRE(params && grads && exp_avg && exp_avg_sq && n > 0, "vae_adamw_step: null pointer or empty arena");
+  VAE_REQUIRE(segments && n_segments > 0 && n_segments <= MAX_SEG, "vae_adamw_step: 1..%d segments, got %d", MAX_SEG, n_segments);
+  VAE_REQUIRE(step >= 1, "vae_adamw_step: step counts from 1");
+  VAE_REQUIRE(lr >= 0 && beta1 >= 0 && beta1 < 1 && beta2 >= 0 && beta2 < 1 && eps >= 0, "vae_adamw_step: bad hyper-parameter");
+  VAE_REQUIRE(vae_aligned16(params) && vae_aligned16(grads) && vae_aligned16(exp_avg) && vae_aligned16(exp_avg_sq),
+              "vae_adamw_step: the four arenas must be 16-byte aligned");
+  VAE_REQUIRE(max_grad_norm <= 0 || (workspace && workspace_bytes >= vae_adamw_workspace_bytes()),
+              "vae_adamw_step: clipping needs vae_adamw_workspace_bytes() of workspace");
+  Segs s;
+  s.n = n_segments;
+  for (int i = 0; i < n_segments; ++i) {
+    VAE_REQUIRE(segments[i].begin >= 0 && segments[i].begin <= segments[i].end && segments[i].end <= n,
+                "vae_adamw_step: segment %d out of range", i);
+    VAE_REQUIRE(i == 0 || segments[i].begin >= segments[i - 1].end, "vae_adamw_step: segments must be sorted and disjoint");
+    s.begin[i] = segments[i].begin;
+    s.end[i] = segments[i].end;
+    s.decay[i] = (float)(1.0 - lr * (double)segments[i].weight_decay);
+  }
+  for (int i = n_segments; i < MAX_SEG; ++i) { s.begin[i] = s.end[i] = 0; s.decay[i] = 1.f; }
+  hipStream_t st = (hipStream_t)stream;
+  const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+  const float step_size = (float)(lr / bc1), bc2_sqrt = (float)sqrt(bc2);
+  int blocks = (int)(((n >> 2) + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) blocks = 1;
+  const int nblocks = blocks < NORM_BLOCKS ? blocks : NORM_BLOCKS;
+  if (max_grad_norm > 0) {
+    hipLaunchKernelGGL(sumsq_kernel, dim3(nblocks), dim3(256), 0, st, grads, n, s, (float)grad_scale, workspace);
+    VAE_CHECK_LAUNCH("vae_adamw_step(norm)");
+  }
+  hipLaunchKernelGGL(adamw_kernel, dim3(blocks), dim3(256), 0, st, params, grads, exp_avg, exp_avg_sq, n, s,
+                     (float)grad_scale, (float)beta1, (float)beta2, (float)eps, step_size, bc2_sqrt, (float)max_grad_norm,
+                     workspace, nblocks, grad_norm_out);
+  VAE_CHECK_LAUNCH("vae_adamw_step");
+  return VAE_OK;
+}

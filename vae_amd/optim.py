@@ -1,0 +1,94 @@
+"""Fused optimiser step on the flat arenas: gradient clipping by global norm
+(``Trainer(gradient_clip_val=0.5)``, train.py:54) + AdamW with the reference's groups
+(``betas=(0.9, 0.998)``, ``eps=1e-7``, weight decay on ``z_encoder`` / ``cell_decoder`` only,
+task.py:534-553) in two HIP launches (``vae_adamw_step``), replacing ``clip_grad_norm_`` +
+``torch.optim.AdamW.step`` (dozens of multi-tensor launches, seven passes over 18 M parameters).
+
+The learning-rate schedule stays on the host: pass ``lr_lambda`` (e.g.
+``WarmupConstantAndDecaySchedule.lr_lambda``, task.py:662-676); ``step()`` evaluates it at the number
+of steps already taken, exactly like ``LambdaLR`` stepped once per optimiser step.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Callable, Dict, Iterable, List, Optional, Tuple
+
+import torch
+
+from . import _lib
+from .arena import ParamArena
+
+
+def reference_weight_decay(name: str, weight_decay: float) -> float:
+    """The reference's two groups (task.py:534-553): decay only on z_encoder.* and cell_decoder.*."""
+    return weight_decay if ("z_encoder" in name or "cell_decoder" in name) else 0.0
+
+
+class FusedAdamW:
+    def __init__(self, arena: ParamArena, lr: float = 5e-4, betas: Tuple[float, float] = (0.9, 0.998), eps: float = 1e-7,
+                 weight_decay: float = 0.0, max_grad_norm: float = 0.5,
+                 decay_of: Callable[[str, float], float] = reference_weight_decay,
+                 lr_lambda: Optional[Callable[[int], float]] = None, skip: Iterable[str] = ()):
+        """``skip``: parameter names that receive no gradient in this run (e.g. the cell heads when no
+        cell loss is used) in addition to ``arena.no_grad``: torch leaves grad=None parameters alone."""
+        if not arena.flat.is_cuda:
+            raise RuntimeError("vae_amd: FusedAdamW needs the arena on a GPU (there is no CPU fallback)")
+        self.lib = _lib.load()
+        self.arena = arena
+        self.base_lr, self.betas, self.eps = float(lr), (float(betas[0]), float(betas[1])), float(eps)
+        self.max_grad_norm = float(max_grad_norm) if max_grad_norm else 0.0
+        self.lr_lambda = lr_lambda
+        self.steps = 0
+        self.exp_avg = torch.zeros_like(arena.flat)
+        self.exp_avg_sq = torch.zeros_like(arena.flat)
+        self.grad_norm = torch.zeros(1, dtype=torch.float32, device=arena.device)
+        self._ws = torch.empty(self.lib.vae_adamw_workspace_bytes() // 4, dtype=torch.float32, device=arena.device)
+        # contiguous ranges with one weight decay each, in arena order
+        skipped = set(skip) | set(arena.no_grad)
+        ranges: List[Tuple[int, int, float]] = []
+        for name, (off, shape) in arena.offsets.items():
+            if name in skipped:
+                continue
+            n = 1
+            for s in shape:
+                n *= s
+            wd = float(decay_of(name, weight_decay))
+            if ranges and ranges[-1][1] == off and ranges[-1][2] == wd:
+                ranges[-1] = (ranges[-1][0], off + n, wd)
+            else:
+                ranges.append((off, off + n, wd))
+        # padding between groups (<= 3 floats) is zero in every arena: bridge equal-decay neighbours
+        merged: List[Tuple[int, int, float]] = []
+        for r in ranges:
+            if merged and r[0] - merged[-1][1] <= 3 and merged[-1][2] == r[2]:
+                merged[-1] = (merged[-1][0], r[1], r[2])
+            else:
+                merged.append(r)
+        if len(merged) > 16:
+            raise RuntimeError(f"vae_amd: FusedAdamW supports up to 16 ranges, this arena needs {len(merged)}")
+        self.ranges = merged
+        self._segs = (_lib.AdamWSegment * len(merged))(*[_lib.AdamWSegment(b, e, wd) for b, e, wd in merged])
+
+    @property
+    def lr(self) -> float:
+        """Learning rate of the NEXT step."""
+        return self.base_lr * (float(self.lr_lambda(self.steps)) if self.lr_lambda is not None else 1.0)
+
+    def step(self, grad_scale: float = 1.0) -> None:
+        lr = self.lr
+        self.steps += 1
+        a = self.arena
+        rc = self.lib.vae_adamw_step(a.flat.data_ptr(), a.flat_grad.data_ptr(), self.exp_avg.data_ptr(),
+                                     self.exp_avg_sq.data_ptr(), a.total, self._segs, len(self.ranges), lr, self.betas[0],
+                                     self.betas[1], self.eps, self.steps, self.max_grad_norm, float(grad_scale),
+                                     self._ws.data_ptr(), self._ws.numel() * 4, self.grad_norm.data_ptr(),
+                                     C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        _lib.check(rc, "adamw_step")
+
+    def state_dict(self) -> Dict[str, object]:
+        return {"steps": self.steps, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq}
+
+    def load_state_dict(self, sd: Dict[str, object]) -> None:
+        self.steps = int(sd["steps"])
+        self.exp_avg.copy_(sd["exp_avg"])
+        self.exp_avg_sq.copy_(sd["exp_avg_sq"])

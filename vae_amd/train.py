@@ -16,6 +16,7 @@ import torch.distributed as dist
 from . import ops
 from .config import model_cfg as _model_cfg, task_cfg as _task_cfg, trainer_cfg as _trainer_cfg
 from .networks import VAE
+from .optim import FusedAdamW
 from .parallel import GradAllReducer, broadcast_parameters
 from .task import LitVAE
 
@@ -30,7 +31,8 @@ def main(train_idx: List[int], test_idx: List[int], cell_class: str, additional_
          counts: torch.Tensor = None, cell_prop_vals: Optional[torch.Tensor] = None,
          cell_mask: Optional[torch.Tensor] = None, cell_properties: Optional[Dict] = None,
          model_cfg: Optional[Dict] = None, task_cfg: Optional[Dict] = None, trainer_cfg: Optional[Dict] = None,
-         batch_size: int = 256, max_steps: int = 50_000, device: str = "cuda", log_every: int = 0):
+         batch_size: int = 256, max_steps: int = 50_000, device: str = "cuda", log_every: int = 0,
+         fused_optimizer: bool = True):
     """Train on ``counts[train_idx]`` (cells x genes, fp32, on ``device``); returns the LitVAE task.
 
     ``test_idx`` / ``cell_class`` / ``additional_restriction`` are accepted for signature parity;
@@ -56,8 +58,18 @@ def main(train_idx: List[int], test_idx: List[int], cell_class: str, additional_
     arena = task.attach_arena(device)
     broadcast_parameters(arena)
     reducer = GradAllReducer(arena) if dist.is_initialized() and dist.get_world_size() > 1 else None
-    opt_cfg = task.configure_optimizers()
-    opt, sched = opt_cfg["optimizer"], opt_cfg["lr_scheduler"]["scheduler"]
+    # optimiser: clip 0.5 + AdamW + warm-up / inverse-sqrt schedule, one fused call per step (optim.py);
+    # fused_optimizer=False keeps torch.optim.AdamW + clip_grad_norm_ exactly as configure_optimizers builds them
+    fused_opt = None
+    if fused_optimizer:
+        warm = float(tcfg["warmup_steps"])
+        fused_opt = FusedAdamW(arena, lr=tcfg["learning_rate"], weight_decay=tcfg["weight_decay"],
+                               max_grad_norm=rcfg["grad_clip_value"],
+                               lr_lambda=lambda s: (warm ** 0.5) * min((s + 1) ** -0.5, (s + 1) * warm ** -1.5),
+                               skip=() if use_heads else [k for k in arena.offsets if k.startswith("cell_decoder")])
+    else:
+        opt_cfg = task.configure_optimizers()
+        opt, sched = opt_cfg["optimizer"], opt_cfg["lr_scheduler"]["scheduler"]
     n = x_all.shape[0]
     gen = torch.Generator(device=device).manual_seed(43)
     params = [p for p in network.parameters() if p.grad is not None]
@@ -68,9 +80,12 @@ def main(train_idx: List[int], test_idx: List[int], cell_class: str, additional_
         out = task.training_step_fused(batch, reducer=reducer)
         if reducer is not None:
             reducer.finish()
-        torch.nn.utils.clip_grad_norm_(params, rcfg["grad_clip_value"])
-        opt.step()
-        sched.step()
+        if fused_opt is not None:
+            fused_opt.step()
+        else:
+            torch.nn.utils.clip_grad_norm_(params, rcfg["grad_clip_value"])
+            opt.step()
+            sched.step()
         if log_every and step % log_every == 0:
             print(f"step {step}: loss {float(out['loss']):.5f} gene_loss {float(out['gene_loss']):.3f}")
     return task
