@@ -157,6 +157,9 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the config's)")
     ap.add_argument("--precision", default="", choices=["", "fp32", "bf16"])
     ap.add_argument("--grad-payload", default="fp32", choices=["fp32", "bf16"])
+    ap.add_argument("--counts", default="f32", choices=["f32", "u8"],
+                    help="dtype of the resident count matrix: f32 as the reference's loader delivers it (default, the "
+                         "headline), or u8 = the reference's on-disk format expanded inside the kernels (row f2)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend; gloo only to rehearse the N>1 path on a box with fewer GPUs than ranks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -214,6 +217,8 @@ def main():
     x_all = synth_counts_device(n_cells, G, dev, seed=43 + rank, zero_inflate=0.3 if cfg["likelihood"] == "zinb" else 0.0)
     lib = torch.log1p(x_all.sum(dim=1).double())
     l_mean, l_var = float(lib.mean()), float(lib.var(unbiased=False))
+    if args.counts == "u8":
+        x_all = x_all.clamp_(max=255).to(torch.uint8)
     n_batches = n_cells // B
     gen = torch.Generator(device=dev).manual_seed(43 + rank)
     eps_z = torch.randn(B, L, generator=gen, device=dev)
@@ -261,11 +266,12 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{args.config}: {cfg['desc']}", "batch_per_gpu": B, "global_batch": B * world,
                        "genes": G, "likelihood": cfg["likelihood"], "n_layers": cfg["n_layers"],
-                       "parallelism": f"dp{world}", "grad_payload": args.grad_payload if world > 1 else None},
+                       "parallelism": f"dp{world}", "grad_payload": args.grad_payload if world > 1 else None,
+                       "counts": args.counts},
             "final_loss": loss,
         }
     if rank == 0 and not args.no_breakdown:
-        xb = x_all[:B]
+        xb = x_all[:B].float()
         ks = kernel_breakdown(arena, cfg, xb, precision)
         name, (t_ms, bound, work) = max(ks.items(), key=lambda kv: kv[1][0])
         if bound == "hbm":

@@ -67,6 +67,10 @@ int vae_row_mean(const float* x, int64_t ldx, int64_t B, int64_t G, float* mean,
  * torch evaluates it)                                         Encoder.forward, modules.py:264      */
 int vae_normalize_rows(const float* x, int64_t ldx, int64_t B, int64_t G, float* mean, float* xn, int64_t ld_xn,
                        void* stream);
+/* the same for counts kept as uint8, the reference's on-disk format (create_dataset.py:131-142,
+ * data.py:406-415): the uint8 -> fp32 expansion of the loader happens in the kernel */
+int vae_normalize_rows_u8(const uint8_t* x, int64_t ldx, int64_t B, int64_t G, float* mean, float* xn, int64_t ld_xn,
+                          void* stream);
 
 /* out = LayerNorm(GELU(pre)) * gamma + beta, eps 1e-5; saves per-row mean / rstd of GELU(pre)
  *                                                           FCLayers, modules.py:112-114          */
@@ -116,6 +120,10 @@ int64_t vae_nbzinb_max_genes(void);
 int vae_nbzinb_fwd(int zinb, const float* logit_scale, int64_t ld_s, const float* logit_dropout, int64_t ld_p,
                    const float* x, int64_t ld_x, const float* library, const float* gene_table, int64_t B, int64_t G,
                    float* ll, float* rowmax, float* rowsum, float* S, void* stream);
+/* uint8 counts (needs G % 4 == 0, ld % 4 == 0, 4-byte aligned rows)                               */
+int vae_nbzinb_fwd_u8(int zinb, const float* logit_scale, int64_t ld_s, const float* logit_dropout, int64_t ld_p,
+                   const uint8_t* x, int64_t ld_x, const float* library, const float* gene_table, int64_t B, int64_t G,
+                   float* ll, float* rowmax, float* rowsum, float* S, void* stream);
 /* gradient of sum_b g_scalar*g_ll[b]*ll[b] (g_ll nullable = 1).  dlogit_* may alias logit_*.
  * dlibrary [B] is written; dpx_r, dbias_scale, dbias_dropout [G] are accumulated -- in a fixed
  * order through `workspace` (>= vae_nbzinb_bwd_workspace_bytes) or, if workspace is NULL, with
@@ -135,6 +143,13 @@ int vae_nbzinb_bwd_overwrite(int zinb, const float* logit_scale, int64_t ld_s, c
                    float* dlogit_scale, int64_t ld_ds, float* dlogit_dropout, int64_t ld_dp, float* dlibrary,
                    float* dpx_r, float* dbias_scale, float* dbias_dropout, float* workspace, int64_t workspace_bytes,
                    void* stream);
+/* uint8 counts; overwrite != 0: as vae_nbzinb_bwd_overwrite                                        */
+int vae_nbzinb_bwd_u8(int zinb, const float* logit_scale, int64_t ld_s, const float* logit_dropout, int64_t ld_p,
+                   const uint8_t* x, int64_t ld_x, const float* library, const float* gene_table, const float* rowmax,
+                   const float* rowsum, const float* S, const float* g_ll, float g_scalar, int64_t B, int64_t G,
+                   float* dlogit_scale, int64_t ld_ds, float* dlogit_dropout, int64_t ld_dp, float* dlibrary,
+                   float* dpx_r, float* dbias_scale, float* dbias_dropout, float* workspace, int64_t workspace_bytes,
+                   int overwrite, void* stream);
 
 /* ---- stand-alone pieces behind the module API ----------------------------------------------------
  * (px_scale, px_rate) of DecoderSCVI.forward, modules.py:401-404, both (B,G) contiguous           */
@@ -162,6 +177,8 @@ int vae_loglik_elem_bwd(int zinb, const float* gout, int64_t ld_g, const float* 
  *   heads_w= [decoder.px_scale_decoder.0.weight ; decoder.px_dropout_decoder.weight]        (2G, Hd)
  *            (NB: the first G rows only), and the matching bias vectors.                          */
 #define VAE_MAX_LAYERS 4
+enum { VAE_X_F32 = 0, VAE_X_U8 = 1 };
+
 typedef struct {
   int64_t B, G, H, Hl, L, Hd;
   int32_t n_layers;  /* 1..VAE_MAX_LAYERS (z-encoder and decoder; the library encoder has 1)        */
@@ -171,6 +188,7 @@ typedef struct {
   float kl_weight;            /* task.py:213-220                                                    */
   float gene_loss_coeff;      /* task.py:489                                                        */
   float loss_scale;           /* multiplies every gradient (1 for plain training)                   */
+  int32_t x_dtype;            /* VAE_X_F32: counts are float; VAE_X_U8: uint8 (the reference's store)  */
 } vae_step_config;
 
 typedef struct {
@@ -195,7 +213,7 @@ enum { VAE_WS_QZ_HEADS = 0, /* (B, L+1): [:, :L] = qz_m                         
        VAE_WS_NSLICES };
 int64_t vae_elbo_step_workspace_bytes(const vae_step_config* cfg);
 int64_t vae_elbo_step_ws_offset(const vae_step_config* cfg, int slice);
-int vae_elbo_step_forward(const vae_step_config* cfg, const vae_step_tensors* params, const float* x, int64_t ldx,
+int vae_elbo_step_forward(const vae_step_config* cfg, const vae_step_tensors* params, const void* x, int64_t ldx,
                           const float* eps_z, const float* eps_l, float* workspace, int64_t workspace_bytes,
                           void* stream);
 /* grads: same layout as params; small tensors (biases, LayerNorm, px_r) are ACCUMULATED into, the
@@ -203,7 +221,7 @@ int vae_elbo_step_forward(const vae_step_config* cfg, const vae_step_tensors* pa
  * event_heads_ready (nullable hipEvent_t) is recorded once the decoder-head weight gradient -- the
  * largest all-reduce bucket -- has been enqueued.                                                   */
 int vae_elbo_step_backward(const vae_step_config* cfg, const vae_step_tensors* params, const vae_step_tensors* grads,
-                           const float* x, int64_t ldx, const float* eps_z, const float* eps_l, int use_dz_extra,
+                           const void* x, int64_t ldx, const float* eps_z, const float* eps_l, int use_dz_extra,
                            float* workspace, int64_t workspace_bytes, void* event_heads_ready, void* stream);
 
 /* ---- fused optimiser step ------------------------------------------------------

@@ -293,3 +293,12 @@ def test_fused_adamw_rejects_bad_arguments():
     opt.steps = -1          # -> step 0 reaches the library
     with pytest.raises(RuntimeError, match="step counts from 1"):
         opt.step()
+
+
+def test_normalize_rows_uint8_equals_float(ops):
+    g = torch.Generator().manual_seed(5)
+    x = torch.poisson(torch.rand(33, 2000, generator=g) * 3, generator=g).clamp_(max=255)
+    x[:, 0] += 1
+    m_f, xn_f = ops.normalize_rows(x.cuda())
+    m_u, xn_u = ops.normalize_rows(x.to(torch.uint8).cuda())
+    assert torch.equal(m_f, m_u) and torch.equal(xn_f, xn_u)

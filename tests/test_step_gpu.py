@@ -209,3 +209,45 @@ def test_full_size_loss_scale_is_linear(full_cfg2):
     g4 = c["arena"].grads()
     for k, v in g1.items():
         assert rel_err(g4[k].cpu().numpy(), 4.0 * v.cpu().numpy()) < 1e-6, k
+
+
+# ------------------------------------------------------------------------------------------------
+# uint8 counts (the reference stores counts as uint8 and expands them on the host,
+# create_dataset.py:131-142 / data.py:406-415; here the expansion happens inside the kernels)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("likelihood,n_layers", [("zinb", 1), ("nb", 2)])
+def test_uint8_counts_give_the_same_bits_as_float_counts(likelihood, n_layers):
+    from oracle import vae_oracle as O
+    from vae_amd.arena import ParamArena
+    from vae_amd.step import ElboStep
+    B, G, H, Hd, Hl, L = 64, 2000, 64, 64, 32, 10
+    p = O.init_params(G, H, Hd, Hl, L, n_layers, seed=9)
+    x = O.synthetic_counts(B, G, seed=9, zero_inflate=0.3).clamp_(max=255)
+    g = torch.Generator().manual_seed(10)
+    eps_z, eps_l = torch.randn(B, L, generator=g).cuda(), torch.randn(B, 1, generator=g).cuda()
+    lm, lv = O.library_prior(x)
+    res = []
+    for xin in (x.cuda(), x.to(torch.uint8).cuda()):
+        arena = ParamArena(p, n_layers, likelihood, "cuda")
+        out = ElboStep(arena, l_mean=lm, l_var=lv).run(xin, eps_z, eps_l)
+        res.append(({k: v.clone() for k, v in out.items() if k in ("recon", "kl_z", "kl_l", "loss", "z")},
+                    {k: v.clone() for k, v in arena.grads().items() if v is not None and not k.startswith("cell_decoder")}))
+    for k, v in res[0][0].items():
+        assert torch.equal(v, res[1][0][k]), k
+    if n_layers == 1:     # the multi-layer path accumulates a few vectors with float atomics
+        for k, v in res[0][1].items():
+            assert torch.equal(v, res[1][1][k]), k
+    else:
+        for k, v in res[0][1].items():
+            assert rel_err(res[1][1][k].cpu().numpy(), v.cpu().numpy()) < 1e-6, k
+
+
+def test_uint8_counts_need_vector_alignment():
+    from oracle import vae_oracle as O
+    from vae_amd.arena import ParamArena
+    from vae_amd.step import ElboStep
+    p = O.init_params(77, 12, 10, 6, 3, 1, seed=3)      # G = 77 is not a multiple of 4
+    arena = ParamArena(p, 1, "zinb", "cuda")
+    x = torch.ones(5, 77, dtype=torch.uint8, device="cuda")
+    with pytest.raises(RuntimeError, match="u8"):
+        ElboStep(arena, l_mean=4.0, l_var=1.0).run(x, torch.zeros(5, 3, device="cuda"), torch.zeros(5, 1, device="cuda"))

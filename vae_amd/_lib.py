@@ -26,6 +26,7 @@ SIGNATURES = {
     "vae_gemm_slabs": (_i32, [_i32, _i32, _i64, _i64, _i64, _ptr, _i64, _ptr, _i64, _ptr, _i64, C.POINTER(C.c_int), _ptr]),
     "vae_row_mean": (_i32, [_ptr, _i64, _i64, _i64, _ptr, _ptr]),
     "vae_normalize_rows": (_i32, [_ptr, _i64, _i64, _i64, _ptr, _ptr, _i64, _ptr]),
+    "vae_normalize_rows_u8": (_i32, [_ptr, _i64, _i64, _i64, _ptr, _ptr, _i64, _ptr]),
     "vae_gelu_ln_fwd": (_i32, [_ptr, _i64, _ptr, _ptr, _i64, _i64, _ptr, _i64, _ptr, _ptr, _ptr]),
     "vae_gelu_ln_bwd": (_i32, [_ptr, _i64, _ptr, _i64, _ptr, _ptr, _ptr, _i64, _i64, _ptr, _i64, _ptr, _ptr, _ptr, _ptr]),
     "vae_reparam_kl_fwd": (_i32, [_ptr, _i64, _ptr, _i64, _i64, _i64, _f32, _f32, _ptr, _ptr, _i64, _ptr, _ptr]),
@@ -36,6 +37,9 @@ SIGNATURES = {
     "vae_gene_table": (_i32, [_ptr, _i64, _ptr, _ptr]),
     "vae_nbzinb_max_genes": (_i64, []),
     "vae_nbzinb_fwd": (_i32, [_i32, _ptr, _i64, _ptr, _i64, _ptr, _i64, _ptr, _ptr, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _ptr]),
+    "vae_nbzinb_fwd_u8": (_i32, [_i32, _ptr, _i64, _ptr, _i64, _ptr, _i64, _ptr, _ptr, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _ptr]),
+    "vae_nbzinb_bwd_u8": (_i32, [_i32, _ptr, _i64, _ptr, _i64, _ptr, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _f32, _i64, _i64,
+                                 _ptr, _i64, _ptr, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _i64, _i32, _ptr]),
     "vae_nbzinb_bwd_workspace_bytes": (_i64, [_i64, _i64]),
     "vae_nbzinb_bwd": (_i32, [_i32, _ptr, _i64, _ptr, _i64, _ptr, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _f32, _i64, _i64,
                               _ptr, _i64, _ptr, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _i64, _ptr]),
@@ -68,7 +72,8 @@ class StepConfig(C.Structure):
     """vae_step_config of include/vae_amd.h"""
     _fields_ = [("B", _i64), ("G", _i64), ("H", _i64), ("Hl", _i64), ("L", _i64), ("Hd", _i64),
                 ("n_layers", C.c_int32), ("zinb", C.c_int32), ("precision", C.c_int32),
-                ("l_mean", _f32), ("l_var", _f32), ("kl_weight", _f32), ("gene_loss_coeff", _f32), ("loss_scale", _f32)]
+                ("l_mean", _f32), ("l_var", _f32), ("kl_weight", _f32), ("gene_loss_coeff", _f32), ("loss_scale", _f32),
+                ("x_dtype", C.c_int32)]
 
 
 class StepTensors(C.Structure):

@@ -204,9 +204,25 @@ __device__ __forceinline__ float4 ld4(const float* __restrict__ row, int i, int 
   return v;
 }
 
-template <bool ZINB, bool VEC, int EPT, int THREADS>
+// counts stored as uint8 (the reference's on-disk format, create_dataset.py:131-142): 4 B per lane
+template <bool VEC>
+__device__ __forceinline__ float4 ld4(const uint8_t* __restrict__ row, int i, int G, float fill) {
+  if (VEC) {
+    const uchar4 u = reinterpret_cast<const uchar4*>(row)[i];
+    return make_float4((float)u.x, (float)u.y, (float)u.z, (float)u.w);
+  }
+  float4 v;
+  const int g = 4 * i;
+  v.x = g < G ? (float)row[g] : fill;
+  v.y = g + 1 < G ? (float)row[g + 1] : fill;
+  v.z = g + 2 < G ? (float)row[g + 2] : fill;
+  v.w = g + 3 < G ? (float)row[g + 3] : fill;
+  return v;
+}
+
+template <bool ZINB, bool VEC, int EPT, int THREADS, typename XT>
 __global__ __launch_bounds__(THREADS, 4) void nbzinb_fwd_kernel(
-    const float* __restrict__ ls, int64_t ld_s, const float* __restrict__ lp, int64_t ld_p, const float* __restrict__ x,
+    const float* __restrict__ ls, int64_t ld_s, const float* __restrict__ lp, int64_t ld_p, const XT* __restrict__ x,
     int64_t ld_x, const float* __restrict__ library, const float* __restrict__ T, int G,
     float* __restrict__ ll_out, float* __restrict__ rowmax, float* __restrict__ rowsum, float* __restrict__ S_out) {
   extern __shared__ __attribute__((aligned(16))) float4 srow[];  // EPT*THREADS float4, then NW floats
@@ -215,7 +231,7 @@ __global__ __launch_bounds__(THREADS, 4) void nbzinb_fwd_kernel(
   const int b = blockIdx.x, tid = threadIdx.x;
   const float* r_s = ls + (int64_t)b * ld_s;
   const float* r_p = ZINB ? lp + (int64_t)b * ld_p : nullptr;
-  const float* r_x = x + (int64_t)b * ld_x;
+  const XT* r_x = x + (int64_t)b * ld_x;
   const int n4 = (G + 3) >> 2;
   const float NEG = -INFINITY;
   const float4 Z4 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -303,9 +319,9 @@ constexpr int BWD_MAX_ROWS = 64;  // cells per workgroup (per-cell constants sta
 
 struct RowIn { float4 l, p, x; };
 
-template <bool ZINB, bool VEC>
+template <bool ZINB, bool VEC, typename XT>
 __device__ __forceinline__ RowIn load_row(const float* ls, int64_t ld_s, const float* lp, int64_t ld_p,
-                                          const float* __restrict__ x, int64_t ld_x, int b, int g0, int G) {
+                                          const XT* __restrict__ x, int64_t ld_x, int b, int g0, int G) {
   RowIn r;
   r.l = ld4<VEC>(ls + (int64_t)b * ld_s, g0 >> 2, G, 0.f);
   r.x = ld4<VEC>(x + (int64_t)b * ld_x, g0 >> 2, G, 0.f);
@@ -313,9 +329,9 @@ __device__ __forceinline__ RowIn load_row(const float* ls, int64_t ld_s, const f
   return r;
 }
 
-template <bool ZINB, bool VEC, bool SLAB>
+template <bool ZINB, bool VEC, bool SLAB, typename XT>
 __global__ __launch_bounds__(256) void nbzinb_bwd_kernel(
-    const float* ls, int64_t ld_s, const float* lp, int64_t ld_p, const float* __restrict__ x, int64_t ld_x,
+    const float* ls, int64_t ld_s, const float* lp, int64_t ld_p, const XT* __restrict__ x, int64_t ld_x,
     const float* __restrict__ library, const float* __restrict__ T, const float* __restrict__ rowmax,
     const float* __restrict__ rowsum, const float* __restrict__ S, const float* __restrict__ g_ll, float g_scalar, int B,
     int G, int rows_per_block, float* dls, int64_t ld_ds, float* dlp, int64_t ld_dp, float* __restrict__ dlibrary,
@@ -346,9 +362,9 @@ __global__ __launch_bounds__(256) void nbzinb_bwd_kernel(
   //   stage A (cell b+2): HBM loads of (logit_scale, logit_dropout, x)
   //   stage B (cell b+1): x has landed -> issue the count-indexed table loads (L2)
   //   stage C (cell b)  : evaluate, store both gradients (they alias the logits of cell b only)
-  RowIn c0 = load_row<ZINB, VEC>(ls, ld_s, lp, ld_p, x, ld_x, b0, g0, G);
+  RowIn c0 = load_row<ZINB, VEC, XT>(ls, ld_s, lp, ld_p, x, ld_x, b0, g0, G);
   RowIn c1 = c0;
-  if (b0 + 1 < b1) c1 = load_row<ZINB, VEC>(ls, ld_s, lp, ld_p, x, ld_x, b0 + 1, g0, G);
+  if (b0 + 1 < b1) c1 = load_row<ZINB, VEC, XT>(ls, ld_s, lp, ld_p, x, ld_x, b0 + 1, g0, G);
   float d0[4], d1[4] = {0.f, 0.f, 0.f, 0.f};
   {
     const float xv[4] = {c0.x.x, c0.x.y, c0.x.z, c0.x.w};
@@ -363,7 +379,7 @@ __global__ __launch_bounds__(256) void nbzinb_bwd_kernel(
       for (int j = 0; j < 4; ++j) d1[j] = Tg[j][(ROW_DGD + tab_index(xv[j])) * G];
     }
     RowIn c2 = c1;
-    if (b + 2 < b1) c2 = load_row<ZINB, VEC>(ls, ld_s, lp, ld_p, x, ld_x, b + 2, g0, G);
+    if (b + 2 < b1) c2 = load_row<ZINB, VEC, XT>(ls, ld_s, lp, ld_p, x, ld_x, b + 2, g0, G);
     const float4 k = rc[b - b0];
     const float l4[4] = {c0.l.x, c0.l.y, c0.l.z, c0.l.w};
     const float p4[4] = {c0.p.x, c0.p.y, c0.p.z, c0.p.w};
@@ -440,12 +456,12 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict_
   o[g] = overwrite ? s : o[g] + s;
 }
 
-template <bool ZINB, bool VEC, int EPT, int THREADS>
-void launch_fwd(const float* ls, int64_t ld_s, const float* lp, int64_t ld_p, const float* x, int64_t ld_x,
+template <bool ZINB, bool VEC, int EPT, int THREADS, typename XT>
+void launch_fwd(const float* ls, int64_t ld_s, const float* lp, int64_t ld_p, const XT* x, int64_t ld_x,
                 const float* library, const float* T, int B, int G, float* ll, float* rowmax, float* rowsum, float* S,
                 hipStream_t st, hipError_t* err) {
   const size_t shmem = (size_t)EPT * THREADS * sizeof(float4) + 64;
-  auto kern = nbzinb_fwd_kernel<ZINB, VEC, EPT, THREADS>;
+  auto kern = nbzinb_fwd_kernel<ZINB, VEC, EPT, THREADS, XT>;
   *err = hipSuccess;
   if (shmem > 64 * 1024)
     *err = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
@@ -454,11 +470,11 @@ void launch_fwd(const float* ls, int64_t ld_s, const float* lp, int64_t ld_p, co
                      rowsum, S);
 }
 
-template <bool ZINB, bool VEC>
-void dispatch_fwd(const float* ls, int64_t ld_s, const float* lp, int64_t ld_p, const float* x, int64_t ld_x,
+template <bool ZINB, bool VEC, typename XT>
+void dispatch_fwd(const float* ls, int64_t ld_s, const float* lp, int64_t ld_p, const XT* x, int64_t ld_x,
                   const float* library, const float* T, int B, int G, float* ll, float* rowmax, float* rowsum, float* S,
                   hipStream_t st, hipError_t* err) {
-#define FWD_CASE(E, TH) launch_fwd<ZINB, VEC, E, TH>(ls, ld_s, lp, ld_p, x, ld_x, library, T, B, G, ll, rowmax, rowsum, S, st, err)
+#define FWD_CASE(E, TH) launch_fwd<ZINB, VEC, E, TH, XT>(ls, ld_s, lp, ld_p, x, ld_x, library, T, B, G, ll, rowmax, rowsum, S, st, err)
   // (EPT, THREADS): 4*EPT*THREADS >= G; 512 threads while two workgroups fit a CU's LDS, else 1024
   if (G <= 1024) FWD_CASE(1, 256);
   else if (G <= 2048) FWD_CASE(1, 512);
@@ -487,26 +503,46 @@ extern "C" int vae_gene_table(const float* px_r, int64_t G, float* table, void* 
 
 extern "C" int64_t vae_nbzinb_max_genes(void) { return 10 * 1024 * 4; }
 
-extern "C" int vae_nbzinb_fwd(int zinb, const float* logit_scale, int64_t ld_s, const float* logit_dropout, int64_t ld_p,
-                              const float* x, int64_t ld_x, const float* library, const float* gene_table, int64_t B,
-                              int64_t G, float* ll, float* rowmax, float* rowsum, float* S, void* stream) {
+template <typename XT>
+static int nbzinb_fwd_impl(int zinb, const float* logit_scale, int64_t ld_s, const float* logit_dropout, int64_t ld_p,
+                           const XT* x, int64_t ld_x, const float* library, const float* gene_table, int64_t B, int64_t G,
+                           float* ll, float* rowmax, float* rowsum, float* S, void* stream) {
+  constexpr bool U8 = sizeof(XT) == 1;
   VAE_REQUIRE(logit_scale && x && library && gene_table && ll && rowmax && rowsum && S, "vae_nbzinb_fwd: null pointer");
   VAE_REQUIRE(!zinb || logit_dropout, "vae_nbzinb_fwd: ZINB needs logit_dropout");
   VAE_REQUIRE(B > 0 && G > 0 && G <= vae_nbzinb_max_genes(), "vae_nbzinb_fwd: G=%lld outside [1, %lld]", (long long)G,
               (long long)vae_nbzinb_max_genes());
   VAE_REQUIRE(ld_s >= G && ld_x >= G && (!zinb || ld_p >= G), "vae_nbzinb_fwd: leading dimension too small");
+  const bool x_ok = U8 ? ((reinterpret_cast<uintptr_t>(x) & 3u) == 0) : vae_aligned16(x);
   const int vec = (G % 4 == 0) && (ld_s % 4 == 0) && (ld_x % 4 == 0) && (!zinb || ld_p % 4 == 0) &&
-                  vae_aligned16(logit_scale) && vae_aligned16(x) && (!zinb || vae_aligned16(logit_dropout)) &&
+                  vae_aligned16(logit_scale) && x_ok && (!zinb || vae_aligned16(logit_dropout)) &&
                   vae_aligned16(gene_table);
+  VAE_REQUIRE(!U8 || vec, "vae_nbzinb_fwd_u8: needs G %% 4 == 0, leading dimensions %% 4 == 0 and aligned rows");
   hipStream_t st = (hipStream_t)stream;
   hipError_t err = hipSuccess;
-#define DISPATCH(Z, V, LP, LDP) dispatch_fwd<Z, V>(logit_scale, ld_s, LP, LDP, x, ld_x, library, gene_table, (int)B, (int)G, ll, rowmax, rowsum, S, st, &err)
-  if (zinb) { if (vec) DISPATCH(true, true, logit_dropout, ld_p); else DISPATCH(true, false, logit_dropout, ld_p); }
-  else      { if (vec) DISPATCH(false, true, nullptr, 0); else DISPATCH(false, false, nullptr, 0); }
+#define DISPATCH(Z, V, LP, LDP) dispatch_fwd<Z, V, XT>(logit_scale, ld_s, LP, LDP, x, ld_x, library, gene_table, (int)B, (int)G, ll, rowmax, rowsum, S, st, &err)
+  if (U8) {  // uint8 counts: vector path only
+    if (zinb) DISPATCH(true, true, logit_dropout, ld_p); else DISPATCH(false, true, nullptr, 0);
+  } else if (zinb) { if (vec) DISPATCH(true, true, logit_dropout, ld_p); else DISPATCH(true, false, logit_dropout, ld_p); }
+  else             { if (vec) DISPATCH(false, true, nullptr, 0); else DISPATCH(false, false, nullptr, 0); }
 #undef DISPATCH
   if (err != hipSuccess) return vae_set_error(VAE_ERR_LAUNCH, "vae_nbzinb_fwd: cannot raise LDS limit: %s", hipGetErrorString(err));
   VAE_CHECK_LAUNCH("vae_nbzinb_fwd");
   return VAE_OK;
+}
+
+extern "C" int vae_nbzinb_fwd(int zinb, const float* logit_scale, int64_t ld_s, const float* logit_dropout, int64_t ld_p,
+                              const float* x, int64_t ld_x, const float* library, const float* gene_table, int64_t B,
+                              int64_t G, float* ll, float* rowmax, float* rowsum, float* S, void* stream) {
+  return nbzinb_fwd_impl<float>(zinb, logit_scale, ld_s, logit_dropout, ld_p, x, ld_x, library, gene_table, B, G, ll, rowmax,
+                                rowsum, S, stream);
+}
+
+extern "C" int vae_nbzinb_fwd_u8(int zinb, const float* logit_scale, int64_t ld_s, const float* logit_dropout, int64_t ld_p,
+                                 const uint8_t* x, int64_t ld_x, const float* library, const float* gene_table, int64_t B,
+                                 int64_t G, float* ll, float* rowmax, float* rowsum, float* S, void* stream) {
+  return nbzinb_fwd_impl<uint8_t>(zinb, logit_scale, ld_s, logit_dropout, ld_p, x, ld_x, library, gene_table, B, G, ll,
+                                  rowmax, rowsum, S, stream);
 }
 
 namespace {
@@ -528,8 +564,9 @@ extern "C" int64_t vae_nbzinb_bwd_workspace_bytes(int64_t B, int64_t G) {
   return (int64_t)chunks * 3 * G * (int64_t)sizeof(float);
 }
 
+template <typename XT>
 static int nbzinb_bwd_impl(int zinb, const float* logit_scale, int64_t ld_s, const float* logit_dropout, int64_t ld_p,
-                           const float* x, int64_t ld_x, const float* library, const float* gene_table,
+                           const XT* x, int64_t ld_x, const float* library, const float* gene_table,
                            const float* rowmax, const float* rowsum, const float* S, const float* g_ll,
                            float g_scalar, int64_t B, int64_t G, float* dlogit_scale, int64_t ld_ds,
                            float* dlogit_dropout, int64_t ld_dp, float* dlibrary, float* dpx_r, float* dbias_scale,
@@ -541,8 +578,10 @@ static int nbzinb_bwd_impl(int zinb, const float* logit_scale, int64_t ld_s, con
   VAE_REQUIRE(B > 0 && G > 0, "vae_nbzinb_bwd: bad shape");
   VAE_REQUIRE(ld_s >= G && ld_x >= G && ld_ds >= G && (!zinb || (ld_p >= G && ld_dp >= G)),
               "vae_nbzinb_bwd: leading dimension too small");
+  constexpr bool U8 = sizeof(XT) == 1;
+  const bool x_ok = U8 ? ((reinterpret_cast<uintptr_t>(x) & 3u) == 0) : vae_aligned16(x);
   const bool vec = (G % 4 == 0) && (ld_s % 4 == 0) && (ld_x % 4 == 0) && (ld_ds % 4 == 0) &&
-                   (!zinb || (ld_p % 4 == 0 && ld_dp % 4 == 0)) && vae_aligned16(logit_scale) && vae_aligned16(x) &&
+                   (!zinb || (ld_p % 4 == 0 && ld_dp % 4 == 0)) && vae_aligned16(logit_scale) && x_ok &&
                    vae_aligned16(dlogit_scale) && (!zinb || (vae_aligned16(logit_dropout) && vae_aligned16(dlogit_dropout)));
   int strips, chunks, rows_per_block;
   bwd_grid(B, G, &strips, &chunks, &rows_per_block);
@@ -552,12 +591,14 @@ static int nbzinb_bwd_impl(int zinb, const float* logit_scale, int64_t ld_s, con
   dim3 grid(strips, chunks);
   hipStream_t st = (hipStream_t)stream;
 #define LAUNCH_BWD(Z, V, S_)                                                                                          \
-  hipLaunchKernelGGL((nbzinb_bwd_kernel<Z, V, S_>), grid, dim3(256), 0, st, logit_scale, ld_s, logit_dropout, ld_p, x,  \
+  hipLaunchKernelGGL((nbzinb_bwd_kernel<Z, V, S_, XT>), grid, dim3(256), 0, st, logit_scale, ld_s, logit_dropout, ld_p, x,  \
                      ld_x, library, gene_table, rowmax, rowsum, S, g_ll, g_scalar, (int)B, (int)G, rows_per_block,    \
                      dlogit_scale, ld_ds, dlogit_dropout, ld_dp, dlibrary, dpx_r, dbias_scale, dbias_dropout, workspace)
 #define LAUNCH_BWD2(Z, V) do { if (slab) LAUNCH_BWD(Z, V, true); else LAUNCH_BWD(Z, V, false); } while (0)
-  if (zinb) { if (vec) LAUNCH_BWD2(true, true); else LAUNCH_BWD2(true, false); }
-  else      { if (vec) LAUNCH_BWD2(false, true); else LAUNCH_BWD2(false, false); }
+  VAE_REQUIRE(!U8 || vec, "vae_nbzinb_bwd_u8: needs G %% 4 == 0, leading dimensions %% 4 == 0 and aligned rows");
+  if (U8) { if (zinb) LAUNCH_BWD2(true, true); else LAUNCH_BWD2(false, true); }
+  else if (zinb) { if (vec) LAUNCH_BWD2(true, true); else LAUNCH_BWD2(true, false); }
+  else           { if (vec) LAUNCH_BWD2(false, true); else LAUNCH_BWD2(false, false); }
 #undef LAUNCH_BWD2
 #undef LAUNCH_BWD
   VAE_CHECK_LAUNCH("vae_nbzinb_bwd");
@@ -575,7 +616,7 @@ extern "C" int vae_nbzinb_bwd(int zinb, const float* logit_scale, int64_t ld_s, 
                               float g_scalar, int64_t B, int64_t G, float* dlogit_scale, int64_t ld_ds,
                               float* dlogit_dropout, int64_t ld_dp, float* dlibrary, float* dpx_r, float* dbias_scale,
                               float* dbias_dropout, float* workspace, int64_t workspace_bytes, void* stream) {
-  return nbzinb_bwd_impl(zinb, logit_scale, ld_s, logit_dropout, ld_p, x, ld_x, library, gene_table, rowmax, rowsum, S, g_ll,
+  return nbzinb_bwd_impl<float>(zinb, logit_scale, ld_s, logit_dropout, ld_p, x, ld_x, library, gene_table, rowmax, rowsum, S, g_ll,
                          g_scalar, B, G, dlogit_scale, ld_ds, dlogit_dropout, ld_dp, dlibrary, dpx_r, dbias_scale,
                          dbias_dropout, workspace, workspace_bytes, stream, 0);
 }
@@ -587,7 +628,19 @@ extern "C" int vae_nbzinb_bwd_overwrite(int zinb, const float* logit_scale, int6
                                         int64_t ld_ds, float* dlogit_dropout, int64_t ld_dp, float* dlibrary, float* dpx_r,
                                         float* dbias_scale, float* dbias_dropout, float* workspace,
                                         int64_t workspace_bytes, void* stream) {
-  return nbzinb_bwd_impl(zinb, logit_scale, ld_s, logit_dropout, ld_p, x, ld_x, library, gene_table, rowmax, rowsum, S, g_ll,
+  return nbzinb_bwd_impl<float>(zinb, logit_scale, ld_s, logit_dropout, ld_p, x, ld_x, library, gene_table, rowmax, rowsum, S, g_ll,
                          g_scalar, B, G, dlogit_scale, ld_ds, dlogit_dropout, ld_dp, dlibrary, dpx_r, dbias_scale,
                          dbias_dropout, workspace, workspace_bytes, stream, 1);
+}
+
+/* uint8 counts; overwrite != 0 as vae_nbzinb_bwd_overwrite */
+extern "C" int vae_nbzinb_bwd_u8(int zinb, const float* logit_scale, int64_t ld_s, const float* logit_dropout, int64_t ld_p,
+                                 const uint8_t* x, int64_t ld_x, const float* library, const float* gene_table,
+                                 const float* rowmax, const float* rowsum, const float* S, const float* g_ll, float g_scalar,
+                                 int64_t B, int64_t G, float* dlogit_scale, int64_t ld_ds, float* dlogit_dropout,
+                                 int64_t ld_dp, float* dlibrary, float* dpx_r, float* dbias_scale, float* dbias_dropout,
+                                 float* workspace, int64_t workspace_bytes, int overwrite, void* stream) {
+  return nbzinb_bwd_impl<uint8_t>(zinb, logit_scale, ld_s, logit_dropout, ld_p, x, ld_x, library, gene_table, rowmax, rowsum, S,
+                                  g_ll, g_scalar, B, G, dlogit_scale, ld_ds, dlogit_dropout, ld_dp, dlibrary, dpx_r,
+                                  dbias_scale, dbias_dropout, workspace, workspace_bytes, stream, overwrite);
 }

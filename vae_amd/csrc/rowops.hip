@@ -41,16 +41,23 @@ __global__ __launch_bounds__(256) void row_mean_kernel(const float* __restrict__
 // Row mean AND the normalised counts xn = x / mean - 1 (Encoder.forward, modules.py:264) in one
 // launch: the row is summed from HBM, then re-read (L2-resident: one row is G*4 bytes) and written
 // normalised.  The encoder GEMMs (forward and wgrad) then stream xn with plain LDS-DMA loads.
-// REG: the whole row (G <= 256*4*EPT, 16-byte aligned) is held in registers: one HBM pass with
-// every load of the row in flight.
-template <bool REG>
-__global__ __launch_bounds__(256) void normalize_rows_kernel(const float* __restrict__ x, int64_t ld, int B, int G,
+// REG: the whole row (G <= 256*4*EPT, vector-aligned) is held in registers: one HBM pass with
+// every load of the row in flight.  XT = float, or uint8_t for counts kept in the reference's
+// on-disk format (create_dataset.py:131-142): the expansion to fp32 happens here.
+__device__ __forceinline__ float4 load4(const float* row, int i) { return reinterpret_cast<const float4*>(row)[i]; }
+__device__ __forceinline__ float4 load4(const uint8_t* row, int i) {
+  const uchar4 u = reinterpret_cast<const uchar4*>(row)[i];
+  return make_float4((float)u.x, (float)u.y, (float)u.z, (float)u.w);
+}
+
+template <bool REG, typename XT>
+__global__ __launch_bounds__(256) void normalize_rows_kernel(const XT* __restrict__ x, int64_t ld, int B, int G,
                                                              int vec, float* __restrict__ mean,
                                                              float* __restrict__ xn, int64_t ld_xn) {
   constexpr int EPT = 20;
   __shared__ float red[4];
   const int b = blockIdx.x;
-  const float* row = x + (int64_t)b * ld;
+  const XT* row = x + (int64_t)b * ld;
   float* orow = xn + (int64_t)b * ld_xn;
   if (REG) {
     const int n4 = G >> 2;
@@ -59,11 +66,11 @@ __global__ __launch_bounds__(256) void normalize_rows_kernel(const float* __rest
 #pragma unroll
     for (int j = 0; j < EPT; ++j) {
       const int i = threadIdx.x + 256 * j;
-      v[j] = i < n4 ? reinterpret_cast<const float4*>(row)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+      v[j] = i < n4 ? load4(row, i) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 #pragma unroll
     for (int j = 0; j < EPT; ++j) s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
-    for (int i = (n4 << 2) + threadIdx.x; i < G; i += 256) s += row[i];
+    for (int i = (n4 << 2) + threadIdx.x; i < G; i += 256) s += (float)row[i];
     s = block_sum<4>(s, red);
     const float m = s / (float)G;
     if (threadIdx.x == 0) mean[b] = m;
@@ -76,25 +83,25 @@ __global__ __launch_bounds__(256) void normalize_rows_kernel(const float* __rest
         reinterpret_cast<float4*>(orow)[i] = o;
       }
     }
-    for (int i = (n4 << 2) + threadIdx.x; i < G; i += 256) orow[i] = row[i] / m - 1.f;
+    for (int i = (n4 << 2) + threadIdx.x; i < G; i += 256) orow[i] = (float)row[i] / m - 1.f;
     return;
   }
   float s = 0.f;
   const int n4 = vec ? (G >> 2) : 0;
   for (int i = threadIdx.x; i < n4; i += 256) {
-    const float4 v = reinterpret_cast<const float4*>(row)[i];
+    const float4 v = load4(row, i);
     s += (v.x + v.y) + (v.z + v.w);
   }
-  for (int i = (n4 << 2) + threadIdx.x; i < G; i += 256) s += row[i];
+  for (int i = (n4 << 2) + threadIdx.x; i < G; i += 256) s += (float)row[i];
   s = block_sum<4>(s, red);
   const float m = s / (float)G;
   if (threadIdx.x == 0) mean[b] = m;
   for (int i = threadIdx.x; i < n4; i += 256) {
-    float4 v = reinterpret_cast<const float4*>(row)[i];
+    float4 v = load4(row, i);
     v.x = v.x / m - 1.f; v.y = v.y / m - 1.f; v.z = v.z / m - 1.f; v.w = v.w / m - 1.f;
     reinterpret_cast<float4*>(orow)[i] = v;
   }
-  for (int i = (n4 << 2) + threadIdx.x; i < G; i += 256) orow[i] = row[i] / m - 1.f;
+  for (int i = (n4 << 2) + threadIdx.x; i < G; i += 256) orow[i] = (float)row[i] / m - 1.f;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -361,18 +368,30 @@ extern "C" int vae_row_mean(const float* x, int64_t ldx, int64_t B, int64_t G, f
   return VAE_OK;
 }
 
-extern "C" int vae_normalize_rows(const float* x, int64_t ldx, int64_t B, int64_t G, float* mean, float* xn,
-                                  int64_t ld_xn, void* stream) {
+template <typename XT>
+static int normalize_rows_impl(const XT* x, int64_t ldx, int64_t B, int64_t G, float* mean, float* xn, int64_t ld_xn,
+                               void* stream) {
   VAE_REQUIRE(x && mean && xn && B > 0 && G > 0 && ldx >= G && ld_xn >= G, "vae_normalize_rows: bad arguments");
-  const int vec = (ldx % 4 == 0) && (ld_xn % 4 == 0) && vae_aligned16(x) && vae_aligned16(xn);
+  const bool x_ok = sizeof(XT) == 1 ? ((reinterpret_cast<uintptr_t>(x) & 3u) == 0) : vae_aligned16(x);
+  const int vec = (ldx % 4 == 0) && (ld_xn % 4 == 0) && x_ok && vae_aligned16(xn);
   if (vec && G <= 256 * 4 * 20)
-    hipLaunchKernelGGL(normalize_rows_kernel<true>, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, x, ldx, (int)B,
-                       (int)G, vec, mean, xn, ld_xn);
+    hipLaunchKernelGGL((normalize_rows_kernel<true, XT>), dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, x, ldx,
+                       (int)B, (int)G, vec, mean, xn, ld_xn);
   else
-    hipLaunchKernelGGL(normalize_rows_kernel<false>, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, x, ldx, (int)B,
-                       (int)G, vec, mean, xn, ld_xn);
+    hipLaunchKernelGGL((normalize_rows_kernel<false, XT>), dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, x, ldx,
+                       (int)B, (int)G, vec, mean, xn, ld_xn);
   VAE_CHECK_LAUNCH("vae_normalize_rows");
   return VAE_OK;
+}
+
+extern "C" int vae_normalize_rows(const float* x, int64_t ldx, int64_t B, int64_t G, float* mean, float* xn,
+                                  int64_t ld_xn, void* stream) {
+  return normalize_rows_impl<float>(x, ldx, B, G, mean, xn, ld_xn, stream);
+}
+
+extern "C" int vae_normalize_rows_u8(const uint8_t* x, int64_t ldx, int64_t B, int64_t G, float* mean, float* xn,
+                                     int64_t ld_xn, void* stream) {
+  return normalize_rows_impl<uint8_t>(x, ldx, B, G, mean, xn, ld_xn, stream);
 }
 
 extern "C" int vae_gelu_ln_fwd(const float* pre, int64_t ld_pre, const float* gamma, const float* beta, int64_t B,

@@ -93,11 +93,12 @@ struct Ctx {
   }
 };
 
-int check_common(const vae_step_config* cfg, const void* a, const void* b, const float* x, int64_t ldx,
+int check_common(const vae_step_config* cfg, const void* a, const void* b, const void* x, int64_t ldx,
                  const float* eps_z, const float* eps_l, float* ws, int64_t ws_bytes, Layout* lo, const char* who) {
   if (!cfg || !a || !b || !x || !eps_z || !eps_l || !ws) return vae_set_error(VAE_ERR_ARG, "%s: null pointer", who);
   if (!make_layout(*cfg, lo)) return vae_set_error(VAE_ERR_ARG, "%s: bad configuration", who);
   if (ldx < cfg->G) return vae_set_error(VAE_ERR_ARG, "%s: ldx < G", who);
+  if (cfg->x_dtype != VAE_X_F32 && cfg->x_dtype != VAE_X_U8) return vae_set_error(VAE_ERR_ARG, "%s: bad x_dtype", who);
   if (cfg->G > vae_nbzinb_max_genes())
     return vae_set_error(VAE_ERR_ARG, "%s: G=%lld exceeds %lld", who, (long long)cfg->G, (long long)vae_nbzinb_max_genes());
   if (!(cfg->l_var > 0.f)) return vae_set_error(VAE_ERR_ARG, "%s: l_var must be positive", who);
@@ -136,17 +137,21 @@ extern "C" int64_t vae_elbo_step_ws_offset(const vae_step_config* cfg, int slice
   }
 }
 
-extern "C" int vae_elbo_step_forward(const vae_step_config* cfg, const vae_step_tensors* p, const float* x, int64_t ldx,
+extern "C" int vae_elbo_step_forward(const vae_step_config* cfg, const vae_step_tensors* p, const void* xv, int64_t ldx,
                                      const float* eps_z, const float* eps_l, float* ws, int64_t ws_bytes, void* stream) {
   Layout lo;
-  TRY(check_common(cfg, p, p, x, ldx, eps_z, eps_l, ws, ws_bytes, &lo, "vae_elbo_step_forward"));
+  TRY(check_common(cfg, p, p, xv, ldx, eps_z, eps_l, ws, ws_bytes, &lo, "vae_elbo_step_forward"));
+  const bool u8 = cfg->x_dtype == VAE_X_U8;
+  const float* x = (const float*)xv;
+  const uint8_t* x8 = (const uint8_t*)xv;
   const vae_step_config& c = *cfg;
   const Ctx k{c, ws, lo, stream};
   const int64_t B = c.B, G = c.G, H = c.H, Hl = c.Hl, L = c.L, Hd = c.Hd, HE = c.H + c.Hl;
   const int64_t NH = c.zinb ? 2 * G : G;
 
   // encoders: x/mean-1 -> Linear(G, H+Hl) -> GELU -> LayerNorm (z and library halves)
-  TRY(vae_normalize_rows(x, ldx, B, G, ws + lo.mean, ws + lo.xn, lo.ld_xn, stream));
+  if (u8) TRY(vae_normalize_rows_u8(x8, ldx, B, G, ws + lo.mean, ws + lo.xn, lo.ld_xn, stream));
+  else TRY(vae_normalize_rows(x, ldx, B, G, ws + lo.mean, ws + lo.xn, lo.ld_xn, stream));
   const float* px;
   if (vae_mid_supported(c)) {
     // one launch from the encoder slabs to the decoder hidden layer
@@ -193,7 +198,9 @@ extern "C" int vae_elbo_step_forward(const vae_step_config* cfg, const vae_step_
   // decoder heads -> fused softmax / library scale / NB-ZINB / row sum -> ELBO scalars
   TRY(k.gemm(VAE_NT, B, NH, Hd, px, Hd, p->heads_w, Hd, ws + lo.logits, NH, p->heads_b, nullptr, 0));
   TRY(vae_gene_table(p->px_r, G, ws + lo.table, stream));
-  TRY(vae_nbzinb_fwd(c.zinb, ws + lo.logits, NH, c.zinb ? ws + lo.logits + G : nullptr, NH, x, ldx, ws + lo.library,
+  if (u8) TRY(vae_nbzinb_fwd_u8(c.zinb, ws + lo.logits, NH, c.zinb ? ws + lo.logits + G : nullptr, NH, x8, ldx, ws + lo.library,
+                     ws + lo.table, B, G, ws + lo.ll, ws + lo.rowmax, ws + lo.rowsum, ws + lo.S, stream));
+  else TRY(vae_nbzinb_fwd(c.zinb, ws + lo.logits, NH, c.zinb ? ws + lo.logits + G : nullptr, NH, x, ldx, ws + lo.library,
                      ws + lo.table, B, G, ws + lo.ll, ws + lo.rowmax, ws + lo.rowsum, ws + lo.S, stream));
   TRY(vae_elbo_reduce(ws + lo.ll, ws + lo.kl_z, ws + lo.kl_l, B, c.kl_weight, c.gene_loss_coeff, ws + lo.scalars,
                       ws + lo.recon, stream));
@@ -201,11 +208,14 @@ extern "C" int vae_elbo_step_forward(const vae_step_config* cfg, const vae_step_
 }
 
 extern "C" int vae_elbo_step_backward(const vae_step_config* cfg, const vae_step_tensors* p, const vae_step_tensors* g,
-                                      const float* x, int64_t ldx, const float* eps_z, const float* eps_l,
+                                      const void* xv, int64_t ldx, const float* eps_z, const float* eps_l,
                                       int use_dz_extra, float* ws, int64_t ws_bytes, void* event_heads_ready,
                                       void* stream) {
   Layout lo;
-  TRY(check_common(cfg, p, g, x, ldx, eps_z, eps_l, ws, ws_bytes, &lo, "vae_elbo_step_backward"));
+  TRY(check_common(cfg, p, g, xv, ldx, eps_z, eps_l, ws, ws_bytes, &lo, "vae_elbo_step_backward"));
+  const bool u8 = cfg->x_dtype == VAE_X_U8;
+  const float* x = (const float*)xv;
+  const uint8_t* x8 = (const uint8_t*)xv;
   const vae_step_config& c = *cfg;
   const Ctx k{c, ws, lo, stream};
   const int64_t B = c.B, G = c.G, H = c.H, Hl = c.Hl, L = c.L, Hd = c.Hd, HE = c.H + c.Hl;
@@ -217,7 +227,10 @@ extern "C" int vae_elbo_step_backward(const vae_step_config* cfg, const vae_step
   float* lp = c.zinb ? logits + G : nullptr;
 
   // epilogue backward: logits := dlogits (in place); d px_r and the head-bias gradients are overwritten
-  TRY(vae_nbzinb_bwd_overwrite(c.zinb, logits, NH, lp, NH, x, ldx, ws + lo.library, ws + lo.table, ws + lo.rowmax, ws + lo.rowsum,
+  if (u8) TRY(vae_nbzinb_bwd_u8(c.zinb, logits, NH, lp, NH, x8, ldx, ws + lo.library, ws + lo.table, ws + lo.rowmax, ws + lo.rowsum,
+                     ws + lo.S, nullptr, g_ll, B, G, logits, NH, lp, NH, ws + lo.dlibrary, g->px_r, g->heads_b,
+                     c.zinb ? g->heads_b + G : nullptr, ws + lo.scratch, lo.scratch_floats * 4, 1, stream));
+  else TRY(vae_nbzinb_bwd_overwrite(c.zinb, logits, NH, lp, NH, x, ldx, ws + lo.library, ws + lo.table, ws + lo.rowmax, ws + lo.rowsum,
                      ws + lo.S, nullptr, g_ll, B, G, logits, NH, lp, NH, ws + lo.dlibrary, g->px_r, g->heads_b,
                      c.zinb ? g->heads_b + G : nullptr, ws + lo.scratch, lo.scratch_floats * 4, stream));
   const float* px = ws + lo.dec_h[c.n_layers - 1];

@@ -36,6 +36,18 @@ def _chk2d(t: torch.Tensor, name: str) -> None:
         raise ValueError(f"vae_amd.ops: {name} must be 2-D with a contiguous last dim, got {tuple(t.shape)} / {t.stride()}")
 
 
+def _chk_counts(t: torch.Tensor, name: str = "x") -> bool:
+    """Counts may be float32 or uint8 (the reference's on-disk format); -> True for uint8."""
+    if t.dtype != torch.uint8:
+        _chk2d(t, name)
+        return False
+    if not t.is_cuda:
+        raise RuntimeError(f"vae_amd.ops: {name} must live on the GPU (no CPU fallback)")
+    if t.dim() != 2 or t.stride(1) != 1:
+        raise ValueError(f"vae_amd.ops: {name} must be 2-D with a contiguous last dim, got {tuple(t.shape)} / {t.stride()}")
+    return True
+
+
 def _chk1d(t: Optional[torch.Tensor], n: int, name: str) -> None:
     if t is None:
         return
@@ -130,10 +142,10 @@ def row_mean(x: torch.Tensor) -> torch.Tensor:
 def normalize_rows(x: torch.Tensor):
     """-> (mean (B,), xn = x / mean - 1 (B,G)): Encoder.forward's input normalisation (modules.py:264)."""
     lib = _lib.load()
-    _chk2d(x, "x")
+    u8 = _chk_counts(x)
     mean = torch.empty(x.shape[0], dtype=torch.float32, device=x.device)
     xn = torch.empty(x.shape, dtype=torch.float32, device=x.device)
-    _lib.check(lib.vae_normalize_rows(_p(x), _ld(x), x.shape[0], x.shape[1], _p(mean), _p(xn), _ld(xn), _stream()),
+    _lib.check((lib.vae_normalize_rows_u8 if u8 else lib.vae_normalize_rows)(_p(x), _ld(x), x.shape[0], x.shape[1], _p(mean), _p(xn), _ld(xn), _stream()),
                "normalize_rows")
     return mean, xn
 
@@ -251,7 +263,8 @@ def nbzinb_fwd(zinb: bool, logit_scale: torch.Tensor, logit_dropout: Optional[to
     -> (ll (B,), rowmax (B,), rowsum (B,), S (B,)); recon = -ll.  The last three are what
     ``nbzinb_bwd`` needs."""
     lib = _lib.load()
-    _chk2d(logit_scale, "logit_scale"); _chk2d(x, "x")
+    _chk2d(logit_scale, "logit_scale")
+    u8 = _chk_counts(x)
     B, G = x.shape
     if logit_scale.shape != (B, G):
         raise ValueError("vae_amd.ops.nbzinb_fwd: logit_scale shape mismatch")
@@ -263,7 +276,7 @@ def nbzinb_fwd(zinb: bool, logit_scale: torch.Tensor, logit_dropout: Optional[to
     if table.shape != (lib.vae_gene_table_rows(), G) or not table.is_contiguous():
         raise ValueError("vae_amd.ops.nbzinb_fwd: table must be the gene table made by ops.gene_table")
     o = torch.empty(4, B, dtype=torch.float32, device=x.device)
-    _lib.check(lib.vae_nbzinb_fwd(int(zinb), _p(logit_scale), _ld(logit_scale), _p(logit_dropout if zinb else None),
+    _lib.check((lib.vae_nbzinb_fwd_u8 if u8 else lib.vae_nbzinb_fwd)(int(zinb), _p(logit_scale), _ld(logit_scale), _p(logit_dropout if zinb else None),
                                   _ld(logit_dropout) if zinb else 0, _p(x), _ld(x), _p(library), _p(table), B, G,
                                   _p(o[0]), _p(o[1]), _p(o[2]), _p(o[3]), _stream()), "nbzinb_fwd")
     return o[0], o[1], o[2], o[3]
@@ -278,6 +291,9 @@ def nbzinb_bwd(zinb: bool, logit_scale: torch.Tensor, logit_dropout: Optional[to
     dpx_r / dbias_* are ACCUMULATED into: through per-chunk slabs summed in a fixed order
     (deterministic=True, default) or with float atomics."""
     lib = _lib.load()
+    u8 = _chk_counts(x)
+    if u8 and not deterministic:
+        raise ValueError("vae_amd.ops.nbzinb_bwd: uint8 counts use the deterministic (workspace) mode")
     B, G = x.shape
     if table.shape != (lib.vae_gene_table_rows(), G) or not table.is_contiguous():
         raise ValueError("vae_amd.ops.nbzinb_bwd: table must be the gene table made by ops.gene_table")
@@ -288,13 +304,13 @@ def nbzinb_bwd(zinb: bool, logit_scale: torch.Tensor, logit_dropout: Optional[to
     _chk1d(dbias_scale, G, "dbias_scale"); _chk1d(dbias_dropout, G, "dbias_dropout")
     nbytes = lib.vae_nbzinb_bwd_workspace_bytes(B, G) if deterministic else 0
     ws = workspace(nbytes, x.device) if deterministic else None
-    _lib.check(lib.vae_nbzinb_bwd(int(zinb), _p(logit_scale), _ld(logit_scale), _p(logit_dropout if zinb else None),
-                                  _ld(logit_dropout) if zinb else 0, _p(x), _ld(x), _p(library), _p(table), _p(rowmax),
-                                  _p(rowsum), _p(S), _p(g_ll), float(g_scalar), B, G, _p(dlogit_scale), _ld(dlogit_scale),
-                                  _p(dlogit_dropout if zinb else None), _ld(dlogit_dropout) if zinb else 0, _p(dlibrary),
-                                  _p(dpx_r), _p(dbias_scale), _p(dbias_dropout if zinb else None), _p(ws), nbytes,
-                                  _stream()),
-               "nbzinb_bwd")
+    args = (int(zinb), _p(logit_scale), _ld(logit_scale), _p(logit_dropout if zinb else None),
+            _ld(logit_dropout) if zinb else 0, _p(x), _ld(x), _p(library), _p(table), _p(rowmax),
+            _p(rowsum), _p(S), _p(g_ll), float(g_scalar), B, G, _p(dlogit_scale), _ld(dlogit_scale),
+            _p(dlogit_dropout if zinb else None), _ld(dlogit_dropout) if zinb else 0, _p(dlibrary),
+            _p(dpx_r), _p(dbias_scale), _p(dbias_dropout if zinb else None), _p(ws), nbytes)
+    rc = lib.vae_nbzinb_bwd_u8(*args, 0, _stream()) if u8 else lib.vae_nbzinb_bwd(*args, _stream())
+    _lib.check(rc, "nbzinb_bwd")
 
 
 def loglik_elem_fwd(zinb: bool, x, mu, theta, pi) -> torch.Tensor:

@@ -133,6 +133,7 @@ class ElboStep:
         cfg, ws, nbytes, v = self._plans[key]
         cfg.loss_scale = float(loss_scale)
         cfg.kl_weight = self.kl_weight
+        cfg.x_dtype = 0
         return cfg, ws, nbytes, v
 
     # ------------------------------------------------------------------------------------
@@ -143,8 +144,9 @@ class ElboStep:
         the next ``run`` with the same batch size (clone what must survive)."""
         a = self.a
         for t, name in ((x, "x"), (eps_z, "eps_z"), (eps_l, "eps_l")):
-            if not t.is_cuda or t.dtype != torch.float32 or t.dim() != 2 or t.stride(1) != 1:
-                raise ValueError(f"ElboStep: {name} must be a 2-D float32 GPU tensor with a contiguous last dim")
+            ok_dtype = t.dtype == torch.float32 or (name == "x" and t.dtype == torch.uint8)
+            if not t.is_cuda or not ok_dtype or t.dim() != 2 or t.stride(1) != 1:
+                raise ValueError(f"ElboStep: {name} must be a 2-D float32 (x: or uint8) GPU tensor with a contiguous last dim")
         B, G = x.shape
         L = self.L
         if G != self.G:
@@ -152,6 +154,7 @@ class ElboStep:
         if eps_z.shape != (B, L) or eps_l.shape != (B, 1) or not eps_z.is_contiguous() or not eps_l.is_contiguous():
             raise ValueError("ElboStep: eps_z must be contiguous (B, L) and eps_l (B, 1)")
         cfg, ws, nbytes, v = self._plan(B, loss_scale)
+        cfg.x_dtype = 1 if x.dtype == torch.uint8 else 0   # uint8 counts: the reference's on-disk format (f2)
         stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         ldx = x.stride(0) if B > 1 else G
         rc = self.lib.vae_elbo_step_forward(C.byref(cfg), C.byref(self.params), x.data_ptr(), ldx, eps_z.data_ptr(),
