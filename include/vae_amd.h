@@ -112,6 +112,10 @@ int vae_elbo_reduce(const float* ll, const float* kl_z, const float* kl_l, int64
  * softmax over genes (modules.py:362,401), px_rate = exp(library)*px_scale (:404),
  * theta = exp(px_r) (task.py:481-483), NB / ZINB log-likelihood (distributions.py:22-62, :65-90),
  * sum over genes (task.py:156-165) -- and its backward.                                           */
+/* px_rate[b,g] = exp(library[b]) * exp(l[b,g] - rowmax[b]) / rowsum[b]  (modules.py:401,404), with the
+ * rowmax / rowsum vae_nbzinb_fwd saved: exactly the mean the likelihood was evaluated at.              */
+int vae_px_rate(const float* logit_scale, int64_t ld_s, const float* library, const float* rowmax, const float* rowsum,
+                int64_t B, int64_t G, float* px_rate, int64_t ld_r, void* stream);
 int64_t vae_gene_table_rows(void);
 /* per-gene constants of the epilogue, (vae_gene_table_rows(), G); rebuild whenever px_r changes   */
 int vae_gene_table(const float* px_r, int64_t G, float* table, void* stream);
@@ -216,6 +220,11 @@ int64_t vae_elbo_step_ws_offset(const vae_step_config* cfg, int slice);
 int vae_elbo_step_forward(const vae_step_config* cfg, const vae_step_tensors* params, const void* x, int64_t ldx,
                           const float* eps_z, const float* eps_l, float* workspace, int64_t workspace_bytes,
                           void* stream);
+/* Inference / validation (LitVAE.validation_step, task.py:235-282) = vae_elbo_step_forward alone, then
+ * optionally the decoder mean px_rate = exp(library) * softmax(logits) (modules.py:404; exported at
+ * task.py:263) from the logits and row statistics the forward left in the workspace.                 */
+int vae_elbo_step_px_rate(const vae_step_config* cfg, const float* workspace, int64_t workspace_bytes, float* px_rate,
+                          int64_t ld_r, void* stream);
 /* grads: same layout as params; small tensors (biases, LayerNorm, px_r) are ACCUMULATED into, the
  * weight matrices are overwritten.  use_dz_extra != 0 adds workspace[VAE_WS_DZ_EXTRA] to dz.
  * event_heads_ready (nullable hipEvent_t) is recorded once the decoder-head weight gradient -- the

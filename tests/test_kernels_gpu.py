@@ -302,3 +302,23 @@ def test_normalize_rows_uint8_equals_float(ops):
     m_f, xn_f = ops.normalize_rows(x.cuda())
     m_u, xn_u = ops.normalize_rows(x.to(torch.uint8).cuda())
     assert torch.equal(m_f, m_u) and torch.equal(xn_f, xn_u)
+
+
+@pytest.mark.parametrize("G", [1003, 2048])
+def test_px_rate_from_saved_row_statistics(ops, G):
+    """px_rate = exp(library) * softmax(logits) (modules.py:401,404) from the rowmax / rowsum of nbzinb_fwd."""
+    B = 19
+    g = torch.Generator().manual_seed(31)
+    logits = (torch.randn(B, G, generator=g) * 3).cuda()
+    library = (torch.randn(B, generator=g) + 6).cuda()
+    x = torch.poisson(torch.rand(B, G, generator=g) * 2, generator=g).cuda()
+    table = ops.gene_table(torch.zeros(G, device="cuda"))
+    _, rowmax, rowsum, _ = ops.nbzinb_fwd(False, logits, None, x, library, table)
+    got = ops.px_rate(logits, library, rowmax, rowsum)
+    ref = torch.exp(library.double())[:, None] * torch.softmax(logits.double(), dim=-1)
+    assert rel_err(got.cpu().numpy(), ref.cpu().numpy()) < 2e-6
+    out = torch.full((B, G + 8), 7.0, device="cuda")[:, :G]        # strided destination, padding untouched
+    ops.px_rate(logits, library, rowmax, rowsum, out=out)
+    assert torch.equal(out, got)
+    with pytest.raises(ValueError):
+        ops.px_rate(logits, library[:-1], rowmax, rowsum)

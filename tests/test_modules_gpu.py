@@ -80,6 +80,39 @@ def test_fused_step_through_litvae(case):
     assert not torch.equal(before, arena.flat)
 
 
+@pytest.mark.parametrize("case", [E2E_CASES[1], E2E_CASES[4]], ids=lambda c: c["name"])
+def test_validation_step_module_and_fused_agree(case, monkeypatch):
+    """Row f3: LitVAE.validation_step (module API) and validation_step_fused (one native forward) log the
+    same validation losses, record the same per-cell results and match the reference's px_rate."""
+    import vae_amd.modules as M
+    gold = load_golden(f"e2e_{case['name']}.npz")
+    case, task, batch, eps_z, eps_l = build_task(case)
+    task.save_gene_vals = True
+    task.eval()
+    B = batch[0].shape[0]
+    batch = batch[:5] + (torch.arange(B), None, np.array(["s"] * B))
+    task.attach_arena("cuda")
+    queue = [eps_z, eps_l]
+    monkeypatch.setattr(M, "reparameterize_gaussian", lambda mu, var: mu + queue.pop(0) * var.sqrt())
+    task.validation_step(batch, 0)
+    logged_mod = dict(task.logged)
+    res_mod = task.on_validation_epoch_end()
+    task.validation_step_fused(batch, eps_z, eps_l)
+    res_fused = task.on_validation_epoch_end()
+    for k in ("recon_loss_val", "kl_z_val"):
+        assert abs(float(logged_mod[k]) - float(task.logged[k])) < TOL_CELL * abs(float(logged_mod[k])), k
+    assert abs(float(task.logged["recon_loss_val"]) - float(gold["f64/out/recon"].mean())) < TOL_CELL * abs(float(gold["f64/out/recon"].mean()))
+    for res in (res_mod, res_fused):
+        assert res["px_r"].shape == (B, case["G"]) and np.array_equal(res["cell_idx"], np.arange(B))
+        assert rel_err(res["px_r"], gold["f64/out/px_rate"]) < 2e-5
+    if case["use_cell_loss"]:
+        assert rel_err(res_fused["latent"], gold["f64/out/qz_m"]) < TOL_CELL
+        for k in case["cell_properties"]:
+            assert rel_err(res_fused["pred_" + k], res_mod["pred_" + k]) < 1e-5, k
+            assert np.array_equal(res_fused[k], res_mod[k])
+    assert task.results["px_r"] == [] and task.results["epoch"] == 1
+
+
 def test_module_forward_outputs():
     """DecoderSCVI / Encoder forward tensors (px_scale, px_rate, px_dropout, q_m, q_v) vs goldens."""
     import vae_amd.modules as M

@@ -85,6 +85,38 @@ def test_forward_only_leaves_grads_untouched():
     assert torch.isfinite(out["loss"])
 
 
+@pytest.mark.parametrize("case", ALL_CASES, ids=[c["name"] for c in ALL_CASES])
+def test_inference_step_matches_reference_goldens(case):
+    """Row f3: validation_step = the forward alone + px_rate export (task.py:235-282) vs the reference's
+    forward tensors; no gradient is touched."""
+    from vae_amd.arena import ParamArena
+    from vae_amd.step import ElboStep
+    gold = load_golden(f"e2e_{case['name']}.npz")
+    case = copy.deepcopy(case)
+    params, x, eps_z, eps_l, _, _ = build_case_inputs(case)
+    arena = ParamArena({k: v.float() for k, v in params.items()}, case["n_layers"], case["likelihood"], "cuda")
+    step = ElboStep(arena, l_mean=float(np.float32(case["l_mean"])), l_var=float(np.float32(case["l_var"])),
+                    kl_weight=case["kl_weight"], gene_loss_coeff=case["gene_loss_coeff"])
+    with pytest.raises(RuntimeError):
+        step.px_rate()                                   # nothing to export before a forward
+    out = step.infer(x.float().cuda(), eps_z.float().cuda(), eps_l.float().cuda(), want_px_rate=True)
+    torch.cuda.synchronize()
+    assert float(arena.flat_grad.abs().max()) == 0.0
+    G, stride = case["G"], case["sample_stride"]
+    g = gold["f64/out/px_rate"]
+    got = sample_like_golden(out["px_rate"], G, stride)
+    assert got.shape == g.shape
+    assert np.max(np.abs(got - g) / np.abs(g).max(axis=1, keepdims=True)) < TOL_CELL   # per cell, to its largest rate
+    assert rel_err(out["px_rate"].sum(-1).cpu().numpy(), np.exp(gold["f64/out/library"]).reshape(-1)) < TOL_CELL
+    for k in ("qz_m", "recon", "kl_z", "kl_l"):
+        gk = gold[f"f64/out/{k}"]
+        assert rel_err(out[k].cpu().numpy().reshape(gk.shape), gk) < TOL_CELL, k
+    # a training step afterwards invalidates the export (its backward overwrites the logits)
+    step.run(x.float().cuda(), eps_z.float().cuda(), eps_l.float().cuda())
+    with pytest.raises(RuntimeError):
+        step.px_rate()
+
+
 def test_bf16_mode_against_bf16_oracle():
     """bf16 GEMM operands / fp32 accumulate: same rounding points as the oracle's bf16 mode;
     stated tolerance 2e-3 on per-cell terms, 2e-2 on gradients (bf16 has 8 mantissa bits and the

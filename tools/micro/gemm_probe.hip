@@ -1,0 +1,56 @@
+// Cycle stamps of one workgroup of gemm_x3_kernel (decoder-head forward shape, cfg2).
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -DVAE_PROBE=600 tools/micro/gemm_probe.hip vae_amd/csrc/runtime.hip -o tools/micro/gemm_probe
+//   add -DVAE_ABL=<bits> to ablate: 1 = stage only once, 2 = fetch only once, 4 = no multiply
+//   ./gemm_probe [layout 0 (NT, decoder heads forward) | 1 (NN, decoder dgrad)]
+#include "../../vae_amd/csrc/gemm.hip"
+#include <stdio.h>
+#include <vector>
+
+template <int LAY>
+void run(GemmArgs g, int grid) {
+  hipEvent_t a, b;
+  hipEventCreate(&a); hipEventCreate(&b);
+  for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((gemm_x3_kernel<LAY, 128, 128, 2, 3>), dim3(grid), dim3(256), 0, 0, g);
+  hipEventRecord(a);
+  for (int i = 0; i < 10; ++i) hipLaunchKernelGGL((gemm_x3_kernel<LAY, 128, 128, 2, 3>), dim3(grid), dim3(256), 0, 0, g);
+  hipEventRecord(b);
+  hipDeviceSynchronize();
+  float ms; hipEventElapsedTime(&ms, a, b);
+  printf("kernel %.1f us (grid %d)\n", ms * 100, grid);
+}
+
+int main(int argc, char** argv) {
+  const int lay = argc > 1 ? atoi(argv[1]) : 0;
+  const int M = 512, N = 40000, K = 256;   // NT: A (M,K), B (N,K)
+  const size_t na = (size_t)M * K, nb = (size_t)N * K;
+  float *A, *B, *C;
+  hipMalloc(&A, na * 4); hipMalloc(&B, nb * 4); hipMalloc(&C, (size_t)M * N * 4);
+  hipMemset(A, 0, na * 4); hipMemset(B, 0, nb * 4);
+  GemmArgs g{};
+  g.A = A; g.B = B; g.C = C; g.lda = K; g.ldb = K; g.ldc = N; g.M = M; g.N = N; g.K = K;
+  g.k_per_split = K; g.split = 1; g.vecA = g.vecB = 1; g.tiles_m = 4; g.tiles_n = (N + 127) / 128;
+  if (lay == 1) { /* NN dgrad: M=512, N=256, K=40000 (A (M,K), B (K,N)) split 8 */
+    g.lda = 40000; g.ldb = 256; g.ldc = 256; g.M = 512; g.N = 256; g.K = 40000;
+    g.tiles_m = 4; g.tiles_n = 2; g.split = 50; g.k_per_split = 800;
+    hipFree(A); hipFree(C); hipMalloc(&A, (size_t)512 * 40000 * 4); hipMemset(A, 0, (size_t)512 * 40000 * 4);
+    hipMalloc(&C, (size_t)50 * 512 * 256 * 4); g.A = A; g.C = C;
+  }
+  const int grid = g.tiles_m * g.tiles_n * g.split;
+  if (lay == 0) run<NT>(g, grid);
+  else          run<NN>(g, grid);
+  static long long h[4][256];
+  hipMemcpyFromSymbol(h, HIP_SYMBOL(g_probe), sizeof(h));
+  // stamps: [0] start, then per K-step 4 (loop top, after sync1, after LDS writes, after sync2), then end of loop, end of kernel
+  const int ksteps = g.k_per_split / 32;
+  for (int w = 0; w < 4; ++w) {
+    printf("wave %d: prologue %lld |", w, h[w][1] - h[w][0]);
+    const int show = ksteps < 10 ? ksteps : 10;
+    for (int k = 0; k < show; ++k) {
+      const long long* s = &h[w][1 + 4 * k];
+      const long long next = (k + 1 < ksteps) ? s[4] : h[w][1 + 4 * ksteps];
+      printf(" [sync1 %lld wr %lld sync2 %lld mm %lld]", s[1] - s[0], s[2] - s[1], s[3] - s[2], next - s[3]);
+    }
+    printf(" | epilogue %lld total %lld\n", h[w][2 + 4 * ksteps] - h[w][1 + 4 * ksteps], h[w][2 + 4 * ksteps] - h[w][0]);
+  }
+  return 0;
+}

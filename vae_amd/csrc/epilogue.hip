@@ -313,6 +313,36 @@ __global__ __launch_bounds__(THREADS, 4) void nbzinb_fwd_kernel(
   }
 }
 
+// ---- px_rate export (validation / inference: LitVAE.validation_step, task.py:240,263) ------
+// px_rate[b,g] = exp(library[b]) * exp(l[b,g] - max_b) / sum_b: the mu the likelihood pass above used
+// (same expression, same rounding), from the row statistics it saved.  Grid (strips of 1024 genes, cells).
+template <bool VEC>
+__global__ __launch_bounds__(256) void px_rate_kernel(const float* __restrict__ ls, int64_t ld_s,
+                                                      const float* __restrict__ library,
+                                                      const float* __restrict__ rowmax,
+                                                      const float* __restrict__ rowsum, int G, float* __restrict__ out,
+                                                      int64_t ld_o) {
+  const int b = blockIdx.y;
+  const int i = blockIdx.x * 256 + threadIdx.x;  // float4 index in the row
+  if (4 * i >= G) return;
+  const float m = rowmax[b];
+  const float scale = expf(library[b]) / rowsum[b];
+  const float4 l = ld4<VEC>(ls + (int64_t)b * ld_s, i, G, 0.f);
+  float4 r;
+  r.x = scale * fexp_acc(l.x - m); r.y = scale * fexp_acc(l.y - m);
+  r.z = scale * fexp_acc(l.z - m); r.w = scale * fexp_acc(l.w - m);
+  float* o = out + (int64_t)b * ld_o;
+  if (VEC) {
+    reinterpret_cast<float4*>(o)[i] = r;
+  } else {
+    const int g = 4 * i;
+    o[g] = r.x;
+    if (g + 1 < G) o[g + 1] = r.y;
+    if (g + 2 < G) o[g + 2] = r.z;
+    if (g + 3 < G) o[g + 3] = r.w;
+  }
+}
+
 // ---- backward: (gene strip of 1024) x (chunk of cells) per workgroup ----------------------
 constexpr int BWD_STRIP = 1024;  // 256 threads x float4
 constexpr int BWD_MAX_ROWS = 64;  // cells per workgroup (per-cell constants staged in LDS)
@@ -543,6 +573,23 @@ extern "C" int vae_nbzinb_fwd_u8(int zinb, const float* logit_scale, int64_t ld_
                                  int64_t G, float* ll, float* rowmax, float* rowsum, float* S, void* stream) {
   return nbzinb_fwd_impl<uint8_t>(zinb, logit_scale, ld_s, logit_dropout, ld_p, x, ld_x, library, gene_table, B, G, ll,
                                   rowmax, rowsum, S, stream);
+}
+
+extern "C" int vae_px_rate(const float* logit_scale, int64_t ld_s, const float* library, const float* rowmax,
+                           const float* rowsum, int64_t B, int64_t G, float* px_rate, int64_t ld_r, void* stream) {
+  VAE_REQUIRE(logit_scale && library && rowmax && rowsum && px_rate, "vae_px_rate: null pointer");
+  VAE_REQUIRE(B > 0 && B <= 65535 && G > 0 && ld_s >= G && ld_r >= G, "vae_px_rate: bad shape B=%lld G=%lld", (long long)B,
+              (long long)G);
+  const bool vec = (G % 4 == 0) && (ld_s % 4 == 0) && (ld_r % 4 == 0) && vae_aligned16(logit_scale) && vae_aligned16(px_rate);
+  const dim3 grid((unsigned)((G + 1023) / 1024), (unsigned)B);
+  if (vec)
+    hipLaunchKernelGGL(px_rate_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, logit_scale, ld_s, library, rowmax,
+                       rowsum, (int)G, px_rate, ld_r);
+  else
+    hipLaunchKernelGGL(px_rate_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, logit_scale, ld_s, library, rowmax,
+                       rowsum, (int)G, px_rate, ld_r);
+  VAE_CHECK_LAUNCH("vae_px_rate");
+  return VAE_OK;
 }
 
 namespace {

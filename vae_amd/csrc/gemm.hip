@@ -613,6 +613,12 @@ __global__ __launch_bounds__(256, 2) void gemm32_dma_kernel(GemmArgs g) {
 //     ds_read_b64_tr_b16 (a 16-lane group reads 4 k x 16 rows and receives them row-major).
 // Same shape requirements, tiles and placement as gemm32_dma_kernel.
 // ---------------------------------------------------------------------------------------
+#ifdef VAE_PROBE   // tools/micro/gemm_probe.hip: cycle stamps of workgroup VAE_PROBE's K loop
+__device__ long long g_probe[4][256];
+#define GSTAMP() do { if (blockIdx.x == VAE_PROBE && lane == 0 && pi < 256) g_probe[wave][pi++] = clock64(); } while (0)
+#else
+#define GSTAMP() do { } while (0)
+#endif
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
 
@@ -701,13 +707,20 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(GemmArgs g) {
       *reinterpret_cast<bf16x4*>(base + 2 * plane + off) = lo;
     }
   };
+#ifdef VAE_PROBE
+  int pi = 0;
+#endif
   auto stage = [&]() {
+    GSTAMP();
     __syncthreads();  // the previous tile's fragment reads are done
+    GSTAMP();
 #pragma unroll
     for (int i = 0; i < NA; ++i) put(sA, PLA, wa[i], ra[i]);
 #pragma unroll
     for (int i = 0; i < NB; ++i) put(sB, PLB, wb[i], rb[i]);
+    GSTAMP();
     __syncthreads();
+    GSTAMP();
   };
 
   // ---- fragment addressing ----
@@ -771,12 +784,20 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(GemmArgs g) {
     }
   };
 
+  GSTAMP();
   if (kbeg < kend) fetch();
   for (int k0 = kbeg; k0 < kend; k0 += BK) {
+#ifdef VAE_ABL   // ablations for tools/micro/gemm_probe.hip: 1 = stage once, 2 = fetch once, 4 = no multiply
+    if (!(VAE_ABL & 1) || k0 == kbeg) stage();
+    if ((!(VAE_ABL & 2) || k0 == kbeg) && k0 + BK < kend) fetch();
+    if (!(VAE_ABL & 4)) multiply();
+#else
     stage();
     if (k0 + BK < kend) fetch();  // in flight during the MFMAs below
     multiply();
+#endif
   }
+  GSTAMP();
 
   float* out = g.C;
   int64_t ldc = g.ldc;
@@ -802,6 +823,7 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(GemmArgs g) {
         }
       }
     }
+  GSTAMP();
 }
 
 // Sums the split-K slabs in slab order, adds the bias, writes (or accumulates into) C.

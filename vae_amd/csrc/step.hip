@@ -207,6 +207,19 @@ extern "C" int vae_elbo_step_forward(const vae_step_config* cfg, const vae_step_
   return VAE_OK;
 }
 
+// After vae_elbo_step_forward on the same workspace: the decoder's mean px_rate (B, G), which the
+// validation step exports (task.py:240,263).  The logits are still in the workspace until a backward runs.
+extern "C" int vae_elbo_step_px_rate(const vae_step_config* cfg, const float* ws, int64_t ws_bytes, float* px_rate,
+                                     int64_t ld_r, void* stream) {
+  Layout lo;
+  if (!cfg || !ws || !px_rate) return vae_set_error(VAE_ERR_ARG, "vae_elbo_step_px_rate: null pointer");
+  if (!make_layout(*cfg, &lo)) return vae_set_error(VAE_ERR_ARG, "vae_elbo_step_px_rate: bad configuration");
+  if (ws_bytes < lo.total * 4) return vae_set_error(VAE_ERR_ARG, "vae_elbo_step_px_rate: workspace too small");
+  const int64_t NH = cfg->zinb ? 2 * (int64_t)cfg->G : cfg->G;
+  return vae_px_rate(ws + lo.logits, NH, ws + lo.library, ws + lo.rowmax, ws + lo.rowsum, cfg->B, cfg->G, px_rate, ld_r,
+                     stream);
+}
+
 extern "C" int vae_elbo_step_backward(const vae_step_config* cfg, const vae_step_tensors* p, const vae_step_tensors* g,
                                       const void* xv, int64_t ldx, const float* eps_z, const float* eps_l,
                                       int use_dz_extra, float* ws, int64_t ws_bytes, void* event_heads_ready,

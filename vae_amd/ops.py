@@ -282,6 +282,25 @@ def nbzinb_fwd(zinb: bool, logit_scale: torch.Tensor, logit_dropout: Optional[to
     return o[0], o[1], o[2], o[3]
 
 
+def px_rate(logit_scale: torch.Tensor, library: torch.Tensor, rowmax: torch.Tensor, rowsum: torch.Tensor,
+            out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """The decoder mean exp(library) * softmax(logit_scale) (modules.py:401,404) from the row statistics
+    ``nbzinb_fwd`` returned -- the value its likelihood used.  -> (B, G)."""
+    lib = _lib.load()
+    _chk2d(logit_scale, "logit_scale")
+    B, G = logit_scale.shape
+    for t, name in ((library, "library"), (rowmax, "rowmax"), (rowsum, "rowsum")):
+        _chk1d(t, B, name)
+    if out is None:
+        out = torch.empty(B, G, dtype=torch.float32, device=logit_scale.device)
+    _chk2d(out, "out")
+    if tuple(out.shape) != (B, G):
+        raise ValueError(f"vae_amd.ops.px_rate: out must be {(B, G)}, got {tuple(out.shape)}")
+    _lib.check(lib.vae_px_rate(_p(logit_scale), _ld(logit_scale), _p(library), _p(rowmax), _p(rowsum), B, G, _p(out),
+                               _ld(out), _stream()), "px_rate")
+    return out
+
+
 def nbzinb_bwd(zinb: bool, logit_scale: torch.Tensor, logit_dropout: Optional[torch.Tensor], x: torch.Tensor,
                library: torch.Tensor, table: torch.Tensor, rowmax, rowsum, S, g_ll: Optional[torch.Tensor],
                g_scalar: float, dlogit_scale: torch.Tensor, dlogit_dropout: Optional[torch.Tensor],

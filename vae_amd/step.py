@@ -101,6 +101,7 @@ class ElboStep:
         self._plans: Dict[int, tuple] = {}
         self._ev_heads = None
         self._zero = None
+        self._last_fwd = None
 
     def _plan(self, B: int, loss_scale: float):
         """Config struct, workspace and named views for batch size B (cached)."""
@@ -183,7 +184,9 @@ class ElboStep:
             out["cell_loss"] = self._zero
             out["loss"] = s[4]
         if not backward:
+            self._last_fwd = (B, cfg, ws, nbytes)
             return out
+        self._last_fwd = None   # the backward overwrites the logits in place
 
         ev = None
         if reducer is not None and reducer.world > 1 and not os.environ.get("VAE_NO_NATIVE_EVENT"):
@@ -198,4 +201,29 @@ class ElboStep:
         if reducer is not None:
             reducer.bucket_ready("dec_heads", after_event=self._ev_heads if ev is not None else None)
             reducer.bucket_ready("rest")
+        return out
+
+    # ------------------------------------------------------------------------------------
+    def px_rate(self, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """The decoder mean px_rate = exp(library) * softmax(logits), (B, G), of the LAST forward-only
+        ``run(..., backward=False)`` -- what the validation step exports (task.py:240,263)."""
+        if self._last_fwd is None:
+            raise RuntimeError("ElboStep.px_rate: call run(..., backward=False) first (a backward overwrites the logits)")
+        B, cfg, ws, nbytes = self._last_fwd
+        if out is None:
+            out = torch.empty(B, self.G, dtype=torch.float32, device=ws.device)
+        if out.shape != (B, self.G) or out.dtype != torch.float32 or not out.is_cuda or out.stride(1) != 1:
+            raise ValueError(f"ElboStep.px_rate: out must be a float32 GPU tensor of shape {(B, self.G)}")
+        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        rc = self.lib.vae_elbo_step_px_rate(C.byref(cfg), ws.data_ptr(), nbytes, out.data_ptr(), out.stride(0), stream)
+        _lib.check(rc, "elbo_step_px_rate")
+        return out
+
+    def infer(self, x: torch.Tensor, eps_z: torch.Tensor, eps_l: torch.Tensor, *, want_px_rate: bool = False,
+              cell_head_fn: Optional[Callable[[torch.Tensor], torch.Tensor]] = None) -> Dict[str, torch.Tensor]:
+        """Validation / inference pass (LitVAE.validation_step, task.py:235-282): the forward alone, no
+        gradient is touched; ``px_rate`` (B, G) on request."""
+        out = self.run(x, eps_z, eps_l, cell_head_fn=cell_head_fn, backward=False)
+        if want_px_rate:
+            out["px_rate"] = self.px_rate()
         return out

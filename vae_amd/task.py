@@ -95,6 +95,7 @@ class LitVAE(nn.Module):
         self.logged: Dict[str, float] = {}
         self._arena: Optional[ParamArena] = None
         self._fused: Optional[ElboStep] = None
+        self._create_results_dict()
         if use_gdro:
             raise NotImplementedError("vae_amd: GroupDRO re-weighting (off in the shipped config) is not wired in")
 
@@ -168,6 +169,117 @@ class LitVAE(nn.Module):
         self.log("cell_loss", c_loss)
         self.log("kl_weight", self.kl_weight)
         return loss
+
+    # -- validation / inference (task.py:235-282, 301-362, 364-416) ---------------------------------
+    def _create_results_dict(self):
+        """Per-epoch buffers the validation step appends to (task.py:103-117)."""
+        res: Dict[str, Any] = {"epoch": self.current_epoch}
+        for k in (self.cell_properties or {}):
+            res[k], res["pred_" + k] = [], []
+        for k in (self.batch_properties or {}):
+            res[k] = []
+        for k in ("latent", "cell_mask", "px_r", "cell_idx", "SubID"):
+            res[k] = []
+        self.results = res
+        # running sums behind the logged accuracy / explained variance of each property
+        self._hits = {k: [0, 0] for k, v in (self.cell_properties or {}).items() if v["discrete"]}
+        self._moments = {k: np.zeros(6) for k, v in (self.cell_properties or {}).items() if not v["discrete"]}
+
+    def cell_scores(self, cell_pred, cell_targets, cell_mask, latent_mean, subject):
+        """Accuracy (discrete) / explained variance (continuous) over the masked cells and the per-cell
+        records of the epoch (task.py:364-416; subject_batch_size 1)."""
+        if self.subject_batch_size > 1:
+            raise NotImplementedError("vae_amd: subject-level batches are not wired into validation")
+        for n, (k, prop) in enumerate(self.cell_properties.items()):
+            keep = cell_mask[:, n] != 0
+            if prop["discrete"]:
+                tgt = cell_targets[:, n].to(torch.int64)
+                hit = (cell_pred[k].argmax(dim=-1) == tgt) & keep
+                self._hits[k][0] += int(hit.sum())
+                self._hits[k][1] += int(keep.sum())
+                if k != "SubID":
+                    self.results[k].append(tgt.cpu().numpy())
+                    self.results["pred_" + k].append(torch.softmax(cell_pred[k].float(), dim=-1).detach().cpu().numpy())
+                self.log(k, self._hits[k][0] / max(self._hits[k][1], 1))
+            else:
+                pred = cell_pred[k][:, 0].float()
+                p64, t64 = pred[keep].double(), cell_targets[keep, n].double()
+                d = t64 - p64
+                self._moments[k] += np.array([p64.numel(), float(t64.sum()), float((t64 * t64).sum()), float(d.sum()),
+                                              float((d * d).sum()), 0.0])
+                cnt, st, stt, sd, sdd, _ = self._moments[k]
+                if cnt > 1:   # 1 - Var(target - pred) / Var(target), the ExplainedVariance metric
+                    var_t = stt / cnt - (st / cnt) ** 2
+                    var_d = sdd / cnt - (sd / cnt) ** 2
+                    self.log(k, 1.0 - var_d / var_t if var_t > 0 else float("nan"))
+                self.results[k].append(cell_targets[:, n].detach().cpu().numpy())
+                self.results["pred_" + k].append(pred.detach().cpu().numpy())
+        if latent_mean is not None:
+            self.results["latent"].append(latent_mean.detach().float().cpu().numpy())
+        self.results["cell_mask"].append(cell_mask.detach().float().cpu().numpy())
+        self.results["SubID"].append(subject)
+
+    def _record_validation(self, batch, qz_m, px_rate):
+        _, cell_targets, cell_mask, batch_labels, _, cell_idx, _, subject = batch
+        self.results["cell_idx"].append(cell_idx.detach().cpu().numpy() if torch.is_tensor(cell_idx) else np.asarray(cell_idx))
+        if self.save_gene_vals and px_rate is not None:
+            self.results["px_r"].append(px_rate.detach().float().cpu().numpy())
+        if self.cell_properties is not None:
+            with torch.no_grad():
+                self.cell_scores(self.network.cell_decoder(qz_m), cell_targets, cell_mask, qz_m, subject)
+        if self.batch_properties is not None:
+            for n, k in enumerate(self.batch_properties.keys()):
+                self.results[k].append(batch_labels[:, n].detach().cpu().numpy())
+
+    @torch.no_grad()
+    def validation_step(self, batch, batch_idx):
+        """Module-API validation step (task.py:235-282): forward, validation losses, cell heads on qz_m."""
+        gene_vals, _, _, batch_labels, batch_mask = batch[:5]
+        net = self.network
+        qz_m, qz_v, z = net.z_encoder(gene_vals, batch_labels, batch_mask)
+        ql_m, ql_v, library = net.l_encoder(gene_vals, batch_labels, batch_mask)
+        _, px_r, px_rate, px_dropout = net.decoder(self.dispersion, z, library, batch_labels, batch_mask)
+        px_r = torch.exp(net.px_r if self.dispersion == "gene" else px_r)
+        l_mean, l_var = self.library_stats(gene_vals)
+        g_loss, kl_z = self.gene_loss(gene_vals, qz_m, qz_v, ql_m, ql_v, l_mean, l_var, px_rate, px_r, px_dropout,
+                                      training=False)
+        self._record_validation(batch, qz_m, px_rate)
+        return g_loss
+
+    @torch.no_grad()
+    def validation_step_fused(self, batch, eps_z=None, eps_l=None):
+        """The validation step on the fused forward (ElboStep.infer): one native call, px_rate only when
+        ``save_gene_vals`` asks for it."""
+        if self._arena is None:
+            self.attach_arena()
+        if self.library_mean is None or self.library_var is None:
+            raise ValueError("fused step needs the library prior constants (library_mean / library_var)")
+        if self._fused is None or self._fused.kl_weight != self.kl_weight:
+            self._fused = ElboStep(self._arena, l_mean=float(self.library_mean), l_var=float(self.library_var),
+                                   kl_weight=self.kl_weight, gene_loss_coeff=self.gene_loss_coeff,
+                                   precision=self.precision)
+        gene_vals = batch[0]
+        B, L = gene_vals.shape[0], self.network.n_latent
+        if eps_z is None:
+            eps_z = torch.empty(B, L, device=gene_vals.device).normal_()
+            eps_l = torch.empty(B, 1, device=gene_vals.device).normal_()
+        out = self._fused.infer(gene_vals, eps_z, eps_l, want_px_rate=self.save_gene_vals)
+        self.log("recon_loss_val", out["recon_mean"])
+        self.log("kl_z_val", out["scalars"][1])
+        self._record_validation(batch, out["qz_m"], out.get("px_rate"))
+        return out
+
+    def on_validation_epoch_end(self):
+        """Concatenate the epoch's records (task.py:301-362, without the pickle dump) and start a new epoch."""
+        done = {}
+        for k, v in self.results.items():
+            if isinstance(v, list) and k != "SubID":
+                done[k] = np.concatenate(v, axis=0) if len(v) > 0 else v
+            else:
+                done[k] = v
+        self._create_results_dict()
+        self.results["epoch"] = self.current_epoch + 1
+        return done
 
     # -- fused fast path ------------------------------------------------------------------------
     def attach_arena(self, device="cuda") -> ParamArena:
