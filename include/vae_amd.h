@@ -252,6 +252,12 @@ int vae_adamw_step(float* params, const float* grads, float* exp_avg, float* exp
                    int64_t step, double max_grad_norm, double grad_scale, float* workspace, int64_t workspace_bytes,
                    float* grad_norm_out, void* stream);
 
+/* L1 penalty of LitVAE.training_step (task.py:491-496): sum_out[0] = sum of |p| over the segments (their
+ * weight_decay field is ignored) and, when grads is not null, grads += grad_coeff * sign(p) -- the gradient of
+ * grad_coeff * sum|p| (torch.norm(p, 1)).  Deterministic two-stage sum.  workspace as for vae_adamw_step.   */
+int vae_l1_penalty(const float* params, float* grads, int64_t n, const vae_adamw_segment* segments, int n_segments,
+                   double grad_coeff, float* workspace, int64_t workspace_bytes, float* sum_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -113,6 +113,42 @@ def test_validation_step_module_and_fused_agree(case, monkeypatch):
     assert task.results["px_r"] == [] and task.results["epoch"] == 1
 
 
+def test_l1_penalty_fused_matches_module_path(monkeypatch):
+    """Row f4, L1 term (task.py:491-496): loss += l1_lambda * sum |p| over z_encoder non-bias parameters."""
+    import vae_amd.modules as M
+    case0 = E2E_CASES[2]
+    lam = 3e-4
+    _, task_m, batch, eps_z, eps_l = build_task(case0)
+    task_m.l1_lambda = lam
+    task_m.network.cuda()
+    queue = [eps_z, eps_l]
+    monkeypatch.setattr(M, "reparameterize_gaussian", lambda mu, var: mu + queue.pop(0) * var.sqrt())
+    loss_m = task_m.training_step(batch, 0)
+    loss_m.backward()
+    _, task_f, batch, eps_z, eps_l = build_task(case0)
+    task_f.l1_lambda = lam
+    arena = task_f.attach_arena("cuda")
+    out = task_f.training_step_fused(batch, eps_z, eps_l)
+    ref_l1 = sum(float(p.detach().abs().double().sum()) for n, p in task_m.network.named_parameters()
+                 if "z_encoder" in n and "bias" not in n)
+    assert abs(float(out["l1"]) - ref_l1) < 1e-6 * ref_l1
+    assert abs(float(out["loss"]) - float(loss_m.detach())) < TOL_CELL * abs(float(loss_m.detach()))
+    gm = dict(task_m.network.named_parameters())
+    n = 0
+    for k, p in task_f.network.named_parameters():
+        if gm[k].grad is None:
+            continue
+        assert rel_err(p.grad.cpu().numpy(), gm[k].grad.cpu().numpy()) < TOL_GRAD, k
+        n += 1
+    assert n >= 15
+    # the penalty really is in the gradient: without it the first-layer weight gradient differs by lam * sign(W)
+    w = "z_encoder.encoder.fc_layers.0.weight"
+    g_with = arena.g(w).clone()
+    task_f.l1_lambda = 0.0
+    task_f.training_step_fused(batch, eps_z, eps_l)
+    assert torch.allclose(g_with - arena.g(w), lam * torch.sign(arena.p(w)), atol=1e-7)
+
+
 def test_module_forward_outputs():
     """DecoderSCVI / Encoder forward tensors (px_scale, px_rate, px_dropout, q_m, q_v) vs goldens."""
     import vae_amd.modules as M

@@ -26,6 +26,7 @@ SIGNATURES = {
     "vae_gemm_slabs": (_i32, [_i32, _i32, _i64, _i64, _i64, _ptr, _i64, _ptr, _i64, _ptr, _i64, C.POINTER(C.c_int), _ptr]),
     "vae_px_rate": (_i32, [_ptr, _i64, _ptr, _ptr, _ptr, _i64, _i64, _ptr, _i64, _ptr]),
     "vae_elbo_step_px_rate": (_i32, [_ptr, _ptr, _i64, _ptr, _i64, _ptr]),
+    "vae_l1_penalty": (_i32, [_ptr, _ptr, _i64, _ptr, _i32, C.c_double, _ptr, _i64, _ptr, _ptr]),
     "vae_row_mean": (_i32, [_ptr, _i64, _i64, _i64, _ptr, _ptr]),
     "vae_normalize_rows": (_i32, [_ptr, _i64, _i64, _i64, _ptr, _ptr, _i64, _ptr]),
     "vae_normalize_rows_u8": (_i32, [_ptr, _i64, _i64, _i64, _ptr, _ptr, _i64, _ptr]),

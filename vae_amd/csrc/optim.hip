@@ -130,7 +130,60 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
   }
 }
 
+// L1 penalty over ranges of the arena (LitVAE.training_step, task.py:491-496): partial sums of |p| per
+// workgroup, and grads += coeff * sign(p).  l1_finish_kernel adds the partials in index order.
+__global__ __launch_bounds__(256) void l1_kernel(const float* __restrict__ p, float* __restrict__ g, Segs s, float coeff,
+                                                 float* __restrict__ partial) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  for (int k = 0; k < s.n; ++k)
+    for (int64_t i = s.begin[k] + (int64_t)blockIdx.x * 256 + threadIdx.x; i < s.end[k]; i += (int64_t)gridDim.x * 256) {
+      const float w = p[i];
+      acc += fabsf(w);
+      if (g) g[i] += w > 0.f ? coeff : (w < 0.f ? -coeff : 0.f);
+    }
+  acc = block_sum<4>(acc, red);
+  if (threadIdx.x == 0) partial[blockIdx.x] = acc;
+}
+__global__ __launch_bounds__(256) void l1_finish_kernel(const float* __restrict__ partial, int n, float* __restrict__ out) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) acc += partial[i];
+  acc = block_sum<4>(acc, red);
+  if (threadIdx.x == 0) out[0] = acc;
+}
+
 }  // namespace
+
+extern "C" int vae_l1_penalty(const float* params, float* grads, int64_t n, const vae_adamw_segment* segments,
+                              int n_segments, double grad_coeff, float* workspace, int64_t workspace_bytes,
+                              float* sum_out, void* stream) {
+  VAE_REQUIRE(params && sum_out && n > 0, "vae_l1_penalty: null pointer or empty arena");
+  VAE_REQUIRE(segments && n_segments > 0 && n_segments <= MAX_SEG, "vae_l1_penalty: 1..%d segments, got %d", MAX_SEG, n_segments);
+  VAE_REQUIRE(workspace && workspace_bytes >= NORM_BLOCKS * (int64_t)sizeof(float),
+              "vae_l1_penalty: needs vae_adamw_workspace_bytes() of workspace");
+  Segs s;
+  s.n = n_segments;
+  int64_t total = 0;
+  for (int i = 0; i < MAX_SEG; ++i) { s.begin[i] = s.end[i] = 0; s.decay[i] = 1.f; }
+  for (int i = 0; i < n_segments; ++i) {
+    VAE_REQUIRE(segments[i].begin >= 0 && segments[i].begin <= segments[i].end && segments[i].end <= n,
+                "vae_l1_penalty: segment %d out of range", i);
+    VAE_REQUIRE(i == 0 || segments[i].begin >= segments[i - 1].end, "vae_l1_penalty: segments must be sorted and disjoint");
+    s.begin[i] = segments[i].begin;
+    s.end[i] = segments[i].end;
+    total += segments[i].end - segments[i].begin;
+  }
+  int blocks = (int)((total + 1023) / 1024);
+  if (blocks > NORM_BLOCKS) blocks = NORM_BLOCKS;
+  if (blocks < 1) blocks = 1;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(l1_kernel, dim3(blocks), dim3(256), 0, st, params, grads, s, (float)grad_coeff, workspace);
+  VAE_CHECK_LAUNCH("vae_l1_penalty");
+  hipLaunchKernelGGL(l1_finish_kernel, dim3(1), dim3(256), 0, st, workspace, blocks, sum_out);
+  VAE_CHECK_LAUNCH("vae_l1_penalty(finish)");
+  return VAE_OK;
+}
 
 extern "C" int64_t vae_adamw_workspace_bytes(void) { return NORM_BLOCKS * (int64_t)sizeof(float); }
 

@@ -92,3 +92,42 @@ class FusedAdamW:
         self.steps = int(sd["steps"])
         self.exp_avg.copy_(sd["exp_avg"])
         self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+
+
+class L1Penalty:
+    """``l1_lambda * sum(|p|)`` over the parameters the reference regularises (task.py:491-496: every
+    ``z_encoder`` parameter whose name has no "bias" -- the Linear weights AND the LayerNorm scales), on the
+    flat arena: one launch adds ``coeff * sign(p)`` to the gradients and sums ``|p|`` (``vae_l1_penalty``)."""
+
+    def __init__(self, arena: ParamArena, selects: Callable[[str], bool] = lambda n: "z_encoder" in n and "bias" not in n):
+        if not arena.flat.is_cuda:
+            raise RuntimeError("vae_amd: L1Penalty needs the arena on a GPU (there is no CPU fallback)")
+        self.lib = _lib.load()
+        self.arena = arena
+        ranges: List[Tuple[int, int]] = []
+        for name, (off, shape) in arena.offsets.items():
+            if name in arena.no_grad or not selects(name):
+                continue
+            n = 1
+            for d in shape:
+                n *= d
+            if ranges and ranges[-1][1] == off:
+                ranges[-1] = (ranges[-1][0], off + n)
+            else:
+                ranges.append((off, off + n))
+        ranges.sort()
+        if not 0 < len(ranges) <= 16:
+            raise RuntimeError(f"vae_amd: L1Penalty supports 1..16 ranges, got {len(ranges)}")
+        self.ranges = ranges
+        self._segs = (_lib.AdamWSegment * len(ranges))(*[_lib.AdamWSegment(b, e, 0.0) for b, e in ranges])
+        self._ws = torch.empty(self.lib.vae_adamw_workspace_bytes() // 4, dtype=torch.float32, device=arena.device)
+        self.total = torch.zeros(1, dtype=torch.float32, device=arena.device)
+
+    def apply(self, grad_coeff: float, backward: bool = True) -> torch.Tensor:
+        """-> sum(|p|) as a 0-dim GPU tensor; gradients += grad_coeff * sign(p) when ``backward``."""
+        a = self.arena
+        rc = self.lib.vae_l1_penalty(a.flat.data_ptr(), a.flat_grad.data_ptr() if backward else None, a.total, self._segs,
+                                     len(self.ranges), float(grad_coeff), self._ws.data_ptr(), self._ws.numel() * 4,
+                                     self.total.data_ptr(), C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        _lib.check(rc, "l1_penalty")
+        return self.total[0]

@@ -95,6 +95,7 @@ class LitVAE(nn.Module):
         self.logged: Dict[str, float] = {}
         self._arena: Optional[ParamArena] = None
         self._fused: Optional[ElboStep] = None
+        self._l1 = None
         self._create_results_dict()
         if use_gdro:
             raise NotImplementedError("vae_amd: GroupDRO re-weighting (off in the shipped config) is not wired in")
@@ -297,6 +298,7 @@ class LitVAE(nn.Module):
             p.grad = None if k in arena.no_grad else arena.g(k)
         self._arena = arena
         self._fused = None
+        self._l1 = None
         return arena
 
     def training_step_fused(self, batch, eps_z=None, eps_l=None, loss_scale: float = 1.0, reducer=None):
@@ -321,7 +323,18 @@ class LitVAE(nn.Module):
         fn = None
         if self.cell_properties is not None and cell_prop_vals is not None:
             fn = lambda z: self._cell_loss(self.network.cell_decoder(z), cell_prop_vals, cell_mask, None)  # noqa: E731
+        l1 = None
+        if self.l1_lambda > 0:   # task.py:491-496; its gradient must be in place before the buckets are reduced
+            from .optim import L1Penalty
+            if self._l1 is None:
+                self._l1 = L1Penalty(self._arena)
+            if reducer is not None and reducer.world > 1:
+                raise NotImplementedError("fused step: l1_lambda with a gradient reducer (add the penalty after finish())")
         out = self._fused.run(gene_vals, eps_z, eps_l, cell_head_fn=fn, loss_scale=loss_scale, reducer=reducer)
+        if self.l1_lambda > 0:
+            l1 = self._l1.apply(self.l1_lambda * loss_scale)
+            out["l1"] = l1
+            out["loss"] = out["loss"] + self.l1_lambda * l1
         self.log("gene_loss", out["gene_loss"])
         self.log("cell_loss", out["cell_loss"])
         return out
