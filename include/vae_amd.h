@@ -170,8 +170,19 @@ int vae_loglik_elem_bwd(int zinb, const float* gout, int64_t ld_g, const float* 
                         int64_t ld_mu, const float* theta, int64_t ld_theta, const float* pi, int64_t ld_pi, int64_t B,
                         int64_t G, float* dmu, float* dtheta, float* dpi, void* stream);
 
+/* ---- dropout ------------------------------------------------------------------------------------
+ * nn.Dropout of FCLayers (modules.py:115): x[b, c] *= keep / (1 - p).  torch's generator cannot be
+ * reproduced, so the stream is this library's own and documented: Philox4x32-10 with
+ *   key = (seed low 32, seed high 32), counter = (elem low 32, elem high 32, site, step),
+ *   elem = b * W + c,   keep  <=>  output word 0 >= floor(p * 2^32).
+ * site: 4 * layer + 0 = z-encoder hidden layer, 4 * layer + 2 = decoder hidden layer (the library encoder
+ * is built without dropout, networks.py:215-222).  The step (vae_elbo_step_*) draws the same masks from cfg->rng_seed / rng_step in the
+ * forward and the backward pass; tests regenerate them on the host (tests/helpers.py).               */
+int vae_dropout_apply(float* x, int64_t ld, int64_t B, int64_t W, float p, uint64_t seed, uint32_t step, uint32_t site,
+                      void* stream);
+
 /* ---- the whole training step -------------------------------------------------------------------
- * LitVAE.training_step (task.py:453-502) for dispersion "gene", no batch covariates, dropout off:
+ * LitVAE.training_step (task.py:453-502) for dispersion "gene", no batch covariates, no input dropout:
  * one call enqueues the forward, one the backward; all intermediates live in `workspace`.
  * Parameter / gradient pointers follow the reference's state_dict (SURVEY.md par. 3.4); tensors the
  * kernels address as one stacked matrix must be adjacent in memory (vae_amd/arena.py):
@@ -193,6 +204,9 @@ typedef struct {
   float gene_loss_coeff;      /* task.py:489                                                        */
   float loss_scale;           /* multiplies every gradient (1 for plain training)                   */
   int32_t x_dtype;            /* VAE_X_F32: counts are float; VAE_X_U8: uint8 (the reference's store)  */
+  float dropout_rate;         /* p of nn.Dropout after the z-encoder / decoder LayerNorms (modules.py:115); 0 = off */
+  uint32_t rng_step;          /* step counter of the dropout stream: change it every step               */
+  uint64_t rng_seed;          /* key of the dropout stream (give every rank its own)                     */
 } vae_step_config;
 
 typedef struct {

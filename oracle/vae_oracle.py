@@ -78,10 +78,12 @@ def _linear(a: Tensor, w: Tensor, b: Optional[Tensor], gemm_dtype) -> Tensor:
     return y if b is None else y + b
 
 
-def fc_layers(p: Dict[str, Tensor], prefix: str, x: Tensor, n_layers: int, gemm_dtype=None) -> Tensor:
-    """FCLayers with dropout off and no batch covariates; modules.py:110-115,121-132.
+def fc_layers(p: Dict[str, Tensor], prefix: str, x: Tensor, n_layers: int, gemm_dtype=None, masks=None) -> Tensor:
+    """FCLayers without batch covariates; modules.py:110-115,121-132.
 
-    Per layer n: Linear (index 4n) -> GELU(erf) -> LayerNorm(eps 1e-5, affine; index 4n+2).
+    Per layer n: Linear (index 4n) -> GELU(erf) -> LayerNorm(eps 1e-5, affine; index 4n+2) -> Dropout
+    (index 4n+3).  ``masks[n]`` is the dropout MULTIPLIER of layer n (keep / (1 - p), what nn.Dropout
+    multiplies by in training mode); None = dropout off / eval.
     """
     for n in range(n_layers):
         w = p[f"{prefix}.fc_layers.{4 * n}.weight"]
@@ -91,26 +93,28 @@ def fc_layers(p: Dict[str, Tensor], prefix: str, x: Tensor, n_layers: int, gemm_
         x = _linear(x, w, b, gemm_dtype)
         x = F.gelu(x)
         x = F.layer_norm(x, (w.shape[0],), g, be, 1e-5)
+        if masks is not None and masks[n] is not None:
+            x = x * masks[n].to(x.dtype)
     return x
 
 
-def encoder_forward(p, prefix: str, x: Tensor, noise: Tensor, n_layers: int, gemm_dtype=None):
+def encoder_forward(p, prefix: str, x: Tensor, noise: Tensor, n_layers: int, gemm_dtype=None, masks=None):
     """Encoder.forward, modules.py:261-271 (GeneDropout identity, z_transformation identity).
 
     ``noise`` is the standard-normal draw Normal.rsample would make (modules.py:11-12);
     q_v has ONE column (shared_variance, modules.py:249) and broadcasts over the latent.
     """
     xn = x / x.mean(dim=-1, keepdim=True) - 1
-    q = fc_layers(p, f"{prefix}.encoder", xn, n_layers, gemm_dtype)
+    q = fc_layers(p, f"{prefix}.encoder", xn, n_layers, gemm_dtype, masks)
     q_m = _linear(q, p[f"{prefix}.mean_encoder.weight"], p[f"{prefix}.mean_encoder.bias"], gemm_dtype)
     q_v = F.softplus(_linear(q, p[f"{prefix}.var_encoder.weight"], p[f"{prefix}.var_encoder.bias"], gemm_dtype)) + 1e-4
     latent = q_m + noise * torch.sqrt(q_v)
     return q_m, q_v, latent
 
 
-def decoder_forward(p, z: Tensor, library: Tensor, n_layers: int, gemm_dtype=None):
+def decoder_forward(p, z: Tensor, library: Tensor, n_layers: int, gemm_dtype=None, masks=None):
     """DecoderSCVI.forward for dispersion != 'gene-cell'; modules.py:371-406."""
-    px = fc_layers(p, "decoder.px_decoder", z, n_layers, gemm_dtype)
+    px = fc_layers(p, "decoder.px_decoder", z, n_layers, gemm_dtype, masks)
     logit_scale = _linear(px, p["decoder.px_scale_decoder.0.weight"], p["decoder.px_scale_decoder.0.bias"], gemm_dtype)
     px_scale = torch.softmax(logit_scale, dim=-1)
     px_dropout = _linear(px, p["decoder.px_dropout_decoder.weight"], p["decoder.px_dropout_decoder.bias"], gemm_dtype)
@@ -170,11 +174,21 @@ def training_step(
     cell_targets: Optional[Tensor] = None,
     cell_mask: Optional[Tensor] = None,
     gemm_dtype=None,
+    drop_masks: Optional[dict] = None,
+    x_z: Optional[Tensor] = None,
 ) -> Dict[str, Tensor]:
-    """Forward of one training step; returns every intermediate the goldens pin."""
-    qz_m, qz_v, z = encoder_forward(p, "z_encoder", x, eps_z, n_layers, gemm_dtype)
+    """Forward of one training step; returns every intermediate the goldens pin.
+
+    Training-mode regularisers enter as DATA, so that the step stays a deterministic function:
+    ``drop_masks = {"z_encoder": [m_0, ...], "decoder": [m_0, ...]}`` are the nn.Dropout multipliers
+    of each hidden layer (modules.py:115; the library encoder is built with dropout 0,
+    networks.py:215-222); ``x_z`` is the z-encoder's input after GeneDropout (modules.py:190-209,263)
+    -- the library encoder and the likelihood see ``x`` itself."""
+    dm = drop_masks or {}
+    qz_m, qz_v, z = encoder_forward(p, "z_encoder", x if x_z is None else x_z, eps_z, n_layers, gemm_dtype,
+                                    dm.get("z_encoder"))
     ql_m, ql_v, library = encoder_forward(p, "l_encoder", x, eps_l, 1, gemm_dtype)  # networks.py:215-222
-    px_scale, px_rate, px_dropout = decoder_forward(p, z, library, n_layers, gemm_dtype)
+    px_scale, px_rate, px_dropout = decoder_forward(p, z, library, n_layers, gemm_dtype, dm.get("decoder"))
     theta = torch.exp(p["px_r"])  # task.py:481-483, dispersion "gene"
 
     if likelihood == "zinb":

@@ -322,3 +322,27 @@ def test_px_rate_from_saved_row_statistics(ops, G):
     assert torch.equal(out, got)
     with pytest.raises(ValueError):
         ops.px_rate(logits, library[:-1], rowmax, rowsum)
+
+
+@pytest.mark.parametrize("p", [0.5, 0.1, 0.93])
+def test_dropout_stream_matches_host_restatement(ops, p):
+    """The dropout masks are the documented Philox4x32-10 stream (include/vae_amd.h): regenerated on the host
+    by tests/helpers.py, whose Philox is pinned by the Random123 known-answer vectors (test_oracle_golden)."""
+    from helpers import dropout_multiplier
+    B, W, seed, step, site = 37, 200, 0x1234567890ABCDEF, 41, 6
+    x = torch.ones(B, W, device="cuda")
+    ops.dropout_apply(x, p, seed, step, site)
+    ref = dropout_multiplier(p, seed, step, site, B, W)
+    assert np.array_equal(x.cpu().numpy(), ref)
+    assert abs((ref > 0).mean() - (1 - p)) < 0.02
+    # a strided view: element index = row * width + column of the VIEW; the padding is untouched
+    buf = torch.ones(B, W + 8, device="cuda")
+    ops.dropout_apply(buf[:, :W], p, seed, step, site)
+    assert np.array_equal(buf[:, :W].cpu().numpy(), ref) and bool((buf[:, W:] == 1).all())
+    # other step / site / seed -> other masks; p = 0 -> untouched
+    y = torch.ones(B, W, device="cuda")
+    assert not torch.equal(ops.dropout_apply(y.clone(), p, seed, step + 1, site), x)
+    assert not torch.equal(ops.dropout_apply(y.clone(), p, seed, step, site + 4), x)
+    assert torch.equal(ops.dropout_apply(y.clone(), 0.0, seed, step, site), y)
+    with pytest.raises(RuntimeError):
+        ops.dropout_apply(y, 1.0, seed, step, site)

@@ -149,6 +149,32 @@ def test_l1_penalty_fused_matches_module_path(monkeypatch):
     assert torch.allclose(g_with - arena.g(w), lam * torch.sign(arena.p(w)), atol=1e-7)
 
 
+def test_fused_step_applies_the_modules_dropout():
+    """training_step_fused reads p from the FCLayers nn.Dropout modules: a new mask every training step, none in
+    eval mode (where the step equals the reference golden again)."""
+    from torch import nn
+    case0 = E2E_CASES[1]
+    gold = load_golden(f"e2e_{case0['name']}.npz")
+    _, task, batch, eps_z, eps_l = build_task(case0)
+    for part in (task.network.z_encoder, task.network.decoder):
+        for m in part.modules():
+            if isinstance(m, nn.Dropout):
+                m.p = 0.3
+    task.attach_arena("cuda")
+    l1 = float(task.training_step_fused(batch, eps_z, eps_l)["loss"])
+    l2 = float(task.training_step_fused(batch, eps_z, eps_l)["loss"])
+    g = float(gold["f64/out/loss"])
+    assert np.isfinite(l1) and np.isfinite(l2) and l1 != l2 and abs(l1 - g) > 1e-4 * abs(g)
+    assert task._fused.dropout_rate == pytest.approx(0.3)
+    task.eval()
+    l3 = float(task.training_step_fused(batch, eps_z, eps_l)["loss"])
+    assert abs(l3 - g) < TOL_CELL * abs(g)
+    task.train()
+    task.network.z_encoder.drop.p = 0.5          # gene-dropout: not on the fused path yet -> loud refusal
+    with pytest.raises(NotImplementedError):
+        task.training_step_fused(batch, eps_z, eps_l)
+
+
 def test_module_forward_outputs():
     """DecoderSCVI / Encoder forward tensors (px_scale, px_rate, px_dropout, q_m, q_v) vs goldens."""
     import vae_amd.modules as M

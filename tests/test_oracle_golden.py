@@ -87,3 +87,16 @@ def test_bf16_mode_is_close_to_fp32():
     o32, _ = run_oracle(E2E_CASES[1], torch.float32)
     o16, _ = run_oracle(E2E_CASES[1], torch.float32, gemm_dtype=torch.bfloat16)
     assert abs(float(o16["loss"]) - float(o32["loss"])) / abs(float(o32["loss"])) < 2e-2
+
+
+def test_host_philox_known_answers():
+    """tests/helpers.philox_word0 (the host restatement of the library's dropout stream) against the
+    Philox4x32-10 known-answer vectors published with Random123 (kat_vectors: all-zero and all-ones
+    counter / key)."""
+    import numpy as np
+    from helpers import dropout_multiplier, philox_word0
+    assert int(philox_word0(0, 0, 0, np.array([0], dtype=np.uint64))[0]) == 0x6627E8D5
+    ones = np.array([0xFFFFFFFFFFFFFFFF], dtype=np.uint64)
+    assert int(philox_word0(0xFFFFFFFFFFFFFFFF, 0xFFFFFFFF, 0xFFFFFFFF, ones)[0]) == 0x408F276D
+    m = dropout_multiplier(0.5, 1234, 7, 0, 512, 256)
+    assert set(np.unique(m)) == {0.0, 2.0} and abs((m > 0).mean() - 0.5) < 0.01

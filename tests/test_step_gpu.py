@@ -117,6 +117,58 @@ def test_inference_step_matches_reference_goldens(case):
         step.px_rate()
 
 
+@pytest.mark.parametrize("case", [E2E_CASES[1], E2E_CASES[2], E2E_CASES[3]], ids=lambda c: c["name"])
+def test_hidden_dropout_matches_oracle_with_the_same_masks(case):
+    """Row f4: nn.Dropout after the z-encoder / decoder LayerNorms (modules.py:115) on the device's Philox
+    stream.  torch's draws cannot be reproduced, so parity is: the HOST regenerates the documented masks and
+    the fp64 oracle runs with them.  1-layer = in-kernel masks of the fused middle, 2-layer = dropout kernels
+    between the unfused launches (both against the same oracle)."""
+    from oracle import vae_oracle as O
+    from vae_amd.arena import ParamArena
+    from vae_amd.step import ElboStep
+    from helpers import dropout_multiplier
+    case = copy.deepcopy(case)
+    params, x, eps_z, eps_l, targets, mask = build_case_inputs(case)
+    p_drop, seed, rng_step = 0.5, 987654321012345, 17
+    B, H, Hd, nl = case["B"], case["H"], case["Hd"], case["n_layers"]
+    masks = {"z_encoder": [torch.from_numpy(dropout_multiplier(p_drop, seed, rng_step, 4 * n, B, H)).double() for n in range(nl)],
+             "decoder": [torch.from_numpy(dropout_multiplier(p_drop, seed, rng_step, 4 * n + 2, B, Hd)).double() for n in range(nl)]}
+    kw = dict(n_layers=nl, likelihood=case["likelihood"], l_mean=case["l_mean"], l_var=case["l_var"],
+              kl_weight=case["kl_weight"], gene_loss_coeff=case["gene_loss_coeff"])
+    if case["use_cell_loss"]:
+        kw.update(cell_properties=case["cell_properties"], grad_reverse=case["grad_reverse"], cell_targets=targets.double(),
+                  cell_mask=mask.double())
+    o_out, o_grads = O.training_step_with_grads(params, x, eps_z, eps_l, drop_masks=masks, **kw)
+    o_plain, _ = O.training_step_with_grads(params, x, eps_z, eps_l, **kw)
+    assert abs(float(o_out["loss"]) - float(o_plain["loss"])) > 1e-3 * abs(float(o_plain["loss"]))   # the masks matter
+
+    def run(train=True):
+        arena = ParamArena({k: v.float() for k, v in params.items()}, nl, case["likelihood"], "cuda")
+        step = ElboStep(arena, l_mean=float(np.float32(case["l_mean"])), l_var=float(np.float32(case["l_var"])),
+                        kl_weight=case["kl_weight"], gene_loss_coeff=case["gene_loss_coeff"], dropout_rate=p_drop, seed=seed)
+        fn = _cell_head_fn(arena, case, targets, mask) if case["use_cell_loss"] else None
+        out = step.run(x.float().cuda(), eps_z.float().cuda(), eps_l.float().cuda(), cell_head_fn=fn, rng_step=rng_step,
+                       train=train)
+        torch.cuda.synchronize()
+        return arena, {k: v.clone() for k, v in out.items()}
+
+    arena, out = run()
+    for k in ("qz_m", "z", "library", "recon", "kl_z", "kl_l"):
+        g = o_out[k].numpy()
+        assert rel_err(out[k].cpu().numpy().reshape(g.shape), g) < TOL_CELL, k
+    assert abs(float(out["loss"]) - float(o_out["loss"])) < TOL_CELL * abs(float(o_out["loss"]))
+    n = 0
+    for k, v in arena.grads().items():
+        if v is None or o_grads[k] is None:
+            continue
+        assert rel_err(v.cpu().numpy(), o_grads[k].numpy()) < TOL_GRAD, k
+        n += 1
+    assert n >= 15
+    # evaluation mode: no masks, the plain forward
+    _, ev = run(train=False)
+    assert abs(float(ev["loss"]) - float(o_plain["loss"])) < TOL_CELL * abs(float(o_plain["loss"]))
+
+
 def test_bf16_mode_against_bf16_oracle():
     """bf16 GEMM operands / fp32 accumulate: same rounding points as the oracle's bf16 mode;
     stated tolerance 2e-3 on per-cell terms, 2e-2 on gradients (bf16 has 8 mantissa bits and the

@@ -16,6 +16,7 @@
 // element e of a vector belongs to thread e % 256.  Per-cell quantities needed for cross-cell
 // sums are written as rows and reduced by small_wgrad_batch.
 #include "middle.h"
+#include "philox.h"
 #include "common.h"
 
 #include <stdlib.h>
@@ -136,6 +137,7 @@ struct MidFwd {
   float *ln_mz, *ln_rz, *ln_ml, *ln_rl;
   float *heads_z, *heads_l, *qz_v, *z, *kl_z, *ql_v, *library, *kl_l;
   float *dec_pre, *dec_h, *ln_md, *ln_rd;
+  VaeDropout drop;                                       // nn.Dropout after each LayerNorm (off: scale == 0)
 };
 
 // softplus variance, sample and KL for one encoder, executed by ONE wave (lane j = latent j).
@@ -246,7 +248,8 @@ __global__ __launch_bounds__(T) void mid_fwd_kernel(MidFwd a) {
     const int e = t + T * i;
     if (e < HE) {
       const bool zh = e < H;
-      const float h = (g[i] - (zh ? mu[0] : mu[1])) * (zh ? rs[0] : rs[1]) * gam[i] + bet[i];
+      float h = (g[i] - (zh ? mu[0] : mu[1])) * (zh ? rs[0] : rs[1]) * gam[i] + bet[i];
+      if (zh && a.drop.on()) h *= a.drop.mult(VAE_SITE_ENC_Z(0), b, H, e);   // the library encoder has no dropout
       hs[e] = h;
       a.h_enc0[(int64_t)b * HE + e] = h;
     }
@@ -328,7 +331,11 @@ __global__ __launch_bounds__(T) void mid_fwd_kernel(MidFwd a) {
 #pragma unroll
   for (int i = 0; i < ME; ++i) {
     const int n = t + T * i;
-    if (n < Hd) a.dec_h[(int64_t)b * Hd + n] = (gd[i] - mu[0]) * rs[0] * dgam[i] + dbet[i];
+    if (n < Hd) {
+      float h = (gd[i] - mu[0]) * rs[0] * dgam[i] + dbet[i];
+      if (a.drop.on()) h *= a.drop.mult(VAE_SITE_DEC(0), b, Hd, n);
+      a.dec_h[(int64_t)b * Hd + n] = h;
+    }
   }
   if (t == 0) {
     a.ln_md[b] = mu[0];
@@ -350,6 +357,7 @@ struct MidBwd {
   float *dbet_d, *dgam_d, *dpre_d;                       // (B, Hd) rows
   float *dq_z, *dq_l;                                    // (B, L+1), (B, 2)
   float *dbet_e, *dgam_e, *dpre_e;                       // (B, H+Hl) rows
+  VaeDropout drop;
 };
 
 // Backward of reparam_wave, by one wave.  Mirrors reparam_kl_bwd_kernel (rowops.hip).
@@ -422,7 +430,8 @@ __global__ __launch_bounds__(T) void mid_bwd_kernel(MidBwd a) {
     const int n = t + T * i;
     dx[i] = xh[i] = pv[i] = 0.f;
     if (n < Hd) {
-      const float dy = dyv[i];
+      float dy = dyv[i];
+      if (a.drop.on()) dy *= a.drop.mult(VAE_SITE_DEC(0), b, Hd, n);
       pv[i] = pd[i];
       xh[i] = (gelu_f(pv[i]) - mud) * rsd;
       dx[i] = dy * gdv[i];
@@ -490,6 +499,7 @@ __global__ __launch_bounds__(T) void mid_bwd_kernel(MidBwd a) {
       } else {
         dy = dot_batched<16>(dq, 1, a.hz_w + e, H, L + 1);
       }
+      if (zh && a.drop.on()) dy *= a.drop.mult(VAE_SITE_ENC_Z(0), b, H, e);
       pv[i] = pe[i];
       xh[i] = (gelu_f(pv[i]) - (zh ? mu0 : mu1)) * (zh ? rs0 : rs1);
       dx[i] = dy * gev[i];
@@ -629,6 +639,7 @@ int vae_mid_forward(const vae_step_config& c, const vae_step_tensors* p, const f
   a.heads_z = heads_z; a.heads_l = heads_l; a.qz_v = qz_v; a.z = z; a.kl_z = kl_z;
   a.ql_v = ql_v; a.library = library; a.kl_l = kl_l;
   a.dec_pre = dec_pre; a.dec_h = dec_h; a.ln_md = ln_md; a.ln_rd = ln_rd;
+  a.drop = vae_make_dropout(c.dropout_rate, c.rng_seed, c.rng_step);
   hipLaunchKernelGGL(mid_fwd_kernel, dim3((unsigned)c.B), dim3(T), (size_t)(c.Hd * (c.L | 1) * 4), (hipStream_t)stream, a);
   VAE_CHECK_LAUNCH("vae_elbo_step_forward(mid)");
   return VAE_OK;
@@ -656,6 +667,7 @@ int vae_mid_backward(const vae_step_config& c, const vae_step_tensors* p, const 
   a.dbet_d = dbet_d; a.dgam_d = dgam_d; a.dpre_d = dpre_d;
   a.dq_z = dq_z; a.dq_l = dq_l;
   a.dbet_e = dbet_e; a.dgam_e = dgam_e; a.dpre_e = dpre_e;
+  a.drop = vae_make_dropout(c.dropout_rate, c.rng_seed, c.rng_step);
   hipLaunchKernelGGL(mid_bwd_kernel, dim3((unsigned)c.B), dim3(T), (size_t)(c.Hd * (c.L | 1) * 4), (hipStream_t)stream, a);
   VAE_CHECK_LAUNCH("vae_elbo_step_backward(mid)");
 

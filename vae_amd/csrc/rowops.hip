@@ -8,6 +8,7 @@
 // accumulated in registers across the rows a wave visits, combined through LDS and flushed
 // with one float atomic per column per workgroup.
 #include "common.h"
+#include "philox.h"
 
 namespace {
 
@@ -465,6 +466,31 @@ extern "C" int vae_elbo_reduce(const float* ll, const float* kl_z, const float* 
   hipLaunchKernelGGL(elbo_reduce_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, ll, kl_z, kl_l, (int)B, kl_weight,
                      gene_loss_coeff, out5, recon);
   VAE_CHECK_LAUNCH("vae_elbo_reduce");
+  return VAE_OK;
+}
+
+// x[b, c] *= keep(b, c) / (1 - p): nn.Dropout (modules.py:115) with the mask of philox.h.  Applied to an
+// activation in the forward pass and to the gradient arriving at the same place in the backward pass.
+__global__ __launch_bounds__(256) void dropout_apply_kernel(float* __restrict__ x, int64_t ld, int64_t B, int W, VaeDropout d,
+                                                            uint32_t site) {
+  const int64_t total = B * W;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t b = i / W;
+    const int c = (int)(i - b * W);
+    x[b * ld + c] *= d.mult(site, b, W, c);
+  }
+}
+
+extern "C" int vae_dropout_apply(float* x, int64_t ld, int64_t B, int64_t W, float p, uint64_t seed, uint32_t step,
+                                 uint32_t site, void* stream) {
+  VAE_REQUIRE(x && B > 0 && W > 0 && W < (1 << 30) && ld >= W, "vae_dropout_apply: bad arguments");
+  VAE_REQUIRE(p >= 0.f && p < 1.f, "vae_dropout_apply: p must be in [0, 1), got %g", (double)p);
+  if (p == 0.f) return VAE_OK;
+  int blocks = (int)((B * W + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(dropout_apply_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, ld, B, (int)W,
+                     vae_make_dropout(p, seed, step), site);
+  VAE_CHECK_LAUNCH("vae_dropout_apply");
   return VAE_OK;
 }
 

@@ -5,6 +5,7 @@
 #include "../../include/vae_amd.h"
 #include "common.h"
 #include "middle.h"
+#include "philox.h"
 
 #include <string.h>
 
@@ -86,6 +87,10 @@ struct Ctx {
   float* ws;
   Layout lo;
   void* st;
+  // nn.Dropout after a hidden LayerNorm (forward: the activation; backward: the gradient arriving there)
+  int drop(float* x, int64_t ld, int64_t W, uint32_t site) const {
+    return vae_dropout_apply(x, ld, c.B, W, c.dropout_rate, c.rng_seed, c.rng_step, site, st);
+  }
   int gemm(int layout, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* Bm, int64_t ldb,
            float* C, int64_t ldc, const float* bias, const float* mean, int acc) const {
     return vae_gemm(layout, c.precision, M, N, K, A, lda, Bm, ldb, C, ldc, bias, mean, acc, ws + lo.scratch,
@@ -102,6 +107,8 @@ int check_common(const vae_step_config* cfg, const void* a, const void* b, const
   if (cfg->G > vae_nbzinb_max_genes())
     return vae_set_error(VAE_ERR_ARG, "%s: G=%lld exceeds %lld", who, (long long)cfg->G, (long long)vae_nbzinb_max_genes());
   if (!(cfg->l_var > 0.f)) return vae_set_error(VAE_ERR_ARG, "%s: l_var must be positive", who);
+  if (!(cfg->dropout_rate >= 0.f && cfg->dropout_rate < 1.f))
+    return vae_set_error(VAE_ERR_ARG, "%s: dropout_rate must be in [0, 1)", who);
   if (ws_bytes < lo->total * 4)
     return vae_set_error(VAE_ERR_ARG, "%s: workspace too small: %lld < %lld bytes", who, (long long)ws_bytes,
                          (long long)(lo->total * 4));
@@ -169,12 +176,14 @@ extern "C" int vae_elbo_step_forward(const vae_step_config* cfg, const vae_step_
                         ws + lo.ln_mz[0], ws + lo.ln_rz[0], stream));
     TRY(vae_gelu_ln_fwd(ws + lo.pre_enc0 + H, HE, p->encl_ln_g, p->encl_ln_b, B, Hl, ws + lo.h_enc0 + H, HE,
                         ws + lo.ln_ml, ws + lo.ln_rl, stream));
+    TRY(k.drop(ws + lo.h_enc0, HE, H, VAE_SITE_ENC_Z(0)));
     const float* hz = ws + lo.h_enc0;
     int64_t ld_hz = HE;
     for (int n = 1; n < c.n_layers; ++n) {
       TRY(k.gemm(VAE_NT, B, H, H, hz, ld_hz, p->encz_w[n], H, ws + lo.encz_pre[n], H, p->encz_b[n], nullptr, 0));
       TRY(vae_gelu_ln_fwd(ws + lo.encz_pre[n], H, p->encz_ln_g[n], p->encz_ln_b[n], B, H, ws + lo.encz_h[n], H,
                           ws + lo.ln_mz[n], ws + lo.ln_rz[n], stream));
+      TRY(k.drop(ws + lo.encz_h[n], H, H, VAE_SITE_ENC_Z(n)));
       hz = ws + lo.encz_h[n];
       ld_hz = H;
     }
@@ -191,6 +200,7 @@ extern "C" int vae_elbo_step_forward(const vae_step_config* cfg, const vae_step_
       TRY(k.gemm(VAE_NT, B, Hd, kin, px, kin, p->dec_w[n], kin, ws + lo.dec_pre[n], Hd, p->dec_b[n], nullptr, 0));
       TRY(vae_gelu_ln_fwd(ws + lo.dec_pre[n], Hd, p->dec_ln_g[n], p->dec_ln_b[n], B, Hd, ws + lo.dec_h[n], Hd,
                           ws + lo.ln_md[n], ws + lo.ln_rd[n], stream));
+      TRY(k.drop(ws + lo.dec_h[n], Hd, Hd, VAE_SITE_DEC(n)));
       px = ws + lo.dec_h[n];
       kin = Hd;
     }
@@ -282,6 +292,7 @@ extern "C" int vae_elbo_step_backward(const vae_step_config* cfg, const vae_step
     for (int n = c.n_layers - 1; n >= 0; --n) {
       const float* inp = n == 0 ? ws + lo.z : ws + lo.dec_h[n - 1];
       const int64_t kin = n == 0 ? L : Hd;
+      TRY(k.drop(dcur, Hd, Hd, VAE_SITE_DEC(n)));
       TRY(vae_gelu_ln_bwd(dcur, Hd, ws + lo.dec_pre[n], Hd, ws + lo.ln_md[n], ws + lo.ln_rd[n], p->dec_ln_g[n], B, Hd, dcur,
                           Hd, g->dec_ln_g[n], g->dec_ln_b[n], g->dec_b[n], stream));
       TRY(k.gemm(VAE_TN, Hd, kin, B, dcur, Hd, inp, kin, g->dec_w[n], kin, nullptr, nullptr, 0));
@@ -313,6 +324,7 @@ extern "C" int vae_elbo_step_backward(const vae_step_config* cfg, const vae_step
     for (int n = c.n_layers - 1; n >= 1; --n) {
       const float* inp = n == 1 ? ws + lo.h_enc0 : ws + lo.encz_h[n - 1];
       const int64_t ld_in = n == 1 ? HE : H;
+      TRY(k.drop(dh, H, H, VAE_SITE_ENC_Z(n)));
       TRY(vae_gelu_ln_bwd(dh, H, ws + lo.encz_pre[n], H, ws + lo.ln_mz[n], ws + lo.ln_rz[n], p->encz_ln_g[n], B, H, dh, H,
                           g->encz_ln_g[n], g->encz_ln_b[n], g->encz_b[n], stream));
       TRY(k.gemm(VAE_TN, H, H, B, dh, H, inp, ld_in, g->encz_w[n], H, nullptr, nullptr, 0));
@@ -321,6 +333,7 @@ extern "C" int vae_elbo_step_backward(const vae_step_config* cfg, const vae_step
       dh = nxt;
     }
     // first encoder layer: GELU/LayerNorm backward of both halves, then ONE wgrad over the counts
+    TRY(k.drop(dh, H, H, VAE_SITE_ENC_Z(0)));
     TRY(vae_gelu_ln_bwd(dh, H, ws + lo.pre_enc0, HE, ws + lo.ln_mz[0], ws + lo.ln_rz[0], p->encz_ln_g[0], B, H,
                         ws + lo.dpre_enc0, HE, g->encz_ln_g[0], g->encz_ln_b[0], g->enc_b0, stream));
     TRY(vae_gelu_ln_bwd(ws + lo.dpre_enc0 + H, HE, ws + lo.pre_enc0 + H, HE, ws + lo.ln_ml, ws + lo.ln_rl, p->encl_ln_g, B,

@@ -131,6 +131,17 @@ def gemm_slabs(layout: int, a: torch.Tensor, b: torch.Tensor, precision: int = F
     return ws[:n.value * M * N].view(n.value, M, N)
 
 
+def dropout_apply(x: torch.Tensor, p: float, seed: int, step: int, site: int) -> torch.Tensor:
+    """In place ``x[b, c] *= keep / (1 - p)`` with the library's documented Philox stream
+    (include/vae_amd.h, "dropout"): nn.Dropout of FCLayers (modules.py:115).  -> x"""
+    lib = _lib.load()
+    _chk2d(x, "x")
+    B, W = x.shape
+    _lib.check(lib.vae_dropout_apply(_p(x), _ld(x), B, W, float(p), int(seed) & (2 ** 64 - 1), int(step) & 0xFFFFFFFF,
+                                     int(site), _stream()), "dropout_apply")
+    return x
+
+
 def row_mean(x: torch.Tensor) -> torch.Tensor:
     lib = _lib.load()
     _chk2d(x, "x")

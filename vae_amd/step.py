@@ -76,7 +76,10 @@ class ElboStep:
     """
 
     def __init__(self, arena: ParamArena, *, l_mean: float, l_var: float, kl_weight: float = 1.0,
-                 gene_loss_coeff: float = 5e-3, precision: int = ops.FP32):
+                 gene_loss_coeff: float = 5e-3, precision: int = ops.FP32, dropout_rate: float = 0.0, seed: int = 0):
+        """``dropout_rate``: p of the nn.Dropout after the z-encoder / decoder LayerNorms (modules.py:115),
+        applied by ``run(..., train=True)`` with masks from the library's Philox stream keyed by ``seed``
+        (give every rank its own) and the step counter ``rng_step``."""
         if arena.likelihood not in ("zinb", "nb"):
             raise ValueError(f"ElboStep: likelihood must be 'zinb' or 'nb', got {arena.likelihood!r}")
         if not arena.flat.is_cuda:
@@ -88,6 +91,9 @@ class ElboStep:
         self.l_mean, self.l_var = float(l_mean), float(l_var)
         self.kl_weight, self.coeff = float(kl_weight), float(gene_loss_coeff)
         self.precision = precision
+        if not 0.0 <= float(dropout_rate) < 1.0:
+            raise ValueError(f"ElboStep: dropout_rate must be in [0, 1), got {dropout_rate}")
+        self.dropout_rate, self.seed, self.rng_step = float(dropout_rate), int(seed) & (2 ** 64 - 1), 0
         a = arena
         self.H = a.p(_enc("z_encoder", 0, "w")).shape[0]
         self.Hl = a.p(_enc("l_encoder", 0, "w")).shape[0]
@@ -140,9 +146,13 @@ class ElboStep:
     # ------------------------------------------------------------------------------------
     def run(self, x: torch.Tensor, eps_z: torch.Tensor, eps_l: torch.Tensor,
             cell_head_fn: Optional[Callable[[torch.Tensor], torch.Tensor]] = None,
-            backward: bool = True, loss_scale: float = 1.0, reducer=None) -> Dict[str, torch.Tensor]:
+            backward: bool = True, loss_scale: float = 1.0, reducer=None, train: Optional[bool] = None,
+            rng_step: Optional[int] = None) -> Dict[str, torch.Tensor]:
         """One step.  The returned tensors are VIEWS of the step workspace: they are overwritten by
-        the next ``run`` with the same batch size (clone what must survive)."""
+        the next ``run`` with the same batch size (clone what must survive).
+
+        ``train`` (default: ``backward``) switches the dropout masks on; ``rng_step`` picks the mask set
+        (default: a counter that advances with every training-mode run)."""
         a = self.a
         for t, name in ((x, "x"), (eps_z, "eps_z"), (eps_l, "eps_l")):
             ok_dtype = t.dtype == torch.float32 or (name == "x" and t.dtype == torch.uint8)
@@ -156,6 +166,13 @@ class ElboStep:
             raise ValueError("ElboStep: eps_z must be contiguous (B, L) and eps_l (B, 1)")
         cfg, ws, nbytes, v = self._plan(B, loss_scale)
         cfg.x_dtype = 1 if x.dtype == torch.uint8 else 0   # uint8 counts: the reference's on-disk format (f2)
+        train = backward if train is None else bool(train)
+        cfg.dropout_rate = self.dropout_rate if train else 0.0
+        cfg.rng_seed = self.seed
+        if rng_step is None:
+            rng_step = self.rng_step
+            self.rng_step += int(train and self.dropout_rate > 0)
+        cfg.rng_step = int(rng_step) & 0xFFFFFFFF
         stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         ldx = x.stride(0) if B > 1 else G
         rc = self.lib.vae_elbo_step_forward(C.byref(cfg), C.byref(self.params), x.data_ptr(), ldx, eps_z.data_ptr(),

@@ -90,6 +90,7 @@ class LitVAE(nn.Module):
         self.subject_batch_size = subject_batch_size
         self.use_gdro = use_gdro
         self.precision = precision
+        self.dropout_seed = int(torch.initial_seed()) & (2 ** 63 - 1)   # key of the fused step's dropout stream
         self.current_epoch = 0
         self.train_step = 0
         self.logged: Dict[str, float] = {}
@@ -301,6 +302,16 @@ class LitVAE(nn.Module):
         self._l1 = None
         return arena
 
+    def _hidden_dropout(self) -> float:
+        """p of the nn.Dropout layers the fused step applies (z-encoder and decoder FCLayers, modules.py:115)."""
+        net = self.network
+        ps = {float(m.p) for part in (net.z_encoder, net.decoder) for m in part.modules() if isinstance(m, nn.Dropout)}
+        if any(float(m.p) > 0 for m in net.l_encoder.modules() if isinstance(m, nn.Dropout)):
+            raise NotImplementedError("fused step: the library encoder is built without dropout (networks.py:215-222)")
+        if len(ps) > 1:
+            raise NotImplementedError(f"fused step: one dropout rate for the z-encoder and the decoder, got {sorted(ps)}")
+        return ps.pop() if ps else 0.0
+
     def training_step_fused(self, batch, eps_z=None, eps_l=None, loss_scale: float = 1.0, reducer=None):
         """One fused fwd+bwd pass; gradients land in ``arena.flat_grad`` (= every p.grad)."""
         self.train_step += 1
@@ -308,13 +319,14 @@ class LitVAE(nn.Module):
             self.attach_arena()
         if self.library_mean is None or self.library_var is None:
             raise ValueError("fused step needs the library prior constants (library_mean / library_var)")
-        if self.training and any(m.p > 0 for m in self.network.modules() if isinstance(m, nn.Dropout)) or \
-                (self.training and self.network.z_encoder.drop.p >= 1e-6):
-            raise NotImplementedError("fused step: dropout / gene-dropout are not on the HIP path yet (SURVEY §8 f4)")
-        if self._fused is None or self._fused.kl_weight != self.kl_weight:
+        if self.training and self.network.z_encoder.drop.p >= 1e-6:
+            raise NotImplementedError("fused step: gene-dropout is not on the HIP path yet (SURVEY §8 f4)")
+        p_drop = self._hidden_dropout() if self.training else 0.0
+        if self._fused is None or self._fused.kl_weight != self.kl_weight or self._fused.dropout_rate != p_drop:
             self._fused = ElboStep(self._arena, l_mean=float(self.library_mean), l_var=float(self.library_var),
                                    kl_weight=self.kl_weight, gene_loss_coeff=self.gene_loss_coeff,
-                                   precision=self.precision)
+                                   precision=self.precision, dropout_rate=p_drop, seed=self.dropout_seed)
+            self._fused.rng_step = self.train_step
         gene_vals, cell_prop_vals, cell_mask = batch[0], batch[1], batch[2]
         B, L = gene_vals.shape[0], self.network.n_latent
         if eps_z is None:  # same draw order as the reference: z-encoder noise, then library noise
