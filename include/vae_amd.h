@@ -170,6 +170,8 @@ int vae_loglik_elem_bwd(int zinb, const float* gout, int64_t ld_g, const float* 
                         int64_t ld_mu, const float* theta, int64_t ld_theta, const float* pi, int64_t ld_pi, int64_t B,
                         int64_t G, float* dmu, float* dtheta, float* dpi, void* stream);
 
+enum { VAE_X_F32 = 0, VAE_X_U8 = 1 };   /* dtype of a count matrix */
+
 /* ---- dropout ------------------------------------------------------------------------------------
  * nn.Dropout of FCLayers (modules.py:115): x[b, c] *= keep / (1 - p).  torch's generator cannot be
  * reproduced, so the stream is this library's own and documented: Philox4x32-10 with
@@ -180,6 +182,18 @@ int vae_loglik_elem_bwd(int zinb, const float* gout, int64_t ld_g, const float* 
  * forward and the backward pass; tests regenerate them on the host (tests/helpers.py).               */
 int vae_dropout_apply(float* x, int64_t ld, int64_t B, int64_t W, float p, uint64_t seed, uint32_t step, uint32_t site,
                       void* stream);
+
+/* GeneDropout on the z-encoder's input (modules.py:190-209,263) followed by the row normalisation
+ * (modules.py:264), training mode:  running = alpha*running + (1-alpha)*mean_b(x > 0);
+ * p_g = clip(p * running_g / mean(running), 0, 0.9);  gene g of cell b is KEPT with probability p_g;
+ * xn = xm / mean_g(xm) - 1 with xm = x * keep  (the reference's extra division by mean_g(p_g) is a per-batch
+ * scale that this normalisation cancels).  Mask stream: Philox4x32-10 as above with site 1 and counter element
+ * b * (G/4) + g/4; gene g is kept iff output word g%4 < threshold[g] = floor(p_g * 2^32).
+ * running (G, in/out) is the module's state; counts (G int32) and threshold (G uint32) are scratch / output;
+ * stats[0] = mean_g(p_g).  x_dtype: VAE_X_F32 / VAE_X_U8.  Needs G % 4 == 0.                              */
+int vae_gene_dropout(const void* x, int x_dtype, int64_t ldx, int64_t B, int64_t G, float p, float alpha, uint64_t seed,
+                     uint32_t step, float* running, int32_t* counts, uint32_t* threshold, float* stats, float* mean,
+                     float* xn, int64_t ld_xn, void* stream);
 
 /* ---- the whole training step -------------------------------------------------------------------
  * LitVAE.training_step (task.py:453-502) for dispersion "gene", no batch covariates, no input dropout:
@@ -192,7 +206,6 @@ int vae_dropout_apply(float* x, int64_t ld, int64_t B, int64_t W, float p, uint6
  *   heads_w= [decoder.px_scale_decoder.0.weight ; decoder.px_dropout_decoder.weight]        (2G, Hd)
  *            (NB: the first G rows only), and the matching bias vectors.                          */
 #define VAE_MAX_LAYERS 4
-enum { VAE_X_F32 = 0, VAE_X_U8 = 1 };
 
 typedef struct {
   int64_t B, G, H, Hl, L, Hd;
@@ -207,6 +220,9 @@ typedef struct {
   float dropout_rate;         /* p of nn.Dropout after the z-encoder / decoder LayerNorms (modules.py:115); 0 = off */
   uint32_t rng_step;          /* step counter of the dropout stream: change it every step               */
   uint64_t rng_seed;          /* key of the dropout stream (give every rank its own)                     */
+  float input_dropout_rate;   /* p of GeneDropout on the z-encoder input (modules.py:190-209); 0 = off   */
+  float input_dropout_alpha;  /* its running-average factor (0.95 in the reference)                      */
+  float* gene_running;        /* (G) device: GeneDropout.running_non_zero_means, updated by the forward  */
 } vae_step_config;
 
 typedef struct {
@@ -228,6 +244,7 @@ enum { VAE_WS_QZ_HEADS = 0, /* (B, L+1): [:, :L] = qz_m                         
        VAE_WS_SCALARS, /* 5 floats, see vae_elbo_reduce                                            */
        VAE_WS_DZ_EXTRA,/* (B, L): written by the CALLER between forward and backward (cell heads)  */
        VAE_WS_RECON,   /* (B) = -ll                                                                */
+       VAE_WS_GENE_THRESHOLD, /* (G) uint32 keep thresholds of GeneDropout, then 1 float mean_g(p_g); -1 when off */
        VAE_WS_NSLICES };
 int64_t vae_elbo_step_workspace_bytes(const vae_step_config* cfg);
 int64_t vae_elbo_step_ws_offset(const vae_step_config* cfg, int slice);

@@ -29,8 +29,9 @@ def sample_like_golden(t, G, stride):
 
 
 # ---- the library's documented dropout stream (include/vae_amd.h "dropout"), restated on the host ----
-def philox_word0(seed: int, step: int, site: int, elem: np.ndarray) -> np.ndarray:
-    """Word 0 of Philox4x32-10 with key (seed lo, seed hi) and counter (elem lo, elem hi, site, step)."""
+def philox4(seed: int, step: int, site: int, elem: np.ndarray) -> np.ndarray:
+    """The four output words (N, 4) of Philox4x32-10 with key (seed lo, seed hi) and counter
+    (elem lo, elem hi, site, step)."""
     elem = np.asarray(elem, dtype=np.uint64)
     m32 = np.uint64(0xFFFFFFFF)
     c0, c1 = elem & m32, elem >> np.uint64(32)
@@ -43,7 +44,19 @@ def philox_word0(seed: int, step: int, site: int, elem: np.ndarray) -> np.ndarra
         c0, c1, c2, c3 = ((p1 >> np.uint64(32)) ^ c1 ^ k0) & m32, p1 & m32, ((p0 >> np.uint64(32)) ^ c3 ^ k1) & m32, p0 & m32
         k0 = (k0 + np.uint64(0x9E3779B9)) & m32
         k1 = (k1 + np.uint64(0xBB67AE85)) & m32
-    return c0.astype(np.uint32)
+    return np.stack([c0, c1, c2, c3], axis=-1).astype(np.uint32)
+
+
+def philox_word0(seed: int, step: int, site: int, elem: np.ndarray) -> np.ndarray:
+    return philox4(seed, step, site, elem)[..., 0]
+
+
+def gene_dropout_keep(threshold: np.ndarray, seed: int, step: int, B: int) -> np.ndarray:
+    """(B, G) bool keep mask of GeneDropout on the z-encoder input (include/vae_amd.h, vae_gene_dropout):
+    site 1, counter element b * (G/4) + g/4, gene g kept iff word g%4 < threshold[g]."""
+    G = threshold.shape[0]
+    words = philox4(seed, step, 1, np.arange(B * (G // 4), dtype=np.uint64)).reshape(B, G)
+    return words < threshold.astype(np.uint32)[None, :]
 
 
 def dropout_multiplier(p: float, seed: int, step: int, site: int, B: int, W: int) -> np.ndarray:

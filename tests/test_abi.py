@@ -64,6 +64,10 @@ def test_workspace_queries():
     n = lib.vae_elbo_step_workspace_bytes(C.byref(cfg))
     assert n > 512 * 40000 * 4                                          # holds the logits at least
     offs = [lib.vae_elbo_step_ws_offset(C.byref(cfg), i) for i in range(len(_lib.WS_SLICES))]
+    assert offs[_lib.WS_SLICES.index("GENE_THRESHOLD")] == -1           # GeneDropout off: no such slice
+    cfg.input_dropout_rate = 0.5                                        # ... on: the workspace grows by xn_z
+    assert lib.vae_elbo_step_workspace_bytes(C.byref(cfg)) >= n + 512 * 20000 * 4
+    offs = [lib.vae_elbo_step_ws_offset(C.byref(cfg), i) for i in range(len(_lib.WS_SLICES))]
     assert all(o >= 0 for o in offs) and len(set(offs)) == len(offs)
     assert lib.vae_elbo_step_ws_offset(C.byref(cfg), 99) == -1
     cfg.n_layers = 9

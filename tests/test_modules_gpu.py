@@ -170,9 +170,12 @@ def test_fused_step_applies_the_modules_dropout():
     l3 = float(task.training_step_fused(batch, eps_z, eps_l)["loss"])
     assert abs(l3 - g) < TOL_CELL * abs(g)
     task.train()
-    task.network.z_encoder.drop.p = 0.5          # gene-dropout: not on the fused path yet -> loud refusal
-    with pytest.raises(NotImplementedError):
-        task.training_step_fused(batch, eps_z, eps_l)
+    task.network.z_encoder.drop.p = 0.5          # gene-dropout: shares its running statistic with the module
+    l4 = float(task.training_step_fused(batch, eps_z, eps_l)["loss"])
+    assert np.isfinite(l4) and task._fused.input_dropout_rate == 0.5
+    run = task.network.z_encoder.drop.running_non_zero_means
+    frac = (batch[0] > 0).float().mean(dim=0, keepdim=True)
+    assert run.shape == frac.shape and torch.allclose(run, 0.05 * frac, atol=1e-7)
 
 
 def test_module_forward_outputs():

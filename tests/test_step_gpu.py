@@ -169,6 +169,64 @@ def test_hidden_dropout_matches_oracle_with_the_same_masks(case):
     assert abs(float(ev["loss"]) - float(o_plain["loss"])) < TOL_CELL * abs(float(o_plain["loss"]))
 
 
+@pytest.mark.parametrize("n_layers,counts", [(1, "f32"), (2, "f32"), (1, "u8")])
+def test_gene_dropout_matches_oracle_with_the_same_mask(n_layers, counts):
+    """Row f4: GeneDropout on the z-encoder input (modules.py:190-209) plus hidden dropout = the shipped
+    configuration's regularisers.  Two training steps: the running non-zero statistic, the keep probabilities
+    (against the reference's formula in fp64) and, with the host-regenerated masks, the whole step vs the oracle."""
+    from oracle import vae_oracle as O
+    from vae_amd.arena import ParamArena
+    from vae_amd.step import ElboStep
+    from helpers import dropout_multiplier, gene_dropout_keep
+    B, G, H, Hd, Hl, L = 48, 400, 64, 48, 32, 6
+    p_in, p_hid, alpha, seed = 0.5, 0.25, 0.95, 20240607
+    p = O.init_params(G, H, Hd, Hl, L, n_layers, seed=9)
+    arena = ParamArena(p, n_layers, "zinb", "cuda")
+    gen = torch.Generator().manual_seed(10)
+    step = ElboStep(arena, l_mean=5.0, l_var=1.5, dropout_rate=p_hid, seed=seed, input_dropout_rate=p_in,
+                    input_dropout_alpha=alpha)
+    running = np.zeros(G)
+    for it in range(2):
+        x = O.synthetic_counts(B, G, seed=11 + it, zero_inflate=0.4).clamp(max=255)
+        eps_z, eps_l = torch.randn(B, L, generator=gen), torch.randn(B, 1, generator=gen)
+        xd = x.to(torch.uint8).cuda() if counts == "u8" else x.cuda()
+        out = step.run(xd, eps_z.cuda(), eps_l.cuda(), rng_step=100 + it)
+        torch.cuda.synchronize()
+        # the reference's statistic and keep probabilities (modules.py:202-205), fp64
+        running = alpha * running + (1 - alpha) * (x.numpy() > 0).mean(axis=0)
+        pg = np.clip(p_in * running / running.mean(), 0.0, 0.9)
+        assert rel_err(step.gene_running.cpu().numpy(), running) < 1e-6
+        thr = out["gene_threshold"].cpu().numpy().view(np.uint32)
+        assert np.max(np.abs(thr.astype(np.float64) - pg * 2.0 ** 32)) < 2.0 ** 32 * 2e-6
+        assert abs(float(out["gene_p_mean"]) - pg.mean()) < 1e-6
+        keep = gene_dropout_keep(thr, seed, 100 + it, B)
+        assert abs(keep.mean() - pg.mean()) < 0.02
+        x_z = x.double() * torch.from_numpy(keep).double() / pg.mean()          # modules.py:209
+        masks = {"z_encoder": [torch.from_numpy(dropout_multiplier(p_hid, seed, 100 + it, 4 * n, B, H)).double() for n in range(n_layers)],
+                 "decoder": [torch.from_numpy(dropout_multiplier(p_hid, seed, 100 + it, 4 * n + 2, B, Hd)).double() for n in range(n_layers)]}
+        o_out, o_grads = O.training_step_with_grads({k: v.double() for k, v in p.items()}, x.double(), eps_z.double(),
+                                                    eps_l.double(), n_layers=n_layers, likelihood="zinb", l_mean=5.0, l_var=1.5,
+                                                    drop_masks=masks, x_z=x_z)
+        for k in ("qz_m", "z", "library", "recon", "kl_z", "kl_l"):
+            g = o_out[k].numpy()
+            assert rel_err(out[k].cpu().numpy().reshape(g.shape), g) < TOL_CELL, (it, k)
+        assert abs(float(out["loss"]) - float(o_out["loss"])) < TOL_CELL * abs(float(o_out["loss"]))
+        n = 0
+        for k, v in arena.grads().items():
+            if v is None or o_grads[k] is None:
+                continue
+            assert rel_err(v.cpu().numpy(), o_grads[k].numpy()) < TOL_GRAD, (it, k)
+            n += 1
+        assert n >= 15
+    # evaluation: no masks, no state update
+    before = step.gene_running.clone()
+    ev = step.run(xd, eps_z.cuda(), eps_l.cuda(), backward=False)
+    o_plain = O.training_step({k: v.double() for k, v in p.items()}, x.double(), eps_z.double(), eps_l.double(),
+                              n_layers=n_layers, likelihood="zinb", l_mean=5.0, l_var=1.5)
+    assert abs(float(ev["loss"]) - float(o_plain["loss"])) < TOL_CELL * abs(float(o_plain["loss"]))
+    assert torch.equal(before, step.gene_running) and "gene_threshold" not in ev
+
+
 def test_bf16_mode_against_bf16_oracle():
     """bf16 GEMM operands / fp32 accumulate: same rounding points as the oracle's bf16 mode;
     stated tolerance 2e-3 on per-cell terms, 2e-2 on gradients (bf16 has 8 mantissa bits and the

@@ -28,6 +28,8 @@ SIGNATURES = {
     "vae_elbo_step_px_rate": (_i32, [_ptr, _ptr, _i64, _ptr, _i64, _ptr]),
     "vae_l1_penalty": (_i32, [_ptr, _ptr, _i64, _ptr, _i32, C.c_double, _ptr, _i64, _ptr, _ptr]),
     "vae_dropout_apply": (_i32, [_ptr, _i64, _i64, _i64, _f32, C.c_uint64, C.c_uint32, C.c_uint32, _ptr]),
+    "vae_gene_dropout": (_i32, [_ptr, _i32, _i64, _i64, _i64, _f32, _f32, C.c_uint64, C.c_uint32, _ptr, _ptr, _ptr, _ptr, _ptr,
+                                _ptr, _i64, _ptr]),
     "vae_row_mean": (_i32, [_ptr, _i64, _i64, _i64, _ptr, _ptr]),
     "vae_normalize_rows": (_i32, [_ptr, _i64, _i64, _i64, _ptr, _ptr, _i64, _ptr]),
     "vae_normalize_rows_u8": (_i32, [_ptr, _i64, _i64, _i64, _ptr, _ptr, _i64, _ptr]),
@@ -77,7 +79,8 @@ class StepConfig(C.Structure):
     _fields_ = [("B", _i64), ("G", _i64), ("H", _i64), ("Hl", _i64), ("L", _i64), ("Hd", _i64),
                 ("n_layers", C.c_int32), ("zinb", C.c_int32), ("precision", C.c_int32),
                 ("l_mean", _f32), ("l_var", _f32), ("kl_weight", _f32), ("gene_loss_coeff", _f32), ("loss_scale", _f32),
-                ("x_dtype", C.c_int32), ("dropout_rate", _f32), ("rng_step", C.c_uint32), ("rng_seed", C.c_uint64)]
+                ("x_dtype", C.c_int32), ("dropout_rate", _f32), ("rng_step", C.c_uint32), ("rng_seed", C.c_uint64),
+                ("input_dropout_rate", _f32), ("input_dropout_alpha", _f32), ("gene_running", _ptr)]
 
 
 class StepTensors(C.Structure):
@@ -91,7 +94,8 @@ class StepTensors(C.Structure):
                 ("heads_w", _ptr), ("heads_b", _ptr)]
 
 
-WS_SLICES = ("QZ_HEADS", "QZ_V", "Z", "KL_Z", "QL_HEADS", "QL_V", "LIBRARY", "KL_L", "LL", "SCALARS", "DZ_EXTRA", "RECON")
+WS_SLICES = ("QZ_HEADS", "QZ_V", "Z", "KL_Z", "QL_HEADS", "QL_V", "LIBRARY", "KL_L", "LL", "SCALARS", "DZ_EXTRA", "RECON",
+             "GENE_THRESHOLD")
 
 _lib = None
 

@@ -12,7 +12,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-__device__ __forceinline__ uint32_t vae_philox_word0(uint64_t seed, uint32_t step, uint32_t site, uint64_t elem) {
+__device__ __forceinline__ uint4 vae_philox4(uint64_t seed, uint32_t step, uint32_t site, uint64_t elem) {
   uint32_t c0 = (uint32_t)elem, c1 = (uint32_t)(elem >> 32), c2 = site, c3 = step;
   uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
 #pragma unroll
@@ -26,7 +26,10 @@ __device__ __forceinline__ uint32_t vae_philox_word0(uint64_t seed, uint32_t ste
     k0 += 0x9E3779B9u;
     k1 += 0xBB67AE85u;
   }
-  return c0;
+  return make_uint4(c0, c1, c2, c3);
+}
+__device__ __forceinline__ uint32_t vae_philox_word0(uint64_t seed, uint32_t step, uint32_t site, uint64_t elem) {
+  return vae_philox4(seed, step, site, elem).x;
 }
 
 // Dropout as nn.Dropout applies it (modules.py:115): kept values are scaled by 1 / (1 - p).
@@ -45,6 +48,9 @@ struct VaeDropout {
 // encoder is built with dropout_rate 0 (networks.py:215-222) and has no site
 #define VAE_SITE_ENC_Z(layer) (4u * (uint32_t)(layer) + 0u)
 #define VAE_SITE_DEC(layer) (4u * (uint32_t)(layer) + 2u)
+// GeneDropout on the z-encoder's input (modules.py:190-209): counter element = cell * ceil(G / 4) + g / 4,
+// output word g % 4; gene g of the cell is KEPT iff that word < threshold[g] = floor(p_g * 2^32)
+#define VAE_SITE_GENES 1u
 
 static inline VaeDropout vae_make_dropout(float p, uint64_t seed, uint32_t step) {
   VaeDropout d;

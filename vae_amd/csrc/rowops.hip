@@ -7,6 +7,7 @@
 // registers, row reductions are wavefront shuffles, per-column reductions over cells are
 // accumulated in registers across the rows a wave visits, combined through LDS and flushed
 // with one float atomic per column per workgroup.
+#include "../../include/vae_amd.h"
 #include "common.h"
 #include "philox.h"
 
@@ -367,6 +368,114 @@ extern "C" int vae_row_mean(const float* x, int64_t ldx, int64_t B, int64_t G, f
                      mean);
   VAE_CHECK_LAUNCH("vae_row_mean");
   return VAE_OK;
+}
+
+// ---- GeneDropout (modules.py:190-209), z-encoder input only ---------------------------------------
+// counts[g] += #cells of this chunk with x[b,g] > 0   (integer atomics: order-independent, deterministic)
+template <typename XT>
+__global__ __launch_bounds__(256) void gene_count_kernel(const XT* __restrict__ x, int64_t ld, int B, int G, int rows,
+                                                         int* __restrict__ counts) {
+  const int g = blockIdx.x * 256 + threadIdx.x;
+  if (g >= G) return;
+  const int b0 = blockIdx.y * rows, b1 = min(B, b0 + rows);
+  int c = 0;
+  for (int b = b0; b < b1; ++b) c += (float)x[(int64_t)b * ld + g] > 0.f;
+  if (c) atomicAdd(counts + g, c);
+}
+// One workgroup: running = alpha * running + (1 - alpha) * counts / B;  p_g = clip(p * running_g / mean(running), 0, 0.9);
+// threshold_g = floor(p_g * 2^32); stats = {mean_g p_g}.
+__global__ __launch_bounds__(1024) void gene_prob_kernel(const int* __restrict__ counts, int B, int G, float p, float alpha,
+                                                         float* __restrict__ running, uint32_t* __restrict__ thr,
+                                                         float* __restrict__ stats) {
+  __shared__ float red[16];
+  float s = 0.f;
+  for (int g = threadIdx.x; g < G; g += 1024) {
+    const float nz = (float)counts[g] / (float)B;
+    const float r = alpha * running[g] + (1.f - alpha) * nz;
+    running[g] = r;
+    s += r;
+  }
+  s = block_sum<16>(s, red);
+  const float rmean = s / (float)G;
+  __syncthreads();
+  float ps = 0.f;
+  for (int g = threadIdx.x; g < G; g += 1024) {
+    const float pg = fminf(fmaxf(p * running[g] / rmean, 0.f), 0.9f);
+    thr[g] = (uint32_t)((double)pg * 4294967296.0);   // pg <= 0.9: no overflow
+    ps += pg;
+  }
+  ps = block_sum<16>(ps, red);
+  if (threadIdx.x == 0) stats[0] = ps / (float)G;
+}
+// x/mean - 1 of the MASKED row: xz = x * keep, mean over all G genes, out = xz / mean - 1.  The reference also
+// divides the masked counts by mean_g(p_g) (modules.py:209); the row normalisation that follows (modules.py:264)
+// cancels any per-batch scale, so it is not applied.  Requires G % 4 == 0 (vector path), any G.
+template <typename XT>
+__global__ __launch_bounds__(256) void normalize_rows_masked_kernel(const XT* __restrict__ x, int64_t ld, int B, int G,
+                                                                    const uint32_t* __restrict__ thr, uint64_t seed,
+                                                                    uint32_t step, float* __restrict__ mean,
+                                                                    float* __restrict__ xn, int64_t ld_xn) {
+  __shared__ float red[4];
+  const int b = blockIdx.x;
+  const XT* row = x + (int64_t)b * ld;
+  float* orow = xn + (int64_t)b * ld_xn;
+  const int n4 = G >> 2;
+  auto masked = [&](int i) {
+    float4 v = load4(row, i);
+    const uint4 t = reinterpret_cast<const uint4*>(thr)[i];
+    const uint4 w = vae_philox4(seed, step, VAE_SITE_GENES, (uint64_t)b * (uint64_t)n4 + (uint64_t)i);
+    v.x = w.x < t.x ? v.x : 0.f; v.y = w.y < t.y ? v.y : 0.f;
+    v.z = w.z < t.z ? v.z : 0.f; v.w = w.w < t.w ? v.w : 0.f;
+    return v;
+  };
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n4; i += 256) {
+    const float4 v = masked(i);
+    s += (v.x + v.y) + (v.z + v.w);
+  }
+  s = block_sum<4>(s, red);
+  const float m = s / (float)G;
+  if (threadIdx.x == 0) mean[b] = m;
+  for (int i = threadIdx.x; i < n4; i += 256) {
+    float4 v = masked(i);
+    v.x = v.x / m - 1.f; v.y = v.y / m - 1.f; v.z = v.z / m - 1.f; v.w = v.w / m - 1.f;
+    reinterpret_cast<float4*>(orow)[i] = v;
+  }
+}
+
+template <typename XT>
+static int gene_dropout_impl(const XT* x, int64_t ldx, int64_t B, int64_t G, float p, float alpha, uint64_t seed,
+                             uint32_t step, float* running, int* counts, uint32_t* thr, float* stats, float* mean, float* xn,
+                             int64_t ld_xn, void* stream) {
+  VAE_REQUIRE(x && running && counts && thr && stats && mean && xn && B > 0 && G > 0 && ldx >= G && ld_xn >= G,
+              "vae_gene_dropout: bad arguments");
+  VAE_REQUIRE(p > 0.f && p <= 1.f && alpha >= 0.f && alpha <= 1.f, "vae_gene_dropout: p in (0, 1], alpha in [0, 1]");
+  const bool x_ok = sizeof(XT) == 1 ? ((reinterpret_cast<uintptr_t>(x) & 3u) == 0) : vae_aligned16(x);
+  VAE_REQUIRE(G % 4 == 0 && ldx % 4 == 0 && ld_xn % 4 == 0 && x_ok && vae_aligned16(xn) && vae_aligned16(thr),
+              "vae_gene_dropout: needs G %% 4 == 0, leading dimensions %% 4 == 0 and aligned rows");
+  hipStream_t st = (hipStream_t)stream;
+  const int rows = 32;
+  VAE_REQUIRE(hipMemsetAsync(counts, 0, (size_t)G * sizeof(int), st) == hipSuccess, "vae_gene_dropout: hipMemsetAsync failed");
+  hipLaunchKernelGGL((gene_count_kernel<XT>), dim3((unsigned)((G + 255) / 256), (unsigned)((B + rows - 1) / rows)), dim3(256), 0,
+                     st, x, ldx, (int)B, (int)G, rows, counts);
+  VAE_CHECK_LAUNCH("vae_gene_dropout(count)");
+  hipLaunchKernelGGL(gene_prob_kernel, dim3(1), dim3(1024), 0, st, counts, (int)B, (int)G, p, alpha, running, thr, stats);
+  VAE_CHECK_LAUNCH("vae_gene_dropout(prob)");
+  hipLaunchKernelGGL((normalize_rows_masked_kernel<XT>), dim3((unsigned)B), dim3(256), 0, st, x, ldx, (int)B, (int)G, thr,
+                     seed, step, mean, xn, ld_xn);
+  VAE_CHECK_LAUNCH("vae_gene_dropout(normalize)");
+  return VAE_OK;
+}
+
+extern "C" int vae_gene_dropout(const void* x, int x_dtype, int64_t ldx, int64_t B, int64_t G, float p, float alpha,
+                                uint64_t seed, uint32_t step, float* running, int32_t* counts, uint32_t* threshold,
+                                float* stats, float* mean, float* xn, int64_t ld_xn, void* stream) {
+  VAE_REQUIRE(x_dtype == VAE_X_F32 || x_dtype == VAE_X_U8, "vae_gene_dropout: bad x_dtype");
+  if (x_dtype == VAE_X_U8)
+    return gene_dropout_impl<uint8_t>((const uint8_t*)x, ldx, B, G, p, alpha, seed, step, running, counts, threshold, stats,
+                                      mean, xn, ld_xn, stream);
+  return gene_dropout_impl<float>((const float*)x, ldx, B, G, p, alpha, seed, step, running, counts, threshold, stats, mean,
+                                  xn, ld_xn, stream);
 }
 
 template <typename XT>

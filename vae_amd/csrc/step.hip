@@ -20,6 +20,7 @@ struct Layout {
   int64_t logits, table, ll, recon, rowmax, rowsum, S, scalars;
   int64_t dz_extra, dlibrary, dheads_z, dheads_l, dpre_enc0, dh, dpx, dz;
   int64_t dbet_d, dgam_d, dbet_e, dgam_e;  // per-cell LayerNorm-gradient rows of the fused middle
+  int64_t xn_z, mean_z, gene_thr, gene_counts;  // GeneDropout: the z-encoder's own normalised counts (-1: off)
   int64_t scratch;        // split-K slabs / column-sum slabs (shared, used by one launch at a time)
   int64_t scratch_floats;
   int64_t total;
@@ -57,10 +58,18 @@ bool make_layout(const vae_step_config& c, Layout* lo) {
   lo->dpre_enc0 = take(B * (H + Hl)); lo->dh = take(B * H); lo->dpx = take(B * Hd); lo->dz = take(B * L);
   lo->dbet_d = take(B * Hd); lo->dgam_d = take(B * Hd);
   lo->dbet_e = take(B * (H + Hl)); lo->dgam_e = take(B * (H + Hl));
+  lo->xn_z = lo->mean_z = lo->gene_thr = lo->gene_counts = -1;
+  if (c.input_dropout_rate > 0.f) {
+    lo->xn_z = take(B * lo->ld_xn);
+    lo->mean_z = take(B);
+    lo->gene_thr = take(G + 4);      // G thresholds, then mean_g(p_g)
+    lo->gene_counts = take(G);
+  }
   // scratch: the largest split-K / column-slab need of any launch in the step
   int64_t s = 0;
   auto gw = [&](int64_t M, int64_t N, int64_t K) { s = maxi(s, vae_gemm_workspace_bytes(M, N, K)); };
   gw(B, H + Hl, G); gw(H + Hl, G, B);                       // encoder first layer fwd / wgrad
+  gw(B, H, G); gw(H, G, B); gw(B, Hl, G); gw(Hl, G, B);     // the same per encoder (GeneDropout)
   gw(B, H, H); gw(H, H, B);                                 // deeper encoder layers
   gw(B, L + 1, H); gw(L + 1, H, B); gw(B, H, L + 1);        // z heads
   gw(B, 2, Hl); gw(2, Hl, B); gw(B, Hl, 2);                 // library heads
@@ -109,6 +118,10 @@ int check_common(const vae_step_config* cfg, const void* a, const void* b, const
   if (!(cfg->l_var > 0.f)) return vae_set_error(VAE_ERR_ARG, "%s: l_var must be positive", who);
   if (!(cfg->dropout_rate >= 0.f && cfg->dropout_rate < 1.f))
     return vae_set_error(VAE_ERR_ARG, "%s: dropout_rate must be in [0, 1)", who);
+  if (!(cfg->input_dropout_rate >= 0.f && cfg->input_dropout_rate <= 1.f))
+    return vae_set_error(VAE_ERR_ARG, "%s: input_dropout_rate must be in [0, 1]", who);
+  if (cfg->input_dropout_rate > 0.f && (!cfg->gene_running || cfg->G % 4 != 0))
+    return vae_set_error(VAE_ERR_ARG, "%s: input dropout needs gene_running and G %% 4 == 0", who);
   if (ws_bytes < lo->total * 4)
     return vae_set_error(VAE_ERR_ARG, "%s: workspace too small: %lld < %lld bytes", who, (long long)ws_bytes,
                          (long long)(lo->total * 4));
@@ -140,6 +153,7 @@ extern "C" int64_t vae_elbo_step_ws_offset(const vae_step_config* cfg, int slice
     case VAE_WS_SCALARS: return lo.scalars;
     case VAE_WS_DZ_EXTRA: return lo.dz_extra;
     case VAE_WS_RECON: return lo.recon;
+    case VAE_WS_GENE_THRESHOLD: return lo.gene_thr;
     default: return -1;
   }
 }
@@ -159,19 +173,39 @@ extern "C" int vae_elbo_step_forward(const vae_step_config* cfg, const vae_step_
   // encoders: x/mean-1 -> Linear(G, H+Hl) -> GELU -> LayerNorm (z and library halves)
   if (u8) TRY(vae_normalize_rows_u8(x8, ldx, B, G, ws + lo.mean, ws + lo.xn, lo.ld_xn, stream));
   else TRY(vae_normalize_rows(x, ldx, B, G, ws + lo.mean, ws + lo.xn, lo.ld_xn, stream));
+  // GeneDropout (training): the z-encoder reads its own masked + normalised counts, the library encoder xn
+  const bool gd = c.input_dropout_rate > 0.f;
+  if (gd)
+    TRY(vae_gene_dropout(xv, c.x_dtype, ldx, B, G, c.input_dropout_rate, c.input_dropout_alpha, c.rng_seed, c.rng_step,
+                         c.gene_running, (int32_t*)(ws + lo.gene_counts), (uint32_t*)(ws + lo.gene_thr),
+                         ws + lo.gene_thr + G, ws + lo.mean_z, ws + lo.xn_z, lo.ld_xn, stream));
   const float* px;
   if (vae_mid_supported(c)) {
     // one launch from the encoder slabs to the decoder hidden layer
     int nslab = 0;
-    TRY(vae_gemm_slabs(VAE_NT, c.precision, B, HE, G, ws + lo.xn, lo.ld_xn, p->enc_w0, G, ws + lo.scratch,
-                       lo.scratch_floats * 4, &nslab, stream));
-    TRY(vae_mid_forward(c, p, ws + lo.scratch, nslab, eps_z, eps_l, ws + lo.pre_enc0, ws + lo.h_enc0, ws + lo.ln_mz[0],
+    const float* slabs = ws + lo.scratch;
+    if (gd) {  // two products (different inputs), left without bias in pre_enc0 = a single "slab"
+      TRY(k.gemm(VAE_NT, B, H, G, ws + lo.xn_z, lo.ld_xn, p->enc_w0, G, ws + lo.pre_enc0, HE, nullptr, nullptr, 0));
+      TRY(k.gemm(VAE_NT, B, Hl, G, ws + lo.xn, lo.ld_xn, p->enc_w0 + H * G, G, ws + lo.pre_enc0 + H, HE, nullptr, nullptr, 0));
+      slabs = ws + lo.pre_enc0;
+      nslab = 1;
+    } else {
+      TRY(vae_gemm_slabs(VAE_NT, c.precision, B, HE, G, ws + lo.xn, lo.ld_xn, p->enc_w0, G, ws + lo.scratch,
+                         lo.scratch_floats * 4, &nslab, stream));
+    }
+    TRY(vae_mid_forward(c, p, slabs, nslab, eps_z, eps_l, ws + lo.pre_enc0, ws + lo.h_enc0, ws + lo.ln_mz[0],
                         ws + lo.ln_rz[0], ws + lo.ln_ml, ws + lo.ln_rl, ws + lo.heads_z, ws + lo.heads_l, ws + lo.qz_v,
                         ws + lo.z, ws + lo.kl_z, ws + lo.ql_v, ws + lo.library, ws + lo.kl_l, ws + lo.dec_pre[0],
                         ws + lo.dec_h[0], ws + lo.ln_md[0], ws + lo.ln_rd[0], stream));
     px = ws + lo.dec_h[0];
   } else {
-    TRY(k.gemm(VAE_NT, B, HE, G, ws + lo.xn, lo.ld_xn, p->enc_w0, G, ws + lo.pre_enc0, HE, p->enc_b0, nullptr, 0));
+    if (gd) {
+      TRY(k.gemm(VAE_NT, B, H, G, ws + lo.xn_z, lo.ld_xn, p->enc_w0, G, ws + lo.pre_enc0, HE, p->enc_b0, nullptr, 0));
+      TRY(k.gemm(VAE_NT, B, Hl, G, ws + lo.xn, lo.ld_xn, p->enc_w0 + H * G, G, ws + lo.pre_enc0 + H, HE, p->enc_b0 + H,
+                 nullptr, 0));
+    } else {
+      TRY(k.gemm(VAE_NT, B, HE, G, ws + lo.xn, lo.ld_xn, p->enc_w0, G, ws + lo.pre_enc0, HE, p->enc_b0, nullptr, 0));
+    }
     TRY(vae_gelu_ln_fwd(ws + lo.pre_enc0, HE, p->encz_ln_g[0], p->encz_ln_b[0], B, H, ws + lo.h_enc0, HE,
                         ws + lo.ln_mz[0], ws + lo.ln_rz[0], stream));
     TRY(vae_gelu_ln_fwd(ws + lo.pre_enc0 + H, HE, p->encl_ln_g, p->encl_ln_b, B, Hl, ws + lo.h_enc0 + H, HE,
@@ -339,6 +373,11 @@ extern "C" int vae_elbo_step_backward(const vae_step_config* cfg, const vae_step
     TRY(vae_gelu_ln_bwd(ws + lo.dpre_enc0 + H, HE, ws + lo.pre_enc0 + H, HE, ws + lo.ln_ml, ws + lo.ln_rl, p->encl_ln_g, B,
                         Hl, ws + lo.dpre_enc0 + H, HE, g->encl_ln_g, g->encl_ln_b, g->enc_b0 + H, stream));
   }
-  TRY(k.gemm(VAE_TN, HE, G, B, ws + lo.dpre_enc0, HE, ws + lo.xn, lo.ld_xn, g->enc_w0, G, nullptr, nullptr, 0));
+  if (c.input_dropout_rate > 0.f) {  // GeneDropout: each encoder's weight gradient over its own input
+    TRY(k.gemm(VAE_TN, H, G, B, ws + lo.dpre_enc0, HE, ws + lo.xn_z, lo.ld_xn, g->enc_w0, G, nullptr, nullptr, 0));
+    TRY(k.gemm(VAE_TN, Hl, G, B, ws + lo.dpre_enc0 + H, HE, ws + lo.xn, lo.ld_xn, g->enc_w0 + H * G, G, nullptr, nullptr, 0));
+  } else {
+    TRY(k.gemm(VAE_TN, HE, G, B, ws + lo.dpre_enc0, HE, ws + lo.xn, lo.ld_xn, g->enc_w0, G, nullptr, nullptr, 0));
+  }
   return VAE_OK;
 }

@@ -76,10 +76,16 @@ class ElboStep:
     """
 
     def __init__(self, arena: ParamArena, *, l_mean: float, l_var: float, kl_weight: float = 1.0,
-                 gene_loss_coeff: float = 5e-3, precision: int = ops.FP32, dropout_rate: float = 0.0, seed: int = 0):
+                 gene_loss_coeff: float = 5e-3, precision: int = ops.FP32, dropout_rate: float = 0.0, seed: int = 0,
+                 input_dropout_rate: float = 0.0, input_dropout_alpha: float = 0.95,
+                 gene_running: Optional[torch.Tensor] = None):
         """``dropout_rate``: p of the nn.Dropout after the z-encoder / decoder LayerNorms (modules.py:115),
         applied by ``run(..., train=True)`` with masks from the library's Philox stream keyed by ``seed``
-        (give every rank its own) and the step counter ``rng_step``."""
+        (give every rank its own) and the step counter ``rng_step``.
+
+        ``input_dropout_rate``: p of GeneDropout on the z-encoder's input (modules.py:190-209);
+        ``gene_running`` (G,) is its ``running_non_zero_means`` state (created as zeros when omitted, updated in
+        place by every training-mode run)."""
         if arena.likelihood not in ("zinb", "nb"):
             raise ValueError(f"ElboStep: likelihood must be 'zinb' or 'nb', got {arena.likelihood!r}")
         if not arena.flat.is_cuda:
@@ -94,6 +100,11 @@ class ElboStep:
         if not 0.0 <= float(dropout_rate) < 1.0:
             raise ValueError(f"ElboStep: dropout_rate must be in [0, 1), got {dropout_rate}")
         self.dropout_rate, self.seed, self.rng_step = float(dropout_rate), int(seed) & (2 ** 64 - 1), 0
+        if not 0.0 <= float(input_dropout_rate) <= 1.0:
+            raise ValueError(f"ElboStep: input_dropout_rate must be in [0, 1], got {input_dropout_rate}")
+        self.input_dropout_rate = float(input_dropout_rate) if input_dropout_rate >= 1e-6 else 0.0   # modules.py:199
+        self.input_dropout_alpha = float(input_dropout_alpha)
+        self.gene_running = gene_running
         a = arena
         self.H = a.p(_enc("z_encoder", 0, "w")).shape[0]
         self.Hl = a.p(_enc("l_encoder", 0, "w")).shape[0]
@@ -102,6 +113,12 @@ class ElboStep:
         self.Hd = a.p(_dec(0, "w")).shape[0]
         if self.n_layers > _lib.VAE_MAX_LAYERS:
             raise ValueError(f"ElboStep: at most {_lib.VAE_MAX_LAYERS} layers")
+        if self.input_dropout_rate > 0:
+            if self.gene_running is None:
+                self.gene_running = torch.zeros(self.G, dtype=torch.float32, device=a.device)
+            r = self.gene_running
+            if not r.is_cuda or r.dtype != torch.float32 or r.numel() != self.G or not r.is_contiguous():
+                raise ValueError("ElboStep: gene_running must be a contiguous float32 GPU tensor of G elements")
         self.params = _tensors(a.p, a.pcat, self.n_layers, self.zinb)
         self.grads = _tensors(a.g, a.gcat, self.n_layers, self.zinb)
         self._plans: Dict[int, tuple] = {}
@@ -109,13 +126,19 @@ class ElboStep:
         self._zero = None
         self._last_fwd = None
 
-    def _plan(self, B: int, loss_scale: float):
-        """Config struct, workspace and named views for batch size B (cached)."""
-        key = B
+    def _plan(self, B: int, loss_scale: float, train: bool = False):
+        """Config struct, workspace and named views for batch size B (cached).  GeneDropout changes the
+        workspace layout, so training-mode plans with it are kept apart."""
+        gene_drop = bool(train and self.input_dropout_rate > 0)
+        key = (B, gene_drop)
         if key not in self._plans:
             cfg = _lib.StepConfig(B=B, G=self.G, H=self.H, Hl=self.Hl, L=self.L, Hd=self.Hd, n_layers=self.n_layers,
                                   zinb=int(self.zinb), precision=self.precision, l_mean=self.l_mean, l_var=self.l_var,
                                   kl_weight=self.kl_weight, gene_loss_coeff=self.coeff, loss_scale=1.0)
+            if gene_drop:
+                cfg.input_dropout_rate = self.input_dropout_rate
+                cfg.input_dropout_alpha = self.input_dropout_alpha
+                cfg.gene_running = self.gene_running.data_ptr()
             nbytes = self.lib.vae_elbo_step_workspace_bytes(C.byref(cfg))
             if nbytes <= 0:
                 raise RuntimeError("vae_amd: bad step configuration")
@@ -136,6 +159,10 @@ class ElboStep:
                 dz_extra=ws[off["DZ_EXTRA"]:off["DZ_EXTRA"] + B * L].view(B, L),
                 recon=ws[off["RECON"]:off["RECON"] + B],
             )
+            if gene_drop:   # keep thresholds floor(p_g * 2^32) as int32 bit patterns, then mean_g(p_g)
+                o = off["GENE_THRESHOLD"]
+                v["gene_threshold"] = ws[o:o + self.G].view(torch.int32)
+                v["gene_p_mean"] = ws[o + self.G:o + self.G + 1]
             self._plans[key] = (cfg, ws, nbytes, v)
         cfg, ws, nbytes, v = self._plans[key]
         cfg.loss_scale = float(loss_scale)
@@ -164,14 +191,14 @@ class ElboStep:
             raise ValueError(f"ElboStep: x has {G} genes, model has {self.G}")
         if eps_z.shape != (B, L) or eps_l.shape != (B, 1) or not eps_z.is_contiguous() or not eps_l.is_contiguous():
             raise ValueError("ElboStep: eps_z must be contiguous (B, L) and eps_l (B, 1)")
-        cfg, ws, nbytes, v = self._plan(B, loss_scale)
-        cfg.x_dtype = 1 if x.dtype == torch.uint8 else 0   # uint8 counts: the reference's on-disk format (f2)
         train = backward if train is None else bool(train)
+        cfg, ws, nbytes, v = self._plan(B, loss_scale, train)
+        cfg.x_dtype = 1 if x.dtype == torch.uint8 else 0   # uint8 counts: the reference's on-disk format (f2)
         cfg.dropout_rate = self.dropout_rate if train else 0.0
         cfg.rng_seed = self.seed
         if rng_step is None:
             rng_step = self.rng_step
-            self.rng_step += int(train and self.dropout_rate > 0)
+            self.rng_step += int(train and (self.dropout_rate > 0 or self.input_dropout_rate > 0))
         cfg.rng_step = int(rng_step) & 0xFFFFFFFF
         stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         ldx = x.stride(0) if B > 1 else G
@@ -182,6 +209,8 @@ class ElboStep:
         out = dict(qz_m=v["heads_z"][:, :L], qz_v=v["qz_v"], z=v["z"], ql_m=v["heads_l"][:, :1], ql_v=v["ql_v"],
                    library=v["library"], recon=v["recon"], kl_z=v["kl_z"], kl_l=v["kl_l"], recon_mean=s[0],
                    gene_loss=s[3], scalars=s)
+        if "gene_threshold" in v:
+            out["gene_threshold"], out["gene_p_mean"] = v["gene_threshold"], v["gene_p_mean"]
 
         # ---------------- cell heads (tiny; torch autograd on z only) ----------------
         use_extra = 0

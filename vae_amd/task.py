@@ -319,13 +319,26 @@ class LitVAE(nn.Module):
             self.attach_arena()
         if self.library_mean is None or self.library_var is None:
             raise ValueError("fused step needs the library prior constants (library_mean / library_var)")
-        if self.training and self.network.z_encoder.drop.p >= 1e-6:
-            raise NotImplementedError("fused step: gene-dropout is not on the HIP path yet (SURVEY §8 f4)")
         p_drop = self._hidden_dropout() if self.training else 0.0
-        if self._fused is None or self._fused.kl_weight != self.kl_weight or self._fused.dropout_rate != p_drop:
+        gdrop = self.network.z_encoder.drop
+        p_in = float(gdrop.p) if self.training and gdrop.p >= 1e-6 else 0.0
+        if getattr(self.network.l_encoder.drop, "p", 0.0) >= 1e-6:
+            raise NotImplementedError("fused step: the library encoder is built without input dropout (networks.py:215-222)")
+        if self._fused is None or self._fused.kl_weight != self.kl_weight or self._fused.dropout_rate != p_drop or \
+                self._fused.input_dropout_rate != p_in:
+            running = None
+            if p_in > 0:   # share GeneDropout.running_non_zero_means with the module: one state for both paths
+                G = self.network.px_r.shape[0]
+                cur = gdrop.running_non_zero_means
+                running = torch.zeros(1, G, dtype=torch.float32, device=self._arena.device)
+                if torch.is_tensor(cur):
+                    running.copy_(cur.to(running.device).reshape(1, G))
+                gdrop.running_non_zero_means = running
+                running = running.view(G)
             self._fused = ElboStep(self._arena, l_mean=float(self.library_mean), l_var=float(self.library_var),
                                    kl_weight=self.kl_weight, gene_loss_coeff=self.gene_loss_coeff,
-                                   precision=self.precision, dropout_rate=p_drop, seed=self.dropout_seed)
+                                   precision=self.precision, dropout_rate=p_drop, seed=self.dropout_seed,
+                                   input_dropout_rate=p_in, input_dropout_alpha=float(gdrop.alpha), gene_running=running)
             self._fused.rng_step = self.train_step
         gene_vals, cell_prop_vals, cell_mask = batch[0], batch[1], batch[2]
         B, L = gene_vals.shape[0], self.network.n_latent
