@@ -247,3 +247,23 @@ def test_train_main_reduces_the_loss():
                           batch_size=128, max_steps=300)
     last = float(task.logged["gene_loss"])
     assert np.isfinite(last) and last < 0.8 * first, (first, last)
+
+
+def test_train_main_with_the_shipped_regularisers():
+    """The reference's shipped model settings (config.py:55-63: 2 layers, dropout 0.5, input dropout 0.5) train on
+    the fused step: hidden dropout + GeneDropout + fused AdamW, loss goes down, the running statistic is live."""
+    from oracle import vae_oracle as O
+    from vae_amd import train
+    x = O.synthetic_counts(512, 256, seed=3, zero_inflate=0.3).cuda()
+    cfg = dict(n_layers=2, n_hidden=64, n_hidden_decoder=64, n_hidden_library=32, n_latent=8, n_latent_cell_decoder=8,
+               dropout_rate=0.5, input_dropout_rate=0.5, grad_reverse_dict={})
+    kw = dict(counts=x, model_cfg=cfg, task_cfg={"warmup_steps": 20.0, "learning_rate": 2e-3}, trainer_cfg={"precision": "32"},
+              batch_size=128)
+    with contextlib.redirect_stdout(io.StringIO()):
+        first = float(train.main(list(range(512)), [], "synthetic", None, max_steps=1, **kw).logged["gene_loss"])
+        task = train.main(list(range(512)), [], "synthetic", None, max_steps=300, **kw)
+    last = float(task.logged["gene_loss"])
+    assert np.isfinite(last) and last < 0.85 * first, (first, last)
+    run = task.network.z_encoder.drop.running_non_zero_means
+    assert torch.is_tensor(run) and run.is_cuda and 0.0 < float(run.mean()) < 1.0
+    assert task._fused.dropout_rate == 0.5 and task._fused.input_dropout_rate == 0.5

@@ -54,7 +54,9 @@ def main(train_idx: List[int], test_idx: List[int], cell_class: str, additional_
     task = LitVAE(network, cell_properties=cell_properties if use_heads else None, library_mean=lib_mean,
                   library_var=lib_var, precision=precision,
                   **{k: v for k, v in tcfg.items() if k not in ("batch_properties",)})
-    task.train()  # dropout / gene-dropout > 0 is refused by the fused step: set both rates to 0
+    task.train()  # dropout / gene-dropout run on the fused step's own Philox stream (include/vae_amd.h, "dropout")
+    if dist.is_initialized():
+        task.dropout_seed += 0x9E3779B97F4A7C15 * dist.get_rank() % (2 ** 63)   # every rank its own masks
     arena = task.attach_arena(device)
     broadcast_parameters(arena)
     reducer = GradAllReducer(arena) if dist.is_initialized() and dist.get_world_size() > 1 else None
