@@ -3,7 +3,9 @@
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from vae_amd import ops
+from vae_amd import ops, _lib
+if os.environ.get("VAE_LIB"):   # an experimental build of the library
+    _lib.LIB_PATH = os.path.abspath(os.environ["VAE_LIB"])
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 20

@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libvae_amd.so")
+LIB_PATH = os.environ.get("VAE_AMD_LIB") or os.path.join(_HERE, "lib", "libvae_amd.so")   # env: an alternative build
 
 _i64, _i32, _f32, _ptr = C.c_int64, C.c_int, C.c_float, C.c_void_p
 
