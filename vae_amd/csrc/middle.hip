@@ -12,8 +12,8 @@
 //     (weight gradients of the three small Linears as outer products, all bias / LayerNorm
 //     gradients as column sums), one launch, fixed summation order, no float atomics.
 //
-// One 256-thread workgroup owns one cell: the hidden vectors (<= 1024 wide) live in registers,
-// element e of a vector belongs to thread e % 256.  Per-cell quantities needed for cross-cell
+// One 512-thread workgroup owns one cell: the hidden vectors (<= 1024 wide) live in registers,
+// element e of a vector belongs to thread e % 512.  Per-cell quantities needed for cross-cell
 // sums are written as rows and reduced by small_wgrad_batch.
 #include "middle.h"
 #include "philox.h"
@@ -30,8 +30,9 @@ __device__ unsigned long long vae_probe[4096 * 16];
 
 namespace {
 
-constexpr int T = 256;   // threads per workgroup
-constexpr int ME = 4;    // elements per thread: hidden widths up to 1024
+constexpr int T = 512;   // threads per workgroup (the kernels are latency-bound: more lanes, fewer rounds per phase)
+constexpr int NWV = T / 64;
+constexpr int ME = 2;    // elements per thread: hidden widths up to 1024
 
 __device__ __forceinline__ float gelu_f(float v) { return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f)); }
 __device__ __forceinline__ float gelu_grad(float v) {
@@ -58,11 +59,11 @@ __device__ __forceinline__ float dot_batched(const float* a, int sa, const float
 // order, with up to 48 loads in flight per thread: a dependent round trip costs ~2 us at the low
 // occupancy of these kernels, so the number of rounds is what matters.
 template <int NE>
-__device__ __forceinline__ void slab_sum_ne(const float* __restrict__ base, int nslab, int64_t stride, int W, float (&v)[4]) {
+__device__ __forceinline__ void slab_sum_ne(const float* __restrict__ base, int nslab, int64_t stride, int W, float (&v)[ME]) {
   constexpr int U = 48 / NE;
   const int t = threadIdx.x;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) v[i] = 0.f;
+  for (int i = 0; i < ME; ++i) v[i] = 0.f;
   for (int s = 0; s < nslab; s += U) {
     float w[NE][U];
 #pragma unroll
@@ -76,14 +77,13 @@ __device__ __forceinline__ void slab_sum_ne(const float* __restrict__ base, int 
       for (int u = 0; u < U; ++u) v[i] += w[i][u];
   }
 }
-__device__ __forceinline__ void slab_sum(const float* __restrict__ base, int nslab, int64_t stride, int W, float (&v)[4]) {
+__device__ __forceinline__ void slab_sum(const float* __restrict__ base, int nslab, int64_t stride, int W, float (&v)[ME]) {
+  static_assert(ME == 2, "slab_sum dispatches on ME == 2");
   if (W <= T) slab_sum_ne<1>(base, nslab, stride, W, v);
-  else if (W <= 2 * T) slab_sum_ne<2>(base, nslab, stride, W, v);
-  else if (W <= 3 * T) slab_sum_ne<3>(base, nslab, stride, W, v);
-  else slab_sum_ne<4>(base, nslab, stride, W, v);
+  else slab_sum_ne<2>(base, nslab, stride, W, v);
 }
 
-// Sums N values over the workgroup (4 waves); red holds >= 4*N floats.  Every thread gets all sums.
+// Sums N values over the workgroup's NWV waves (wave order); red holds >= NWV*N floats.  Every thread gets all sums.
 template <int N>
 __device__ __forceinline__ void block_sums(float (&v)[N], float* red) {
   const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
@@ -92,11 +92,16 @@ __device__ __forceinline__ void block_sums(float (&v)[N], float* red) {
   __syncthreads();
   if (l == 0) {
 #pragma unroll
-    for (int i = 0; i < N; ++i) red[i * 4 + w] = v[i];
+    for (int i = 0; i < N; ++i) red[i * NWV + w] = v[i];
   }
   __syncthreads();
 #pragma unroll
-  for (int i = 0; i < N; ++i) v[i] = (red[i * 4 + 0] + red[i * 4 + 1]) + (red[i * 4 + 2] + red[i * 4 + 3]);
+  for (int i = 0; i < N; ++i) {
+    float t = red[i * NWV];
+#pragma unroll
+    for (int j = 1; j < NWV; ++j) t += red[i * NWV + j];
+    v[i] = t;
+  }
 }
 
 // LayerNorm statistics of g[] over two adjacent segments [0,W0) and [W0,W0+W1) (W1 may be 0).
@@ -189,7 +194,7 @@ __global__ __launch_bounds__(T) void mid_fwd_kernel(MidFwd a) {
   __shared__ float hs[ME * T];   // LayerNorm outputs of both encoders (H+Hl)
   __shared__ float hd[72];       // head outputs: [0:L] q_m z, [L] var z, [L+1] q_m l, [L+2] var l
   __shared__ float zs[64];
-  __shared__ float red[16];
+  __shared__ float red[2 * NWV];
   const int t = threadIdx.x, b = blockIdx.x;
   const int lane = t & 63, wave = t >> 6;
   const int H = a.H, Hl = a.Hl, HE = a.H + a.Hl, L = a.L, Hd = a.Hd;
@@ -210,12 +215,12 @@ __global__ __launch_bounds__(T) void mid_fwd_kernel(MidFwd a) {
     dbet[i] = e < Hd ? a.bd[e] : 0.f;
   }
   stage_dec_w(a.d_w, Hd, L, LP, dyn);
-  // head weights of this wave's outputs o = wave + 4 r (lanes along k: coalesced row reads), k < 256
-  constexpr int RH = 9;  // outputs per wave per pass: one pass covers L + 3 <= 36
+  // head weights of this wave's outputs o = wave + NWV r (lanes along k: coalesced row reads), k < 256
+  constexpr int RH = (36 + NWV - 1) / NWV;  // outputs per wave per pass: one pass covers L + 3 <= 36
   float hw[RH][4];
 #pragma unroll
   for (int r = 0; r < RH; ++r) {
-    const int o = wave + 4 * r;
+    const int o = wave + NWV * r;
     const bool zo = o <= L;
     const float* w = zo ? a.hz_w + (int64_t)o * H : a.hl_w + (int64_t)(o - L - 1) * Hl;
     const int n = o < L + 3 ? (zo ? H : Hl) : 0;
@@ -261,10 +266,10 @@ __global__ __launch_bounds__(T) void mid_fwd_kernel(MidFwd a) {
   __syncthreads();
   STAMP(3);
   // 3. heads: output o <= L -> z heads over H, o = L+1, L+2 -> library heads over Hl.  A wave owns
-  //    four outputs at a time; its lanes run along k, so every weight load is a coalesced row read.
+  //    RH outputs at a time; its lanes run along k, so every weight load is a coalesced row read.
   {
     const int nmax = max(H, Hl);
-    for (int base = wave; base < L + 3; base += 4 * RH) {
+    for (int base = wave; base < L + 3; base += NWV * RH) {
       float acc[RH];
 #pragma unroll
       for (int r = 0; r < RH; ++r) acc[r] = 0.f;
@@ -272,7 +277,7 @@ __global__ __launch_bounds__(T) void mid_fwd_kernel(MidFwd a) {
         if (base != wave || c != 0) {  // beyond the prefetched block: load now
 #pragma unroll
           for (int r = 0; r < RH; ++r) {
-            const int o = base + 4 * r;
+            const int o = base + NWV * r;
             const bool zo = o <= L;
             const float* w = zo ? a.hz_w + (int64_t)o * H : a.hl_w + (int64_t)(o - L - 1) * Hl;
             const int n = o < L + 3 ? (zo ? H : Hl) : 0;
@@ -282,7 +287,7 @@ __global__ __launch_bounds__(T) void mid_fwd_kernel(MidFwd a) {
         }
 #pragma unroll
         for (int r = 0; r < RH; ++r) {
-          const int o = base + 4 * r;
+          const int o = base + NWV * r;
           const bool zo = o <= L;
           const int n = o < L + 3 ? (zo ? H : Hl) : 0;
 #pragma unroll
@@ -294,7 +299,7 @@ __global__ __launch_bounds__(T) void mid_fwd_kernel(MidFwd a) {
       }
 #pragma unroll
       for (int r = 0; r < RH; ++r) {
-        const int o = base + 4 * r;
+        const int o = base + NWV * r;
         const float v = wave_sum(acc[r]);
         if (lane == 0 && o < L + 3) hd[o] = v + (o <= L ? a.hz_b[o] : a.hl_b[o - L - 1]);
       }
@@ -387,7 +392,7 @@ __global__ __launch_bounds__(T) void mid_bwd_kernel(MidBwd a) {
   __shared__ float ds[ME * T];   // d pre-activation of the decoder layer
   __shared__ float dzs[64];
   __shared__ float dq[72];       // [0:L+1] z heads, [L+1:L+3] library heads
-  __shared__ float red[16];
+  __shared__ float red[4 * NWV];
   const int t = threadIdx.x, b = blockIdx.x;
   const int H = a.H, Hl = a.Hl, HE = a.H + a.Hl, L = a.L, Hd = a.Hd;
 
@@ -525,9 +530,9 @@ __global__ __launch_bounds__(T) void mid_bwd_kernel(MidBwd a) {
 
 // ---------------------------------------------------------------------------------------
 // out[p*sp + q*sq] = sum_b U[b][p] * V[b][q]   (U null: column sums of V), for a table of tasks.
-// A workgroup owns 8 p x 64 q outputs of one task: 256 cells at a time are staged in LDS (all the
-// global loads of a round in flight together); thread (q = t%64, r = t/64) sums the cells
-// b = r (mod 4) in ascending order, the four partial sums are combined r = 0..3: deterministic.
+// A workgroup (1024 threads) owns 8 p x 64 q outputs of one task: 256 cells at a time are staged in LDS (all
+// the global loads of a round in flight together); thread (q = t%64, r = t/64) sums the cells
+// b = r (mod 16) in ascending order, the sixteen partial sums are combined r = 0..15: deterministic.
 // ---------------------------------------------------------------------------------------
 constexpr int MAX_TASKS = 16;
 constexpr int PT = 8;
@@ -542,11 +547,13 @@ struct WgradBatch {
   int ntask, B;
 };
 
-__global__ __launch_bounds__(T) void small_wgrad_kernel(WgradBatch wb) {
+constexpr int TW = 1024;                  // threads of a small_wgrad workgroup
+constexpr int NR = TW / 64;               // cell residues: thread (l, r) sums the cells b = r (mod NR)
+__global__ __launch_bounds__(TW) void small_wgrad_kernel(WgradBatch wb) {
   constexpr int RC = 256;                 // cells staged per round
   __shared__ float Vs[RC][64];            // V[b0+row][q0+col]
   __shared__ float Us[RC][PT];            // U[b0+row][p0+i] (ones for a column sum)
-  __shared__ float comb[4][PT][64];
+  float (*comb)[PT][64] = reinterpret_cast<float (*)[PT][64]>(&Vs[0][0]);  // [NR][PT][64], reuses Vs after the last round
   int k = 0;
 #pragma unroll
   for (int i = 1; i < MAX_TASKS; ++i) k += (i < wb.ntask && (int)blockIdx.x >= wb.task[i].tile0) ? 1 : 0;
@@ -561,17 +568,18 @@ __global__ __launch_bounds__(T) void small_wgrad_kernel(WgradBatch wb) {
 #pragma unroll
   for (int i = 0; i < PT; ++i) acc[i] = 0.f;
 
-  float vreg[RC / 4], ureg[RC * PT / T];
-  auto fetch = [&](int b0) {  // thread (l, r) loads column l of rows r, r+4, ...: coalesced, all in flight
+  constexpr int UJ = (RC * PT + TW - 1) / TW;
+  float vreg[RC / NR], ureg[UJ];
+  auto fetch = [&](int b0) {  // thread (l, r) loads column l of rows r, r+NR, ...: coalesced, all in flight
     const int rows = min(RC, wb.B - b0);
 #pragma unroll
-    for (int j = 0; j < RC / 4; ++j) {
-      const int row = r + 4 * j;
+    for (int j = 0; j < RC / NR; ++j) {
+      const int row = r + NR * j;
       vreg[j] = (row < rows && qok) ? tk.V[(int64_t)(b0 + row) * tk.ldV + q0 + l] : 0.f;
     }
 #pragma unroll
-    for (int j = 0; j < RC * PT / T; ++j) {
-      const int idx = threadIdx.x + T * j, row = idx / PT, i = idx % PT;
+    for (int j = 0; j < UJ; ++j) {
+      const int idx = threadIdx.x + TW * j, row = idx / PT, i = idx % PT;
       float u = 0.f;
       if (row < rows && i < np) u = tk.U ? tk.U[(int64_t)(b0 + row) * tk.ldU + p0 + i] : 1.f;
       ureg[j] = u;
@@ -582,16 +590,16 @@ __global__ __launch_bounds__(T) void small_wgrad_kernel(WgradBatch wb) {
     const int rows = min(RC, wb.B - b0);
     __syncthreads();  // previous round's reads are done
 #pragma unroll
-    for (int j = 0; j < RC / 4; ++j) Vs[r + 4 * j][l] = vreg[j];
+    for (int j = 0; j < RC / NR; ++j) Vs[r + NR * j][l] = vreg[j];
 #pragma unroll
-    for (int j = 0; j < RC * PT / T; ++j) {
-      const int idx = threadIdx.x + T * j;
-      Us[idx / PT][idx % PT] = ureg[j];
+    for (int j = 0; j < UJ; ++j) {
+      const int idx = threadIdx.x + TW * j;
+      if (idx < RC * PT) Us[idx / PT][idx % PT] = ureg[j];
     }
     __syncthreads();
     if (b0 + RC < wb.B) fetch(b0 + RC);  // next round's loads fly during this round's sums
-    // thread (l, r) accumulates rows r, r+4, ... in ascending order
-    for (int row = r; row < rows; row += 4) {
+    // thread (l, r) accumulates rows r, r+NR, ... in ascending order
+    for (int row = r; row < rows; row += NR) {
       const float v = Vs[row][l];
       const float4 u0 = *reinterpret_cast<const float4*>(&Us[row][0]);
       const float4 u1 = *reinterpret_cast<const float4*>(&Us[row][4]);
@@ -601,13 +609,15 @@ __global__ __launch_bounds__(T) void small_wgrad_kernel(WgradBatch wb) {
       acc[6] = fmaf(u1.z, v, acc[6]); acc[7] = fmaf(u1.w, v, acc[7]);
     }
   }
+  __syncthreads();  // the last round's reads of Vs are done
 #pragma unroll
   for (int i = 0; i < PT; ++i) comb[r][i][l] = acc[i];
   __syncthreads();
-  if (r == 0 && qok) {
-    for (int i = 0; i < np; ++i)
-      tk.out[(int64_t)(p0 + i) * tk.sp + (int64_t)(q0 + l) * tk.sq] =
-          ((comb[0][i][l] + comb[1][i][l]) + comb[2][i][l]) + comb[3][i][l];
+  if (r < np && qok) {   // wave r finishes output row p0 + r: the NR partial sums in residue order
+    float v = comb[0][r][l];
+#pragma unroll
+    for (int j = 1; j < NR; ++j) v += comb[j][r][l];
+    tk.out[(int64_t)(p0 + r) * tk.sp + (int64_t)(q0 + l) * tk.sq] = v;
   }
 }
 
@@ -696,7 +706,7 @@ int vae_mid_backward(const vae_step_config& c, const vae_step_tensors* p, const 
   add(nullptr, 0, 1, dpre_e, HE, HE, g->enc_b0, 0, 1);
   wb.ntask = n;
   wb.B = B;
-  hipLaunchKernelGGL(small_wgrad_kernel, dim3((unsigned)tiles), dim3(T), 0, (hipStream_t)stream, wb);
+  hipLaunchKernelGGL(small_wgrad_kernel, dim3((unsigned)tiles), dim3(TW), 0, (hipStream_t)stream, wb);
   VAE_CHECK_LAUNCH("vae_elbo_step_backward(small wgrad)");
   return VAE_OK;
 }
