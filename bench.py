@@ -183,7 +183,12 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            # high-priority RCCL stream: the collective's kernels must get CUs while the backward still fills the chip
+            try:
+                opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
+                dist.init_process_group("nccl", device_id=dev, pg_options=opts)
+            except (AttributeError, TypeError):
+                dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group("gloo")
 

@@ -34,7 +34,7 @@ class GradAllReducer:
         # RCCL averages in the collective itself (ReduceOp.AVG); gloo has no AVG: sum, then scale
         self.avg_in_collective = (self.world > 1 and self.on_gpu and payload == "fp32"
                                   and dist.get_backend(group) == "nccl")
-        self.comm_stream = torch.cuda.Stream(device=arena.device) if self.on_gpu else None
+        self.comm_stream = torch.cuda.Stream(device=arena.device, priority=-1) if self.on_gpu else None
         self._pending: List[Tuple[torch.Tensor, Optional[torch.Tensor], object]] = []
         # bucket boundaries (element offsets into flat_grad): decoder-head weights | everything else.
         # Under NB the dropout-head weights have no gradient and fall between the two ranges.
