@@ -31,7 +31,18 @@ CONFIGS = {
                  cells=100_000, desc="20k-gene ZINB, bf16 MFMA GEMMs + fp32 likelihood, batch 4096"),
     "cfg4": dict(G=20000, H=256, Hd=256, Hl=128, L=30, n_layers=2, likelihood="zinb", B=4096, precision="bf16",
                  cells=131_072, desc="20k genes, 2-layer encoder/decoder, batch 4096 per GPU, data parallel"),
+    # BASELINE.json configs[4]: the multi-task model (cell-property heads on z, gradient reversal) at 30k genes,
+    # widths of the reference's shipped config.py (2 x 512, latent 32, bf16-mixed)
+    "cfg5": dict(G=30000, H=512, Hd=512, Hl=128, L=32, n_layers=2, likelihood="zinb", B=2048, precision="bf16",
+                 cells=65_536, heads=True, desc="multi-task VAE with cell-property heads, 30k genes, 2 x 512, batch 2048 per GPU"),
 }
+HEADS = {   # cell properties of the multi-task configuration: two discrete, one adversarial, one continuous
+    "Dementia": {"discrete": True, "values": [0, 1], "stop_grad": False},
+    "BRAAK_AD": {"discrete": True, "values": [0, 1, 2, 3, 4, 5, 6], "stop_grad": False},
+    "Sex": {"discrete": True, "values": [0, 1], "stop_grad": False},
+    "Age": {"discrete": False, "values": [-1], "stop_grad": False},
+}
+HEADS_GRAD_REVERSE = {"Sex": 0.2}
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s
 # dense TFLOP/s.  fp32 GEMMs run as six bf16 MFMA products per fp32 multiply-add (exact 3-way operand
 # split, gemm.hip), so their ceiling in ALGORITHMIC fp32 flops is the bf16 peak / 6 -- above the
@@ -210,9 +221,14 @@ def main():
     torch.manual_seed(43)
     net = VAE(G, n_hidden=cfg["H"], n_hidden_decoder=cfg["Hd"], n_hidden_library=cfg["Hl"], n_latent=L,
               n_latent_cell_decoder=L, n_layers=cfg["n_layers"], dropout_rate=0.0, input_dropout_rate=0.0,
-              cell_properties={"Dementia": {"discrete": True, "values": [0, 1], "stop_grad": False}},
-              grad_reverse_dict={}, reconstruction_loss=cfg["likelihood"])
+              cell_properties=HEADS if cfg.get("heads") else {"Dementia": HEADS["Dementia"]},
+              grad_reverse_dict=HEADS_GRAD_REVERSE if cfg.get("heads") else {}, reconstruction_loss=cfg["likelihood"],
+              cell_decoder_hidden_layer=False)
     arena = ParamArena(dict(net.named_parameters()), cfg["n_layers"], cfg["likelihood"], dev)
+    cell_decoder = net.cell_decoder.to(dev) if cfg.get("heads") else None
+    if cell_decoder is not None:   # the heads' parameters and gradients are arena views too
+        for k, q in cell_decoder.named_parameters():
+            q.data, q.grad = arena.p("cell_decoder." + k), arena.g("cell_decoder." + k)
     del net
     broadcast_parameters(arena)
 
@@ -231,10 +247,17 @@ def main():
 
     step = ElboStep(arena, l_mean=l_mean, l_var=l_var, kl_weight=1.0, gene_loss_coeff=5e-3, precision=precision)
     reducer = GradAllReducer(arena, payload=args.grad_payload) if world > 1 else None
+    head_fn = None
+    if cell_decoder is not None:   # CellDecoder + _cell_loss (modules.py:312-324, task.py:419-451) on z, torch autograd
+        from vae_amd.task import cell_loss
+        targets = torch.stack([torch.randint(0, len(v["values"]), (B,), generator=gen, device=dev).float() if v["discrete"]
+                               else torch.randn(B, generator=gen, device=dev) for v in HEADS.values()], dim=1)
+        mask = (torch.rand(B, len(HEADS), generator=gen, device=dev) > 0.1).float()
+        head_fn = lambda z: cell_loss(cell_decoder(z), HEADS, targets, mask)  # noqa: E731
 
     def one_step(i):
         xb = x_all[(i % n_batches) * B:(i % n_batches + 1) * B]
-        out = step.run(xb, eps_z, eps_l, reducer=reducer)
+        out = step.run(xb, eps_z, eps_l, cell_head_fn=head_fn, reducer=reducer)
         if reducer is not None:
             reducer.finish()
         return out

@@ -25,6 +25,8 @@ GEMM_SHAPES = [
     (8, 16, 64), (5, 31, 30), (129, 130, 33), (512, 384, 2000), (96, 257, 4101), (300, 40, 7), (1, 1, 1),
     # K % 32 == 0 and 16-byte rows: the LDS-DMA pipeline (ragged tiles, split-K slabs, single pass)
     (132, 260, 4096), (130, 262, 4096), (640, 1280, 256), (1024, 2048, 128), (512, 384, 2048),
+    # K % 4 == 0 but not % 32 (30 000 genes): the same pipeline with a zero-filled last K step, with and without split-K
+    (260, 136, 4100), (256, 640, 3004), (1024, 1024, 36),
 ]
 
 
@@ -79,8 +81,9 @@ def test_gemm_slabs_sum_to_the_product(ops, layout, shape):
 
 
 @pytest.mark.parametrize("layout", [0, 1, 2])
-def test_gemm_bf16(ops, layout):
-    M, N, K = 130, 200, 1000
+@pytest.mark.parametrize("shape", [(130, 200, 1000), (520, 384, 2004)])
+def test_gemm_bf16(ops, layout, shape):
+    M, N, K = shape
     a64, b64 = _rand((M, K), 4), _rand((K, N), 5)
     ar, br = a64.float().bfloat16().double(), b64.float().bfloat16().double()
     ref = ar @ br

@@ -79,6 +79,23 @@ def test_fused_step_matches_reference_goldens(case):
     assert checked >= 15
 
 
+def test_cell_head_gradients_do_not_accumulate_across_steps():
+    """The cell heads' gradients come from torch autograd (which accumulates): the step clears them, so a second
+    identical step leaves the same gradients as the first."""
+    case, arena, out = run_step(E2E_CASES[3])
+    first = {k: v.clone() for k, v in arena.grads().items() if v is not None and k.startswith("cell_decoder")}
+    assert first and all(float(v.abs().max()) > 0 for v in first.values())
+    from vae_amd.step import ElboStep
+    params, x, eps_z, eps_l, targets, mask = build_case_inputs(copy.deepcopy(E2E_CASES[3]))
+    step = ElboStep(arena, l_mean=float(np.float32(case["l_mean"])), l_var=float(np.float32(case["l_var"])),
+                    kl_weight=case["kl_weight"], gene_loss_coeff=case["gene_loss_coeff"])
+    fn = _cell_head_fn(arena, case, targets, mask)
+    for _ in range(2):
+        step.run(x.float().cuda(), eps_z.float().cuda(), eps_l.float().cuda(), cell_head_fn=fn)
+    for k, v in first.items():
+        assert rel_err(arena.g(k).cpu().numpy(), v.cpu().numpy()) < 1e-6, k
+
+
 def test_forward_only_leaves_grads_untouched():
     case, arena, out = run_step(E2E_CASES[1], backward=False)
     assert float(arena.flat_grad.abs().max()) == 0.0

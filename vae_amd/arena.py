@@ -78,6 +78,7 @@ class ParamArena:
                 self.offsets[k] = (off, params[k].shape)
                 off += params[k].numel()
         self.used_end = self.small_end
+        self.cell_begin = self.offsets[cell[0]][0] if cell else self.small_end   # cell heads: last groups of "small"
         self.total = (off + 3) & ~3
         self.flat = torch.zeros(self.total, dtype=torch.float32, device=self.device)
         self.flat_grad = torch.zeros(self.total, dtype=torch.float32, device=self.device)
@@ -125,6 +126,11 @@ class ParamArena:
 
     def gcat(self, *keys: str) -> torch.Tensor:
         return self._cat(self.flat_grad, keys)
+
+    def zero_cell_grads(self) -> None:
+        """The cell-head gradients come from torch autograd, which ACCUMULATES: clear them once per step."""
+        if self.cell_begin < self.small_end:
+            self.flat_grad[self.cell_begin:self.small_end].zero_()
 
     def zero_small_grads(self) -> None:
         self.flat_grad[self.small_begin:self.small_end].zero_()

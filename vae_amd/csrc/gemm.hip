@@ -692,6 +692,22 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(GemmArgs g) {
 #pragma unroll
     for (int i = 0; i < NB; ++i) { rb[i] = *reinterpret_cast<const float4*>(pb[i]); pb[i] += step_b; }
   };
+  // last, partial K step (K % 32 != 0, K % 4 == 0): chunks past kend read a safe address and count as zeros
+  auto fetch_tail = [&](int tail) {
+    const float4 Z = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int c = tid + 256 * i;
+      const int kk = A_KC ? 4 * (c & 7) : c / (BM / 4);
+      ra[i] = kk < tail ? *reinterpret_cast<const float4*>(pa[i]) : Z;
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int c = tid + 256 * i;
+      const int kk = B_KC ? 4 * (c & 7) : c / (BN / 4);
+      rb[i] = kk < tail ? *reinterpret_cast<const float4*>(pb[i]) : Z;
+    }
+  };
   auto put = [&](__bf16* base, int plane, int off, const float4& v) {
     const float f[4] = {v.x, v.y, v.z, v.w};
     bf16x4 hi, mi, lo;
@@ -785,17 +801,25 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(GemmArgs g) {
   };
 
   GSTAMP();
-  if (kbeg < kend) fetch();
-  for (int k0 = kbeg; k0 < kend; k0 += BK) {
+  const int nfull = kend > kbeg ? (kend - kbeg) / BK : 0;
+  const int tail = kend > kbeg ? (kend - kbeg) % BK : 0;   // only the last slab of a K that is not a multiple of 32
+  if (nfull > 0) fetch();
+  else if (tail) fetch_tail(tail);
+  for (int i = 0; i < nfull; ++i) {
 #ifdef VAE_ABL   // ablations for tools/micro/gemm_probe.hip: 1 = stage once, 2 = fetch once, 4 = no multiply
-    if (!(VAE_ABL & 1) || k0 == kbeg) stage();
-    if ((!(VAE_ABL & 2) || k0 == kbeg) && k0 + BK < kend) fetch();
+    if (!(VAE_ABL & 1) || i == 0) stage();
+    if ((!(VAE_ABL & 2) || i == 0) && i + 1 < nfull) fetch();
     if (!(VAE_ABL & 4)) multiply();
 #else
     stage();
-    if (k0 + BK < kend) fetch();  // in flight during the MFMAs below
+    if (i + 1 < nfull) fetch();  // in flight during the MFMAs below
+    else if (tail) fetch_tail(tail);
     multiply();
 #endif
+  }
+  if (tail) {
+    stage();
+    multiply();
   }
   GSTAMP();
 
@@ -906,7 +930,7 @@ struct DmaPlan { int bm, bn, split; };
 DmaPlan make_dma_plan(int M, int N, int K) {
   static const int force = getenv("VAE_GEMM_DMA_TILE") ? atoi(getenv("VAE_GEMM_DMA_TILE")) : 0;  // 0 | 128 | 160
   const int shapes[3][2] = {{128, 128}, {128, 160}, {160, 128}};
-  const int ktiles = K / BK;
+  const int ktiles = (K + BK - 1) / BK;
   DmaPlan best = {128, 128, 1};
   double best_us = 1e30;
   for (int c = 0; c < 3; ++c) {
@@ -952,7 +976,7 @@ void launch_t(const GemmArgs& g, bool norm, dim3 grid, hipStream_t st, int tile)
 extern "C" int64_t vae_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K) {
   const Plan p = make_plan((int)M, (int)N, (int)K);
   int split = p.split;
-  if (K % BK == 0 && p.tile == 128) {  // whichever pipeline the operands' alignment selects at run time
+  if (K % 4 == 0 && p.tile == 128) {  // whichever pipeline the operands' alignment selects at run time
     const DmaPlan d = make_dma_plan((int)M, (int)N, (int)K);
     if (d.split > split) split = d.split;
   }
@@ -986,7 +1010,10 @@ int gemm_impl(int layout, int precision, int64_t M, int64_t N, int64_t K, const 
   static const int no_dma = getenv("VAE_GEMM_NO_DMA") ? atoi(getenv("VAE_GEMM_NO_DMA")) : 0;  // tuning knob
   const bool norm = x_mean != nullptr;
   const bool a_rc = layout == TN, b_rc = layout != NT;
-  const bool dma_ok = precision <= 1 && !norm && plan.tile == 128 && !no_dma && K % BK == 0 && g.vecA && g.vecB &&
+  static const int x3_on = getenv("VAE_GEMM_X3") ? atoi(getenv("VAE_GEMM_X3")) : 1;
+  // the split-precision pipeline takes any K % 4 == 0 (zero-filled last K step); the fp32 LDS-DMA one needs K % 32 == 0
+  const bool k_ok = (x3_on || precision == 1) ? (K % 4 == 0) : (K % BK == 0);
+  const bool dma_ok = precision <= 1 && !norm && plan.tile == 128 && !no_dma && k_ok && g.vecA && g.vecB &&
                       (!a_rc || M % 4 == 0) && (!b_rc || N % 4 == 0) && M >= 4 && N >= 4;
   int bm = plan.tile, bn = plan.tile, split = plan.split;
   if (dma_ok) {

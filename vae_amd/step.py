@@ -219,6 +219,7 @@ class ElboStep:
             with torch.enable_grad():
                 cell_loss = cell_head_fn(z_leaf)
             if backward:
+                a.zero_cell_grads()   # autograd accumulates into the arena views; every other gradient is overwritten
                 (cell_loss * loss_scale).backward()
                 v["dz_extra"].copy_(z_leaf.grad)
                 use_extra = 1
