@@ -349,3 +349,52 @@ def test_dropout_stream_matches_host_restatement(ops, p):
     assert torch.equal(ops.dropout_apply(y.clone(), 0.0, seed, step, site), y)
     with pytest.raises(RuntimeError):
         ops.dropout_apply(y, 1.0, seed, step, site)
+
+
+@pytest.mark.parametrize("zinb", [True, False])
+@pytest.mark.parametrize("G", [1000, 1003, 4100])
+@pytest.mark.parametrize("counts", ["f32", "u8"])
+def test_fused_epilogue_against_the_oracle_likelihood(ops, zinb, G, counts):
+    """vae_nbzinb_fwd / _bwd alone vs the oracle's softmax -> exp(library) -> log_(zi)nb_positive -> sum
+    (modules.py:362,404, distributions.py:22-90, task.py:156-165) in fp64 autograd, on counts that hit every branch:
+    zeros, table counts (< 16), Stirling counts (16..255, thousands) and -- float counts only -- fractional ones;
+    extreme dropout logits on both sides of the softplus threshold."""
+    from oracle import vae_oracle as O
+    if counts == "u8" and G % 4:
+        pytest.skip("uint8 counts need the vector path")
+    B = 9
+    g = torch.Generator().manual_seed(77)
+    x = torch.poisson(torch.rand(B, G, generator=g) * 3, generator=g)
+    x[torch.rand(B, G, generator=g) < 0.4] = 0
+    x[:, 5] = torch.tensor([0, 1, 15, 16, 17, 100, 255, 40, 3.0])
+    if counts == "f32":
+        x[:, 6] = torch.tensor([2500.0, 0.5, 7.25, 1e-9, 30000.0, 15.5, 16.5, 0.0, 1.0])   # large, fractional, below eps
+    ls = torch.randn(B, G, generator=g) * 2
+    lp = torch.randn(B, G, generator=g) * 3
+    lp[:, 7] = torch.tensor([-30.0, 30.0, -21.0, 21.0, -19.0, 19.0, 0.0, -50.0, 50.0])
+    lib = torch.randn(B, generator=g) * 0.5 + 6
+    px_r = torch.randn(G, generator=g) * 0.7
+    leaves = [t.double().requires_grad_(True) for t in (ls, lp, lib, px_r)]
+    mu = torch.exp(leaves[2])[:, None] * torch.softmax(leaves[0], dim=-1)
+    th = torch.exp(leaves[3])
+    ll64 = (O.log_zinb_positive(x.double(), mu, th, leaves[1]) if zinb else O.log_nb_positive(x.double(), mu, th)).sum(-1)
+    w = torch.linspace(0.5, 1.5, B, dtype=torch.float64)
+    (ll64 * w * -3e-3).sum().backward()
+
+    xd = x.to(torch.uint8).cuda() if counts == "u8" else x.cuda()
+    lsd, lpd = ls.cuda(), lp.cuda()
+    table = ops.gene_table(px_r.cuda())
+    ll, rmax, rsum, S = ops.nbzinb_fwd(zinb, lsd, lpd if zinb else None, xd, lib.cuda(), table)
+    assert np.max(np.abs(ll.cpu().double().numpy() - ll64.detach().numpy()) / np.abs(ll64.detach().numpy())) < 1e-5
+    dls, dlp = torch.empty_like(lsd), torch.empty_like(lpd)
+    dlib = torch.empty(B, device="cuda")
+    dpxr, dbs, dbp = (torch.zeros(G, device="cuda") for _ in range(3))
+    ops.nbzinb_bwd(zinb, lsd, lpd if zinb else None, xd, lib.cuda(), table, rmax, rsum, S, w.float().cuda(), -3e-3, dls,
+                   dlp if zinb else None, dlib, dpxr, dbs, dbp if zinb else None)
+    assert rel_err(dls.cpu().numpy(), leaves[0].grad.numpy()) < 1e-4
+    assert rel_err(dlib.cpu().numpy(), leaves[2].grad.numpy()) < 1e-4
+    assert rel_err(dpxr.cpu().numpy(), leaves[3].grad.numpy()) < 1e-4
+    assert rel_err(dbs.cpu().numpy(), leaves[0].grad.sum(0).numpy()) < 1e-4
+    if zinb:
+        assert rel_err(dlp.cpu().numpy(), leaves[1].grad.numpy()) < 1e-4
+        assert rel_err(dbp.cpu().numpy(), leaves[1].grad.sum(0).numpy()) < 1e-4
