@@ -161,6 +161,14 @@ int vae_softmax_rate_fwd(const float* logit_scale, int64_t ld_s, const float* li
                          float* px_scale, float* px_rate, void* stream);
 int vae_softmax_rate_bwd(const float* px_scale, const float* library, const float* d_scale, const float* d_rate,
                          int64_t B, int64_t G, float* dlogits, int64_t ld_d, float* dlibrary, void* stream);
+/* Poisson log-probability, element-wise (reconstruction_loss "poisson", task.py:167-168;
+ * torch.distributions.Poisson.log_prob = xlogy(x, rate) - rate - lgamma(x + 1)) and its gradient
+ * drate = gout * (x / rate - 1).                                                                    */
+int vae_poisson_fwd(const float* x, int64_t ld_x, const float* rate, int64_t ld_rate, int64_t B, int64_t G, float* out,
+                    int64_t ld_out, void* stream);
+int vae_poisson_bwd(const float* gout, int64_t ld_g, const float* x, int64_t ld_x, const float* rate, int64_t ld_rate,
+                    int64_t B, int64_t G, float* drate, int64_t ld_d, void* stream);
+
 /* element-wise log_nb_positive / log_zinb_positive (distributions.py:65-90 / :22-62), eps = 1e-8;
  * theta addressed as theta[b*ld_theta + g] (ld_theta = 0 broadcasts a (G,) vector)                */
 int vae_loglik_elem_fwd(int zinb, const float* x, int64_t ld_x, const float* mu, int64_t ld_mu, const float* theta,

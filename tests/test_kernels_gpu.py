@@ -398,3 +398,24 @@ def test_fused_epilogue_against_the_oracle_likelihood(ops, zinb, G, counts):
     if zinb:
         assert rel_err(dlp.cpu().numpy(), leaves[1].grad.numpy()) < 1e-4
         assert rel_err(dbp.cpu().numpy(), leaves[1].grad.sum(0).numpy()) < 1e-4
+
+
+def test_poisson_log_prob_matches_torch():
+    """reconstruction_loss "poisson" (task.py:167-168): vae_amd.distributions.Poisson.log_prob on the HIP kernel
+    vs torch.distributions.Poisson in fp64, values and gradient w.r.t. the rate."""
+    from vae_amd.distributions import Poisson
+    g = torch.Generator().manual_seed(5)
+    rate = (torch.rand(13, 301, generator=g) * 20 + 1e-3)
+    x = torch.poisson(rate, generator=g)
+    x[0, :4] = torch.tensor([0.0, 1.0, 170.0, 3000.0])
+    r64 = rate.double().requires_grad_(True)
+    ref = torch.distributions.Poisson(r64).log_prob(x.double())
+    w = torch.rand(13, 301, generator=g).double()
+    (ref * w).sum().backward()
+    rd = rate.cuda().requires_grad_(True)
+    out = Poisson(rd).log_prob(x.cuda())
+    (out * w.float().cuda()).sum().backward()
+    assert np.max(np.abs(out.detach().cpu().double().numpy() - ref.detach().numpy()) / (1 + np.abs(ref.detach().numpy()))) < 1e-5   # fp32 rounding of terms ~20x the result
+    assert rel_err(rd.grad.cpu().numpy(), r64.grad.numpy()) < 1e-5
+    # the recon loss of the task: -log_prob summed over genes
+    assert rel_err((-out).sum(-1).detach().cpu().numpy(), (-ref).sum(-1).detach().numpy()) < 1e-5

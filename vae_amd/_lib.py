@@ -30,6 +30,8 @@ SIGNATURES = {
     "vae_dropout_apply": (_i32, [_ptr, _i64, _i64, _i64, _f32, C.c_uint64, C.c_uint32, C.c_uint32, _ptr]),
     "vae_gene_dropout": (_i32, [_ptr, _i32, _i64, _i64, _i64, _f32, _f32, C.c_uint64, C.c_uint32, _ptr, _ptr, _ptr, _ptr, _ptr,
                                 _ptr, _i64, _ptr]),
+    "vae_poisson_fwd": (_i32, [_ptr, _i64, _ptr, _i64, _i64, _i64, _ptr, _i64, _ptr]),
+    "vae_poisson_bwd": (_i32, [_ptr, _i64, _ptr, _i64, _ptr, _i64, _i64, _i64, _ptr, _i64, _ptr]),
     "vae_row_mean": (_i32, [_ptr, _i64, _i64, _i64, _ptr, _ptr]),
     "vae_normalize_rows": (_i32, [_ptr, _i64, _i64, _i64, _ptr, _ptr, _i64, _ptr]),
     "vae_normalize_rows_u8": (_i32, [_ptr, _i64, _i64, _i64, _ptr, _ptr, _i64, _ptr]),

@@ -105,6 +105,21 @@ class SoftmaxRateFn(Function):
         return dl, dlib.view(ctx.lib_shape)
 
 
+class PoissonLogProbFn(Function):
+    """Poisson(rate).log_prob(x) (task.py:167-168) on the HIP kernels; gradient to the rate only."""
+
+    @staticmethod
+    def forward(ctx, x, rate):
+        x, rate = _c(x), _c(rate)
+        ctx.save_for_backward(x, rate)
+        return ops.poisson_fwd(x, rate)
+
+    @staticmethod
+    def backward(ctx, gout):
+        x, rate = ctx.saved_tensors
+        return None, ops.poisson_bwd(_c(gout), x, rate)
+
+
 class LogLikFn(Function):
     """Element-wise log_nb_positive / log_zinb_positive (distributions.py:22-90)."""
 

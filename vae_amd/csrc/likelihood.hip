@@ -213,6 +213,52 @@ __global__ __launch_bounds__(FWD_THREADS) void softmax_rate_bwd_kernel(const flo
 
 }  // namespace
 
+// ---- Poisson (reconstruction_loss == "poisson", task.py:167-168) ---------------------------------
+// torch.distributions.Poisson.log_prob: xlogy(x, rate) - rate - lgamma(x + 1); d/d rate = x / rate - 1.
+__global__ void poisson_fwd_kernel(const float* __restrict__ x, int64_t ld_x, const float* __restrict__ rate, int64_t ld_r,
+                                   int B, int G, float* __restrict__ out, int64_t ld_o) {
+  const int64_t total = (int64_t)B * G;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t b = i / G, g = i % G;
+    const float xx = x[b * ld_x + g], r = rate[b * ld_r + g];
+    const float xl = xx == 0.f ? 0.f : xx * logf(r);   // xlogy
+    out[b * ld_o + g] = xl - r - lgammaf(xx + 1.f);
+  }
+}
+__global__ void poisson_bwd_kernel(const float* __restrict__ gout, int64_t ld_g, const float* __restrict__ x, int64_t ld_x,
+                                   const float* __restrict__ rate, int64_t ld_r, int B, int G, float* __restrict__ drate,
+                                   int64_t ld_d) {
+  const int64_t total = (int64_t)B * G;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t b = i / G, g = i % G;
+    const float xx = x[b * ld_x + g], r = rate[b * ld_r + g];
+    drate[b * ld_d + g] = gout[b * ld_g + g] * ((xx == 0.f ? 0.f : xx / r) - 1.f);
+  }
+}
+
+extern "C" int vae_poisson_fwd(const float* x, int64_t ld_x, const float* rate, int64_t ld_rate, int64_t B, int64_t G,
+                               float* out, int64_t ld_out, void* stream) {
+  VAE_REQUIRE(x && rate && out && B > 0 && G > 0 && ld_x >= G && ld_rate >= G && ld_out >= G, "vae_poisson_fwd: bad arguments");
+  int blocks = (int)((B * G + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(poisson_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, ld_x, rate, ld_rate, (int)B, (int)G,
+                     out, ld_out);
+  VAE_CHECK_LAUNCH("vae_poisson_fwd");
+  return VAE_OK;
+}
+
+extern "C" int vae_poisson_bwd(const float* gout, int64_t ld_g, const float* x, int64_t ld_x, const float* rate,
+                               int64_t ld_rate, int64_t B, int64_t G, float* drate, int64_t ld_d, void* stream) {
+  VAE_REQUIRE(gout && x && rate && drate && B > 0 && G > 0 && ld_g >= G && ld_x >= G && ld_rate >= G && ld_d >= G,
+              "vae_poisson_bwd: bad arguments");
+  int blocks = (int)((B * G + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(poisson_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, gout, ld_g, x, ld_x, rate, ld_rate,
+                     (int)B, (int)G, drate, ld_d);
+  VAE_CHECK_LAUNCH("vae_poisson_bwd");
+  return VAE_OK;
+}
+
 extern "C" int64_t vae_nbzinb_max_genes(void);
 
 extern "C" int vae_loglik_elem_fwd(int zinb, const float* x, int64_t ld_x, const float* mu, int64_t ld_mu,

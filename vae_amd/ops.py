@@ -343,6 +343,29 @@ def nbzinb_bwd(zinb: bool, logit_scale: torch.Tensor, logit_dropout: Optional[to
     _lib.check(rc, "nbzinb_bwd")
 
 
+def poisson_fwd(x: torch.Tensor, rate: torch.Tensor) -> torch.Tensor:
+    """Element-wise Poisson log-probability xlogy(x, rate) - rate - lgamma(x + 1) (task.py:167-168)."""
+    lib = _lib.load()
+    _chk2d(x, "x"); _chk2d(rate, "rate")
+    if x.shape != rate.shape:
+        raise ValueError("vae_amd.ops.poisson_fwd: x and rate must have the same shape")
+    B, G = x.shape
+    out = torch.empty(B, G, dtype=torch.float32, device=x.device)
+    _lib.check(lib.vae_poisson_fwd(_p(x), _ld(x), _p(rate), _ld(rate), B, G, _p(out), G, _stream()), "poisson_fwd")
+    return out
+
+
+def poisson_bwd(gout: torch.Tensor, x: torch.Tensor, rate: torch.Tensor) -> torch.Tensor:
+    """d/d rate of ``poisson_fwd`` times ``gout``."""
+    lib = _lib.load()
+    _chk2d(gout, "gout"); _chk2d(x, "x"); _chk2d(rate, "rate")
+    B, G = x.shape
+    out = torch.empty(B, G, dtype=torch.float32, device=x.device)
+    _lib.check(lib.vae_poisson_bwd(_p(gout), _ld(gout), _p(x), _ld(x), _p(rate), _ld(rate), B, G, _p(out), G, _stream()),
+               "poisson_bwd")
+    return out
+
+
 def loglik_elem_fwd(zinb: bool, x, mu, theta, pi) -> torch.Tensor:
     """Element-wise log_nb_positive / log_zinb_positive; theta is (G,) or (B,G)."""
     lib = _lib.load()
