@@ -122,6 +122,13 @@ def decoder_forward(p, z: Tensor, library: Tensor, n_layers: int, gemm_dtype=Non
     return px_scale, px_rate, px_dropout
 
 
+def decoder_px_r(p, z: Tensor, n_layers: int, gemm_dtype=None, masks=None) -> Tensor:
+    """The third decoder head of dispersion 'gene-cell' (modules.py:366,405): px_r = Linear(px), one
+    dispersion per cell and gene (theta = exp(px_r), task.py:483)."""
+    px = fc_layers(p, "decoder.px_decoder", z, n_layers, gemm_dtype, masks)
+    return _linear(px, p["decoder.px_r_decoder.weight"], p["decoder.px_r_decoder.bias"], gemm_dtype)
+
+
 def gaussian_kl(qm: Tensor, qv: Tensor, pm, pv) -> Tensor:
     """KL(N(qm, sqrt(qv)) || N(pm, sqrt(pv))) per element, the closed form torch's
     ``_kl_normal_normal`` evaluates (task.py:190-198)."""
@@ -176,6 +183,7 @@ def training_step(
     gemm_dtype=None,
     drop_masks: Optional[dict] = None,
     x_z: Optional[Tensor] = None,
+    dispersion: str = "gene",
 ) -> Dict[str, Tensor]:
     """Forward of one training step; returns every intermediate the goldens pin.
 
@@ -189,9 +197,16 @@ def training_step(
                                     dm.get("z_encoder"))
     ql_m, ql_v, library = encoder_forward(p, "l_encoder", x, eps_l, 1, gemm_dtype)  # networks.py:215-222
     px_scale, px_rate, px_dropout = decoder_forward(p, z, library, n_layers, gemm_dtype, dm.get("decoder"))
-    theta = torch.exp(p["px_r"])  # task.py:481-483, dispersion "gene"
+    if dispersion == "gene":
+        theta = torch.exp(p["px_r"])  # task.py:481-483
+    elif dispersion == "gene-cell":
+        theta = torch.exp(decoder_px_r(p, z, n_layers, gemm_dtype, dm.get("decoder")))  # modules.py:405, task.py:483
+    else:
+        raise ValueError(dispersion)  # 'gene-batch' / 'gene-label' reference undefined names (task.py:475-480)
 
-    if likelihood == "zinb":
+    if likelihood == "poisson":  # task.py:167-168: torch Poisson.log_prob = xlogy(x, rate) - rate - lgamma(x + 1)
+        ll = torch.xlogy(x, px_rate) - px_rate - torch.lgamma(x + 1)
+    elif likelihood == "zinb":
         ll = log_zinb_positive(x, px_rate, theta, px_dropout)
     elif likelihood == "nb":
         ll = log_nb_positive(x, px_rate, theta)

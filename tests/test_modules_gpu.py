@@ -178,6 +178,50 @@ def test_fused_step_applies_the_modules_dropout():
     assert run.shape == frac.shape and torch.allclose(run, 0.05 * frac, atol=1e-7)
 
 
+@pytest.mark.parametrize("variant", ["gene-cell", "poisson"])
+def test_module_path_likelihood_variants(variant, monkeypatch):
+    """Row f3 variants on the module API: dispersion "gene-cell" (third decoder head, theta per cell and gene,
+    modules.py:366,405) and reconstruction_loss "poisson" (task.py:167-168) vs the fp64 oracle."""
+    import vae_amd.modules as M
+    from oracle import vae_oracle as O
+    from vae_amd.networks import VAE
+    from vae_amd.task import LitVAE
+    case = copy.deepcopy(E2E_CASES[2])
+    params, x, eps_z, eps_l, _, _ = build_case_inputs(case)
+    params = dict(params)
+    g = torch.Generator().manual_seed(3)
+    params["decoder.px_r_decoder.weight"] = torch.randn(case["G"], case["Hd"], generator=g, dtype=torch.float64) * 0.05
+    params["decoder.px_r_decoder.bias"] = torch.randn(case["G"], generator=g, dtype=torch.float64) * 0.1
+    disp = "gene-cell" if variant == "gene-cell" else "gene"
+    lik = "poisson" if variant == "poisson" else case["likelihood"]
+    o_out, o_grads = O.training_step_with_grads(params, x, eps_z, eps_l, n_layers=case["n_layers"], likelihood=lik,
+                                                l_mean=case["l_mean"], l_var=case["l_var"], kl_weight=case["kl_weight"],
+                                                gene_loss_coeff=case["gene_loss_coeff"], dispersion=disp)
+    with contextlib.redirect_stdout(io.StringIO()):
+        net = VAE(case["G"], n_hidden=case["H"], n_hidden_decoder=case["Hd"], n_hidden_library=case["Hl"],
+                  n_latent=case["L"], n_latent_cell_decoder=case["L"], n_layers=case["n_layers"], dropout_rate=0.0,
+                  input_dropout_rate=0.0, cell_properties=case["cell_properties"], grad_reverse_dict=case["grad_reverse"],
+                  reconstruction_loss=lik, dispersion=disp, cell_decoder_hidden_layer=False)
+    net.load_state_dict({k: v.float() for k, v in params.items() if not (k == "px_r" and disp == "gene-cell")})
+    task = LitVAE(net.cuda(), cell_properties=None, dispersion=disp, reconstruction_loss=lik, n_epochs_kl_warmup=None,
+                  gene_loss_coeff=case["gene_loss_coeff"], library_mean=np.float32(case["l_mean"]),
+                  library_var=np.float32(case["l_var"]))
+    task.train()
+    queue = [eps_z.float().cuda(), eps_l.float().cuda()]
+    monkeypatch.setattr(M, "reparameterize_gaussian", lambda mu, var: mu + queue.pop(0) * var.sqrt())
+    loss = task.training_step((x.float().cuda(), None, None, None, None, None, None, None), 0)
+    loss.backward()
+    assert abs(float(loss.detach()) - float(o_out["loss"])) < TOL_CELL * abs(float(o_out["loss"]))
+    n = 0
+    for k, p in net.named_parameters():
+        if o_grads[k] is None:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+            continue
+        assert rel_err(p.grad.cpu().numpy(), o_grads[k].numpy()) < TOL_GRAD, k
+        n += 1
+    assert n >= (17 if variant == "gene-cell" else 12)
+
+
 def test_module_forward_outputs():
     """DecoderSCVI / Encoder forward tensors (px_scale, px_rate, px_dropout, q_m, q_v) vs goldens."""
     import vae_amd.modules as M
