@@ -60,6 +60,24 @@ int64_t vae_gemm_slabs_workspace_bytes(int64_t M, int64_t N, int64_t K);
 int vae_gemm_slabs(int layout, int precision, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
                    const float* B, int64_t ldb, float* workspace, int64_t workspace_bytes, int* n_slabs, void* stream);
 
+/* The same products on TWO f16 terms per operand element and three matrix-core products (half the matrix
+ * work of vae_gemm's fp32 mode, two LDS planes instead of three): element a is first multiplied by a power of
+ * two *scale (device pointer; vae_absmax_scale computes it from max|A| so that the scaled operand fills the
+ * upper part of f16's range), then split as hi = rn_f16(a s), lo = rn_f16(a s - hi) -- 22 significant bits -- and
+ * hi*hi + hi*lo + lo*hi accumulate in fp32; the result is scaled back exactly.  The error of a product is below
+ * 2^-21 of max|A| max|B| terms, i.e. NORMWISE fp32-grade for operands whose large entries matter (every operand of
+ * the training step); an element 2^-12 below the matrix maximum keeps fewer bits (vae_gemm keeps all).
+ * Shapes outside the split pipeline (small or unaligned) run the exact fp32 kernel.                     */
+int64_t vae_absmax_workspace_bytes(void);
+int vae_absmax_scale(const float* X, int64_t rows, int64_t cols, int64_t ld, float* scale_out, float* workspace,
+                     int64_t workspace_bytes, void* stream);
+int vae_gemm_scaled(int layout, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* scale_a,
+                    const float* B, int64_t ldb, const float* scale_b, float* C, int64_t ldc, const float* bias,
+                    int accumulate, float* workspace, int64_t workspace_bytes, void* stream);
+int vae_gemm_scaled_slabs(int layout, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* scale_a,
+                          const float* B, int64_t ldb, const float* scale_b, float* workspace, int64_t workspace_bytes,
+                          int* n_slabs, void* stream);
+
 /* ---- row kernels ----------------------------------------------------------------------------- */
 /* mean[b] = mean_g x[b,g]                                   Encoder.forward, modules.py:264      */
 int vae_row_mean(const float* x, int64_t ldx, int64_t B, int64_t G, float* mean, void* stream);

@@ -45,7 +45,7 @@ def test_argument_validation_without_gpu():
     assert rc == 1 and b"layout" in lib.vae_last_error()
     rc = lib.vae_gemm(0, 0, 4, 4, 4, None, 4, None, 4, None, 4, None, None, 0, None, 0, None)
     assert rc == 1 and b"null" in lib.vae_last_error()
-    rc = lib.vae_gemm(0, 3, 4, 4, 4, None, 4, None, 4, None, 4, None, None, 0, None, 0, None)
+    rc = lib.vae_gemm(0, 4, 4, 4, 4, None, 4, None, 4, None, 4, None, None, 0, None, 0, None)
     assert rc == 1 and b"precision" in lib.vae_last_error()
     rc = lib.vae_nbzinb_fwd(1, None, 0, None, 0, None, 0, None, None, 1, 1, None, None, None, None, None)
     assert rc == 1

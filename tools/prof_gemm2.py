@@ -34,6 +34,15 @@ cases = {
   "dec_dgrad NN": (lambda: ops.gemm(ops.NN, logits, w_heads, precision=P), 2.0*B*2*G*Hd),
   "enc_wgrad TN": (lambda: ops.gemm(ops.TN, dpre, xn, out=gw_enc, precision=P), 2.0*B*H*G),
 }
+if os.environ.get("SCALED"):   # two scaled f16 terms, three products
+    sc = {k: ops.absmax_scale(t) for k, t in dict(xn=xn, w_enc=w_enc, w_heads=w_heads, px=px, dpre=dpre, logits=logits).items()}
+    cases = {
+      "enc_fwd   NT": (lambda: ops.gemm_scaled(ops.NT, xn, w_enc, sc["xn"], sc["w_enc"]), 2.0*B*H*G),
+      "dec_fwd   NT": (lambda: ops.gemm_scaled(ops.NT, px, w_heads, sc["px"], sc["w_heads"], out=logits), 2.0*B*2*G*Hd),
+      "dec_wgrad TN": (lambda: ops.gemm_scaled(ops.TN, logits, px, sc["logits"], sc["px"], out=gw_heads), 2.0*B*2*G*Hd),
+      "dec_dgrad NN": (lambda: ops.gemm_scaled(ops.NN, logits, w_heads, sc["logits"], sc["w_heads"]), 2.0*B*2*G*Hd),
+      "enc_wgrad TN": (lambda: ops.gemm_scaled(ops.TN, dpre, xn, sc["dpre"], sc["xn"], out=gw_enc), 2.0*B*H*G),
+    }
 only = os.environ.get("ONLY")
 tot = 0
 for k, (fn, fl) in cases.items():

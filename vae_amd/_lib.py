@@ -32,6 +32,12 @@ SIGNATURES = {
                                 _ptr, _i64, _ptr]),
     "vae_poisson_fwd": (_i32, [_ptr, _i64, _ptr, _i64, _i64, _i64, _ptr, _i64, _ptr]),
     "vae_poisson_bwd": (_i32, [_ptr, _i64, _ptr, _i64, _ptr, _i64, _i64, _i64, _ptr, _i64, _ptr]),
+    "vae_absmax_workspace_bytes": (_i64, []),
+    "vae_absmax_scale": (_i32, [_ptr, _i64, _i64, _i64, _ptr, _ptr, _i64, _ptr]),
+    "vae_gemm_scaled": (_i32, [_i32, _i64, _i64, _i64, _ptr, _i64, _ptr, _ptr, _i64, _ptr, _ptr, _i64, _ptr, _i32, _ptr, _i64,
+                               _ptr]),
+    "vae_gemm_scaled_slabs": (_i32, [_i32, _i64, _i64, _i64, _ptr, _i64, _ptr, _ptr, _i64, _ptr, _ptr, _i64,
+                                     C.POINTER(C.c_int), _ptr]),
     "vae_row_mean": (_i32, [_ptr, _i64, _i64, _i64, _ptr, _ptr]),
     "vae_normalize_rows": (_i32, [_ptr, _i64, _i64, _i64, _ptr, _ptr, _i64, _ptr]),
     "vae_normalize_rows_u8": (_i32, [_ptr, _i64, _i64, _i64, _ptr, _ptr, _i64, _ptr]),

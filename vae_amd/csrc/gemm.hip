@@ -46,6 +46,8 @@ struct GemmArgs {
   int vecA, vecB;      // 16-byte vector loads allowed
   int accumulate;      // C += (only when split == 1)
   int tiles_m, tiles_n;
+  const float* sa;     // gemm_x3_kernel<NP = 2> (two f16 terms): device pointers to the power-of-two factors the
+  const float* sb;     // operands are multiplied by before the split (null = 1); the product is scaled back
 };
 
 // ---- global -> register tile loaders (R*8/256 float4 per thread per operand, R = 64 or 128) ----
@@ -619,6 +621,8 @@ __device__ long long g_probe[4][256];
 #else
 #define GSTAMP() do { } while (0)
 #endif
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
 
@@ -708,8 +712,26 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(GemmArgs g) {
       rb[i] = kk < tail ? *reinterpret_cast<const float4*>(pb[i]) : Z;
     }
   };
-  auto put = [&](__bf16* base, int plane, int off, const float4& v) {
+  float scA = 1.f, scB = 1.f;   // NP == 2: operand scales (uniform loads)
+  if (NP == 2) {
+    if (g.sa) scA = *g.sa;
+    if (g.sb) scB = *g.sb;
+  }
+  auto put = [&](__bf16* base, int plane, int off, const float4& v, float sc) {
     const float f[4] = {v.x, v.y, v.z, v.w};
+    if (NP == 2) {  // two f16 terms of the scaled value: hi = rn(a s), lo = rn(a s - hi): 22 significant bits
+      f16x4 h4, l4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float as = f[j] * sc;
+        const _Float16 h = (_Float16)as;
+        h4[j] = h;
+        l4[j] = (_Float16)(as - (float)h);
+      }
+      *reinterpret_cast<bf16x4*>(base + off) = __builtin_bit_cast(bf16x4, h4);
+      *reinterpret_cast<bf16x4*>(base + plane + off) = __builtin_bit_cast(bf16x4, l4);
+      return;
+    }
     bf16x4 hi, mi, lo;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -731,9 +753,9 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(GemmArgs g) {
     __syncthreads();  // the previous tile's fragment reads are done
     GSTAMP();
 #pragma unroll
-    for (int i = 0; i < NA; ++i) put(sA, PLA, wa[i], ra[i]);
+    for (int i = 0; i < NA; ++i) put(sA, PLA, wa[i], ra[i], scA);
 #pragma unroll
-    for (int i = 0; i < NB; ++i) put(sB, PLB, wb[i], rb[i]);
+    for (int i = 0; i < NB; ++i) put(sB, PLB, wb[i], rb[i], scB);
     GSTAMP();
     __syncthreads();
     GSTAMP();
@@ -788,6 +810,15 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(GemmArgs g) {
             acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ti][0], b[0], c, 0, 0, 0);
             continue;
           }
+          if (NP == 2) {  // f16 hi / lo: lo*hi, hi*lo, hi*hi (the dropped lo*lo is < 2^-22 of the product)
+            const f16x8 ah = __builtin_bit_cast(f16x8, a[ti][0]), al = __builtin_bit_cast(f16x8, a[ti][NP > 1 ? 1 : 0]);
+            const f16x8 bh = __builtin_bit_cast(f16x8, b[0]), bl = __builtin_bit_cast(f16x8, b[NP > 1 ? 1 : 0]);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, c, 0, 0, 0);
+            acc[ti][tj] = c;
+            continue;
+          }
           c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ti][NP > 1 ? 1 : 0], b[NP > 1 ? 1 : 0], c, 0, 0, 0);
           c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ti][NP > 1 ? 2 : 0], b[0], c, 0, 0, 0);
           c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ti][0], b[NP > 1 ? 2 : 0], c, 0, 0, 0);
@@ -823,6 +854,7 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(GemmArgs g) {
   }
   GSTAMP();
 
+  const float inv_sc = 1.f / (scA * scB);   // powers of two: exact
   float* out = g.C;
   int64_t ldc = g.ldc;
   if (g.split > 1) {
@@ -841,7 +873,7 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(GemmArgs g) {
         const int m = m0 + wm * (32 * TM) + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
         if (m < g.M) {
           float* p = out + (int64_t)m * ldc + n;
-          float v = acc[mi][ni][r] + bv;
+          float v = (NP == 2 ? acc[mi][ni][r] * inv_sc : acc[mi][ni][r]) + bv;
           if (g.split == 1 && g.accumulate) v += *p;
           *p = v;
         }
@@ -988,9 +1020,15 @@ namespace {
 // -- no reduce pass, no bias -- for a consumer kernel that sums them while it reads.
 int gemm_impl(int layout, int precision, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B,
               int64_t ldb, float* C, int64_t ldc, const float* bias, const float* x_mean, int accumulate,
-              float* workspace, int64_t workspace_bytes, void* stream, int* slabs_out) {
+              float* workspace, int64_t workspace_bytes, void* stream, int* slabs_out, const float* scale_a = nullptr,
+              const float* scale_b = nullptr) {
   VAE_REQUIRE(layout >= 0 && layout <= 2, "vae_gemm: layout must be 0 (NT), 1 (NN) or 2 (TN), got %d", layout);
-  VAE_REQUIRE(precision >= 0 && precision <= 2, "vae_gemm: precision must be 0 (fp32), 1 (bf16) or 2 (bf16x3), got %d", precision);
+  VAE_REQUIRE(precision >= 0 && precision <= 3, "vae_gemm: precision must be 0 (fp32), 1 (bf16), 2 (bf16x3) or 3 (f16x2), got %d",
+              precision);
+  // 3 = two scaled f16 terms, three products: only the split pipeline implements it; shapes outside it take the
+  // exact fp32 MFMA kernel (the scales are then not needed)
+  const bool f16x2 = precision == 3;
+  if (f16x2) precision = 0;
   VAE_REQUIRE(M > 0 && N > 0 && K > 0 && M < (1 << 30) && N < (1 << 30) && K < (1 << 30),
               "vae_gemm: bad shape M=%lld N=%lld K=%lld", (long long)M, (long long)N, (long long)K);
   VAE_REQUIRE(A && B && (C || slabs_out), "vae_gemm: null operand");
@@ -1001,6 +1039,7 @@ int gemm_impl(int layout, int precision, int64_t M, int64_t N, int64_t K, const 
 
   GemmArgs g;
   g.A = A; g.B = B; g.C = C; g.bias = bias; g.mean = x_mean;
+  g.sa = scale_a; g.sb = scale_b;
   g.lda = lda; g.ldb = ldb; g.ldc = ldc;
   g.M = (int)M; g.N = (int)N; g.K = (int)K;
   g.accumulate = accumulate;
@@ -1012,7 +1051,7 @@ int gemm_impl(int layout, int precision, int64_t M, int64_t N, int64_t K, const 
   const bool a_rc = layout == TN, b_rc = layout != NT;
   static const int x3_on = getenv("VAE_GEMM_X3") ? atoi(getenv("VAE_GEMM_X3")) : 1;
   // the split-precision pipeline takes any K % 4 == 0 (zero-filled last K step); the fp32 LDS-DMA one needs K % 32 == 0
-  const bool k_ok = (x3_on || precision == 1) ? (K % 4 == 0) : (K % BK == 0);
+  const bool k_ok = (x3_on || precision == 1 || f16x2) ? (K % 4 == 0) : (K % BK == 0);
   const bool dma_ok = precision <= 1 && !norm && plan.tile == 128 && !no_dma && k_ok && g.vecA && g.vecB &&
                       (!a_rc || M % 4 == 0) && (!b_rc || N % 4 == 0) && M >= 4 && N >= 4;
   int bm = plan.tile, bn = plan.tile, split = plan.split;
@@ -1064,6 +1103,10 @@ int gemm_impl(int layout, int precision, int64_t M, int64_t N, int64_t K, const 
       if (layout == NT) VAE_X3_LAUNCH(NT, 1);
       else if (layout == NN) VAE_X3_LAUNCH(NN, 1);
       else VAE_X3_LAUNCH(TN, 1);
+    } else if (f16x2) {
+      if (layout == NT) VAE_X3_LAUNCH(NT, 2);
+      else if (layout == NN) VAE_X3_LAUNCH(NN, 2);
+      else VAE_X3_LAUNCH(TN, 2);
     } else if (use_x3) {
       if (layout == NT) VAE_X3_LAUNCH(NT, 3);
       else if (layout == NN) VAE_X3_LAUNCH(NN, 3);
@@ -1104,6 +1147,70 @@ int gemm_impl(int layout, int precision, int64_t M, int64_t N, int64_t K, const 
   return VAE_OK;
 }
 }  // namespace
+
+namespace {
+// scale[0] = 2^e with max|X| * 2^e in [2^13, 2^14) (1 for an all-zero matrix): the factor that puts an operand of
+// the two-f16-term product in the upper part of f16's range.  Two stages, fixed order.
+__global__ __launch_bounds__(256) void absmax_partial_kernel(const float* __restrict__ X, int64_t ld, int64_t rows, int cols,
+                                                             float* __restrict__ partial) {
+  __shared__ float red[4];
+  float m = 0.f;
+  const int64_t total = rows * cols;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / cols;
+    m = fmaxf(m, fabsf(X[r * ld + (i - r * cols)]));
+  }
+  m = block_max<4>(m, red);
+  if (threadIdx.x == 0) partial[blockIdx.x] = m;
+}
+__global__ __launch_bounds__(256) void absmax_scale_kernel(const float* __restrict__ partial, int n, float* __restrict__ scale) {
+  __shared__ float red[4];
+  float m = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) m = fmaxf(m, partial[i]);
+  m = block_max<4>(m, red);
+  if (threadIdx.x == 0) {
+    int e = 0;
+    float s = 1.f;
+    if (m > 0.f && m < INFINITY) {
+      frexpf(m, &e);               // m = f * 2^e, f in [0.5, 1)
+      s = ldexpf(1.f, 14 - e);     // m * s in [2^13, 2^14)
+    }
+    scale[0] = s;
+  }
+}
+}  // namespace
+
+extern "C" int64_t vae_absmax_workspace_bytes(void) { return 1024 * (int64_t)sizeof(float); }
+
+extern "C" int vae_absmax_scale(const float* X, int64_t rows, int64_t cols, int64_t ld, float* scale_out, float* workspace,
+                                int64_t workspace_bytes, void* stream) {
+  VAE_REQUIRE(X && scale_out && rows > 0 && cols > 0 && cols < (1 << 30) && ld >= cols, "vae_absmax_scale: bad arguments");
+  VAE_REQUIRE(workspace && workspace_bytes >= vae_absmax_workspace_bytes(), "vae_absmax_scale: needs vae_absmax_workspace_bytes()");
+  int blocks = (int)((rows * cols + 4095) / 4096);
+  if (blocks > 1024) blocks = 1024;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(absmax_partial_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, X, ld, rows, (int)cols, workspace);
+  VAE_CHECK_LAUNCH("vae_absmax_scale");
+  hipLaunchKernelGGL(absmax_scale_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, workspace, blocks, scale_out);
+  VAE_CHECK_LAUNCH("vae_absmax_scale(finish)");
+  return VAE_OK;
+}
+
+extern "C" int vae_gemm_scaled(int layout, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* scale_a,
+                               const float* B, int64_t ldb, const float* scale_b, float* C, int64_t ldc, const float* bias,
+                               int accumulate, float* workspace, int64_t workspace_bytes, void* stream) {
+  VAE_REQUIRE(scale_a && scale_b, "vae_gemm_scaled: null scale");
+  return gemm_impl(layout, 3, M, N, K, A, lda, B, ldb, C, ldc, bias, nullptr, accumulate, workspace, workspace_bytes, stream,
+                   nullptr, scale_a, scale_b);
+}
+
+extern "C" int vae_gemm_scaled_slabs(int layout, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
+                                     const float* scale_a, const float* B, int64_t ldb, const float* scale_b,
+                                     float* workspace, int64_t workspace_bytes, int* n_slabs, void* stream) {
+  VAE_REQUIRE(n_slabs && scale_a && scale_b, "vae_gemm_scaled_slabs: null argument");
+  return gemm_impl(layout, 3, M, N, K, A, lda, B, ldb, nullptr, N, nullptr, nullptr, 0, workspace, workspace_bytes, stream,
+                   n_slabs, scale_a, scale_b);
+}
 
 extern "C" int vae_gemm(int layout, int precision, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
                         const float* B, int64_t ldb, float* C, int64_t ldc, const float* bias, const float* x_mean,

@@ -14,7 +14,7 @@ import torch
 from . import _lib
 
 NT, NN, TN = 0, 1, 2
-FP32, BF16, BF16X3 = 0, 1, 2
+FP32, BF16, BF16X3, F16X2 = 0, 1, 2, 3
 
 _workspaces = {}
 
@@ -105,6 +105,48 @@ def gemm(layout: int, a: torch.Tensor, b: torch.Tensor, *, out: Optional[torch.T
     rc = lib.vae_gemm(layout, precision, M, N, K, _p(a), _ld(a), _p(b), _ld(b), _p(out), _ld(out), _p(bias), _p(x_mean),
                       int(accumulate), _p(ws), nbytes, _stream())
     _lib.check(rc, "gemm")
+    return out
+
+
+def absmax_scale(x: torch.Tensor) -> torch.Tensor:
+    """-> 1-element tensor: the power of two s with max|x| * s in [2^13, 2^14) (``gemm_scaled`` operand scale)."""
+    lib = _lib.load()
+    _chk2d(x, "x")
+    out = torch.empty(1, dtype=torch.float32, device=x.device)
+    nb = lib.vae_absmax_workspace_bytes()
+    ws = torch.empty(nb // 4, dtype=torch.float32, device=x.device)
+    _lib.check(lib.vae_absmax_scale(_p(x), x.shape[0], x.shape[1], _ld(x), _p(out), _p(ws), nb, _stream()), "absmax_scale")
+    return out
+
+
+def gemm_scaled(layout: int, a: torch.Tensor, b: torch.Tensor, scale_a: Optional[torch.Tensor] = None,
+                scale_b: Optional[torch.Tensor] = None, *, out: Optional[torch.Tensor] = None,
+                bias: Optional[torch.Tensor] = None, accumulate: bool = False) -> torch.Tensor:
+    """``gemm`` on two f16 terms per element and three products (include/vae_amd.h, vae_gemm_scaled); the scales
+    default to ``absmax_scale`` of each operand."""
+    lib = _lib.load()
+    _chk2d(a, "a"); _chk2d(b, "b")
+    if layout == NT:
+        (M, K), (N, K2) = a.shape, b.shape
+    elif layout == NN:
+        (M, K), (K2, N) = a.shape, b.shape
+    elif layout == TN:
+        (K, M), (K2, N) = a.shape, b.shape
+    else:
+        raise ValueError("layout must be NT, NN or TN")
+    if K != K2:
+        raise ValueError(f"vae_amd.ops.gemm_scaled: inner dimensions differ ({K} vs {K2})")
+    sa = absmax_scale(a) if scale_a is None else scale_a
+    sb = absmax_scale(b) if scale_b is None else scale_b
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.float32, device=a.device)
+    _chk2d(out, "out")
+    _chk1d(bias, N, "bias")
+    nbytes = lib.vae_gemm_workspace_bytes(M, N, K)
+    ws = workspace(nbytes, a.device) if nbytes else None
+    rc = lib.vae_gemm_scaled(layout, M, N, K, _p(a), _ld(a), _p(sa), _p(b), _ld(b), _p(sb), _p(out), _ld(out), _p(bias),
+                             int(accumulate), _p(ws), nbytes, _stream())
+    _lib.check(rc, "gemm_scaled")
     return out
 
 
