@@ -47,9 +47,14 @@ HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s
 # dense TFLOP/s.  fp32 GEMMs run as six bf16 MFMA products per fp32 multiply-add (exact 3-way operand
 # split, gemm.hip), so their ceiling in ALGORITHMIC fp32 flops is the bf16 peak / 6 -- above the
 # 157.3 TFLOP/s of the fp32 MFMA instruction that the first version of the path used.
-MFMA_PEAK = {"fp32": 2500.0 / 6.0, "bf16": 2500.0}
-MFMA_BASIS = {"fp32": "bf16 dense 2500 TFLOP/s / 6 products per fp32 multiply-add (bf16x3 split); the fp32 MFMA peak is 157.3",
+MFMA_PEAK = {"fp32": 2500.0 / 3.0, "fp32x3": 2500.0 / 6.0, "bf16": 2500.0}
+MFMA_BASIS = {"fp32": "f16 dense 2500 TFLOP/s / 3 products per fp32 multiply-add (two scaled f16 terms); the fp32 MFMA peak is 157.3",
+              "fp32x3": "bf16 dense 2500 TFLOP/s / 6 products per fp32 multiply-add (three bf16 terms); the fp32 MFMA peak is 157.3",
               "bf16": "bf16 dense 2500 TFLOP/s"}
+DTYPE_TEXT = {"fp32": "f32 (the five gene-sized GEMMs: operands scaled by a power of two and split into 2 f16 terms, 3 f16 MFMA "
+                      "products, f32 accumulate -- error vs f64 below the f32 MFMA's own; everything else f32)",
+              "fp32x3": "f32 (GEMM operands split exactly into 3 bf16 terms, 6 bf16 MFMA products, f32 accumulate; everything else f32)",
+              "bf16": "bf16 GEMM operands, f32 accumulate and likelihood"}
 
 
 def synth_counts_device(n, G, device, seed, zero_inflate):
@@ -109,11 +114,18 @@ def kernel_breakdown(arena, cfg, x, precision):
     P = precision
     ks = {}
     fl = lambda m, n, k: 2.0 * m * n * k  # noqa: E731
-    ks["gemm_enc_fwd"] = (time_kernel(lambda: ops.gemm(ops.NT, xn, w_enc, precision=P)), "mfma", fl(B, H + Hl, G))
-    ks["gemm_dec_fwd"] = (time_kernel(lambda: ops.gemm(ops.NT, px, w_heads, out=logits, precision=P)), "mfma", fl(B, NH, Hd))
-    ks["gemm_dec_wgrad"] = (time_kernel(lambda: ops.gemm(ops.TN, logits, px, out=gw_heads, precision=P)), "mfma", fl(NH, Hd, B))
-    ks["gemm_dec_dgrad"] = (time_kernel(lambda: ops.gemm(ops.NN, logits, w_heads, precision=P)), "mfma", fl(B, Hd, NH))
-    ks["gemm_enc_wgrad"] = (time_kernel(lambda: ops.gemm(ops.TN, dpre, xn, out=gw_enc, precision=P)), "mfma", fl(H + Hl, G, B))
+    if P == ops.F16X2:   # the step's producers hand the operand maxima to the GEMMs; here: computed once, outside the timing
+        sc = {id(t): ops.absmax_scale(t) for t in (xn, w_enc, px, w_heads, logits, dpre)}
+        mm = lambda lay, a, b, out=None: ops.gemm_scaled(lay, a, b, sc[id(a)], sc[id(b)], out=out)  # noqa: E731
+    else:
+        mm = lambda lay, a, b, out=None: ops.gemm(lay, a, b, out=out, precision=P)  # noqa: E731
+    ks["gemm_enc_fwd"] = (time_kernel(lambda: mm(ops.NT, xn, w_enc)), "mfma", fl(B, H + Hl, G))
+    ks["gemm_dec_fwd"] = (time_kernel(lambda: mm(ops.NT, px, w_heads, logits)), "mfma", fl(B, NH, Hd))
+    if P == ops.F16X2:
+        sc[id(logits)] = ops.absmax_scale(logits)
+    ks["gemm_dec_wgrad"] = (time_kernel(lambda: mm(ops.TN, logits, px, gw_heads)), "mfma", fl(NH, Hd, B))
+    ks["gemm_dec_dgrad"] = (time_kernel(lambda: mm(ops.NN, logits, w_heads)), "mfma", fl(B, Hd, NH))
+    ks["gemm_enc_wgrad"] = (time_kernel(lambda: mm(ops.TN, dpre, xn, gw_enc)), "mfma", fl(H + Hl, G, B))
     logits.normal_()
     per = 12 if zinb else 8
     ks["nbzinb_fwd"] = (time_kernel(lambda: ops.nbzinb_fwd(zinb, logits[:, :G], logits[:, G:] if zinb else None, x, lib, table)),
@@ -166,7 +178,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the config's)")
-    ap.add_argument("--precision", default="", choices=["", "fp32", "bf16"])
+    ap.add_argument("--precision", default="", choices=["", "fp32", "fp32x3", "bf16"],
+                    help="fp32 = fp32-grade products on two scaled f16 terms / three MFMA products (default of cfg1/cfg2); "
+                         "fp32x3 = three bf16 terms / six products; bf16 = operands rounded to bf16")
     ap.add_argument("--grad-payload", default="fp32", choices=["fp32", "bf16"])
     ap.add_argument("--counts", default="f32", choices=["f32", "u8"],
                     help="dtype of the resident count matrix: f32 as the reference's loader delivers it (default, the "
@@ -215,7 +229,7 @@ def main():
     if args.precision:
         cfg["precision"] = args.precision
     B, G, L = cfg["B"], cfg["G"], cfg["L"]
-    precision = ops.BF16 if cfg["precision"] == "bf16" else ops.FP32
+    precision = {"bf16": ops.BF16, "fp32x3": ops.FP32, "fp32": ops.F16X2}[cfg["precision"]]
 
     # model: the reference architecture with torch default init under seed 43 (train.py:20)
     torch.manual_seed(43)
@@ -289,8 +303,7 @@ def main():
             "metric": "training cells/sec (fwd+bwd ELBO, 20k genes)" if G == 20000 else f"training cells/sec (fwd+bwd ELBO, {G} genes)",
             "value": value, "unit": "cells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": ("f32 (GEMM operands split exactly into 3 bf16 terms, 6 bf16 MFMA products, f32 accumulate; everything else f32)"
-                      if cfg["precision"] == "fp32" else "bf16 GEMM operands, f32 accumulate and likelihood"),
+            "dtype": DTYPE_TEXT[cfg["precision"]],
             "data": "synthetic",
             "config": {"workload": f"{args.config}: {cfg['desc']}", "batch_per_gpu": B, "global_batch": B * world,
                        "genes": G, "likelihood": cfg["likelihood"], "n_layers": cfg["n_layers"],

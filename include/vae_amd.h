@@ -34,8 +34,12 @@ extern "C" {
 #define VAE_NT 0 /* C[m,n] = sum_k A[m,k] B[n,k]   nn.Linear forward            */
 #define VAE_NN 1 /* C[m,n] = sum_k A[m,k] B[k,n]   autograd dgrad               */
 #define VAE_TN 2 /* C[m,n] = sum_k A[k,m] B[k,n]   autograd wgrad               */
-#define VAE_FP32 0 /* exact fp32 MFMA (v_mfma_f32_32x32x2_f32)                  */
+#define VAE_FP32 0 /* fp32-grade: three bf16 terms per element, six products (aligned shapes), else the fp32 MFMA */
 #define VAE_BF16 1 /* operands rounded to bf16, fp32 accumulate (..32x32x16_bf16) */
+#define VAE_BF16X3 2 /* vae_gemm only: the three-term split on the generic (ragged-shape) kernel         */
+#define VAE_FP32_F16X2 3 /* fp32-grade normwise: two scaled f16 terms, three products (vae_gemm_scaled); as a step
+                          * precision: the five gene-sized products use it, the operand maxima come from the
+                          * kernels that produce the operands; every other product as VAE_FP32            */
 
 /* ---- library ---------------------------------------------------------------------------- */
 int vae_version(void);             /* 100 * major + minor */
@@ -237,7 +241,7 @@ typedef struct {
   int64_t B, G, H, Hl, L, Hd;
   int32_t n_layers;  /* 1..VAE_MAX_LAYERS (z-encoder and decoder; the library encoder has 1)        */
   int32_t zinb;      /* 1 = ZINB, 0 = NB                                                          */
-  int32_t precision; /* VAE_FP32 / VAE_BF16 for every GEMM                                         */
+  int32_t precision; /* VAE_FP32 / VAE_BF16 / VAE_FP32_F16X2                                        */
   float l_mean, l_var;        /* prior of the library-size KL (task.py:230-231)                     */
   float kl_weight;            /* task.py:213-220                                                    */
   float gene_loss_coeff;      /* task.py:489                                                        */
@@ -271,6 +275,9 @@ enum { VAE_WS_QZ_HEADS = 0, /* (B, L+1): [:, :L] = qz_m                         
        VAE_WS_DZ_EXTRA,/* (B, L): written by the CALLER between forward and backward (cell heads)  */
        VAE_WS_RECON,   /* (B) = -ll                                                                */
        VAE_WS_GENE_THRESHOLD, /* (G) uint32 keep thresholds of GeneDropout, then 1 float mean_g(p_g); -1 when off */
+       VAE_WS_OPERAND_MAXIMA, /* 8 floats: max|operand| slots of VAE_FP32_F16X2 (kernels maintain them; the workspace
+                               * must be zero-filled once before its first use, and slots 5..6 -- the weight maxima --
+                               * cleared by the caller if the weights change without a backward in between)      */
        VAE_WS_NSLICES };
 int64_t vae_elbo_step_workspace_bytes(const vae_step_config* cfg);
 int64_t vae_elbo_step_ws_offset(const vae_step_config* cfg, int slice);

@@ -48,10 +48,14 @@ def run_step(case, precision=0, backward=True):
     return case, arena, out
 
 
+FP32_MODES = [0, 3]   # ops.FP32 (three bf16 terms, six products) and ops.F16X2 (two scaled f16 terms, three products)
+
+
+@pytest.mark.parametrize("precision", FP32_MODES, ids=["bf16x3", "f16x2"])
 @pytest.mark.parametrize("case", ALL_CASES, ids=[c["name"] for c in ALL_CASES])
-def test_fused_step_matches_reference_goldens(case):
+def test_fused_step_matches_reference_goldens(case, precision):
     gold = load_golden(f"e2e_{case['name']}.npz")
-    case, arena, out = run_step(case)
+    case, arena, out = run_step(case, precision=precision)
     G, stride = case["G"], case["sample_stride"]
     for k in ("qz_m", "qz_v", "z", "ql_m", "ql_v", "library", "recon", "kl_z", "kl_l"):
         g = gold[f"f64/out/{k}"]
@@ -264,8 +268,9 @@ def test_bf16_mode_against_bf16_oracle():
         assert rel_err(v.cpu().numpy(), o_grads[k].numpy()) < 3e-2, k
 
 
+@pytest.mark.parametrize("precision", FP32_MODES, ids=["bf16x3", "f16x2"])
 @pytest.mark.parametrize("likelihood", ["zinb", "nb"])
-def test_midsize_against_oracle(likelihood):
+def test_midsize_against_oracle(likelihood, precision):
     """B=96, G=2000 (cfg-1 shape): HIP step vs the fp64 oracle on seeded synthetic data."""
     from oracle import vae_oracle as O
     from vae_amd.arena import ParamArena
@@ -279,7 +284,7 @@ def test_midsize_against_oracle(likelihood):
     o_out, o_grads = O.training_step_with_grads({k: v.double() for k, v in p.items()}, x.double(), eps_z.double(),
                                                 eps_l.double(), n_layers=1, likelihood=likelihood, l_mean=lm, l_var=lv)
     arena = ParamArena(p, 1, likelihood, "cuda")
-    step = ElboStep(arena, l_mean=lm, l_var=lv)
+    step = ElboStep(arena, l_mean=lm, l_var=lv, precision=precision)
     out = step.run(x.cuda(), eps_z.cuda(), eps_l.cuda())
     rec = out["recon"].cpu().double().numpy()
     assert np.max(np.abs(rec - o_out["recon"].numpy()) / np.abs(o_out["recon"].numpy())) < TOL_CELL
@@ -294,8 +299,8 @@ def test_midsize_against_oracle(likelihood):
 # BASELINE.json configs[1] at FULL size (B=512, G=20000, hidden 256/128, latent 30, ZINB, fp32):
 # direct comparison with the fp64 oracle plus size-independent properties of the step.
 # ------------------------------------------------------------------------------------------------
-@pytest.fixture(scope="module")
-def full_cfg2():
+@pytest.fixture(scope="module", params=FP32_MODES, ids=["bf16x3", "f16x2"])
+def full_cfg2(request):
     from oracle import vae_oracle as O
     from vae_amd.arena import ParamArena
     from vae_amd.step import ElboStep
@@ -306,7 +311,7 @@ def full_cfg2():
     eps_z, eps_l = torch.randn(B, L, generator=g), torch.randn(B, 1, generator=g)
     lm, lv = O.library_prior(x)
     arena = ParamArena(p, 1, "zinb", "cuda")
-    step = ElboStep(arena, l_mean=lm, l_var=lv)
+    step = ElboStep(arena, l_mean=lm, l_var=lv, precision=request.param)
     return dict(O=O, p=p, x=x, eps_z=eps_z, eps_l=eps_l, lm=lm, lv=lv, arena=arena, step=step, B=B, L=L,
                 xd=x.cuda(), ezd=eps_z.cuda(), eld=eps_l.cuda())
 

@@ -103,7 +103,7 @@ class StepTensors(C.Structure):
 
 
 WS_SLICES = ("QZ_HEADS", "QZ_V", "Z", "KL_Z", "QL_HEADS", "QL_V", "LIBRARY", "KL_L", "LL", "SCALARS", "DZ_EXTRA", "RECON",
-             "GENE_THRESHOLD")
+             "GENE_THRESHOLD", "OPERAND_MAXIMA")
 
 _lib = None
 

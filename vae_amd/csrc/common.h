@@ -28,6 +28,22 @@ static inline bool vae_aligned16(const void* p) { return (reinterpret_cast<uintp
 #ifdef __HIPCC__
 constexpr int WAVE = 64;
 
+// Running maximum of |v| in a float slot that starts at 0: non-negative floats order like their bit patterns, so an
+// integer atomic does it -- order-independent, hence deterministic.  (A NaN ends up in the slot and disables the scale.)
+__device__ __forceinline__ void vae_atomic_absmax(float* slot, float v) {
+  const unsigned int bits = __float_as_uint(fabsf(v));
+  // most callers do not raise the maximum: a plain (possibly stale) read filters them, the atomic keeps it exact
+  if (bits > *reinterpret_cast<volatile unsigned int*>(slot)) atomicMax(reinterpret_cast<unsigned int*>(slot), bits);
+}
+// The power of two that puts an operand with maximum magnitude m into [2^13, 2^14): the scale of the two-f16-term
+// products (gemm.hip).  1 for m = 0, inf or NaN.
+__device__ __forceinline__ float vae_scale_from_absmax(float m) {
+  if (!(m > 0.f) || !(m < INFINITY)) return 1.f;
+  int e;
+  (void)frexpf(m, &e);
+  return ldexpf(1.f, 14 - e);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);

@@ -27,7 +27,9 @@
 // (d px_r, both bias gradients) stay in registers across the chunk and are flushed with one
 // float atomic per gene per workgroup; the next cell's loads are issued before the current
 // cell's stores so that HBM latency is overlapped although the gradients alias the logits.
+#include "../../include/vae_amd.h"
 #include "common.h"
+#include "internal.h"
 
 #include <stdlib.h>
 
@@ -365,8 +367,12 @@ __global__ __launch_bounds__(256) void nbzinb_bwd_kernel(
     const float* __restrict__ library, const float* __restrict__ T, const float* __restrict__ rowmax,
     const float* __restrict__ rowsum, const float* __restrict__ S, const float* __restrict__ g_ll, float g_scalar, int B,
     int G, int rows_per_block, float* dls, int64_t ld_ds, float* dlp, int64_t ld_dp, float* __restrict__ dlibrary,
-    float* __restrict__ dpx_r, float* __restrict__ dbias_s, float* __restrict__ dbias_p, float* __restrict__ slab) {
+    float* __restrict__ dpx_r, float* __restrict__ dbias_s, float* __restrict__ dbias_p, float* __restrict__ slab,
+    float* __restrict__ absmax) {
   __shared__ float4 rc[BWD_MAX_ROWS];  // per cell: {max + log(sumexp), exp(library), S_b, delta_b}
+  __shared__ unsigned int wg_absmax;    // max |gradient| written by this workgroup (absmax != null), as float bits
+  if (threadIdx.x == 0) wg_absmax = 0u;
+  float am = 0.f;
   const int g0 = blockIdx.x * BWD_STRIP + threadIdx.x * 4;
   const int b0 = blockIdx.y * rows_per_block;
   const int b1 = min(B, b0 + rows_per_block);
@@ -421,6 +427,7 @@ __global__ __launch_bounds__(256) void nbzinb_bwd_kernel(
       const Bwd e = elem_bwd<ZINB>(x4[j], k.y * p, p4[j], th[j], lt[j], it[j], d0[j], Tg[j], G);
       o_s[j] = k.w * (e.a - p * k.z);
       o_p[j] = k.w * e.dpi;
+      if (j < nv) am = fmaxf(am, fmaxf(fabsf(o_s[j]), ZINB ? fabsf(o_p[j]) : 0.f));
       acc_t[j] += k.w * e.dth * th[j];
       acc_s[j] += o_s[j];
       acc_p[j] += o_p[j];
@@ -442,6 +449,11 @@ __global__ __launch_bounds__(256) void nbzinb_bwd_kernel(
     c1 = c2;
 #pragma unroll
     for (int j = 0; j < 4; ++j) d0[j] = d1[j];
+  }
+  if (absmax) {  // threads past G have left: LDS integer max of the rest, then one global integer atomic per workgroup
+    atomicMax(&wg_absmax, __float_as_uint(am));
+    __syncthreads();
+    if (threadIdx.x == 0) atomicMax(reinterpret_cast<unsigned int*>(absmax), wg_absmax);
   }
   if (SLAB) {
     // partial column sums of this cell chunk: plain coalesced stores into slab[chunk][3][G];
@@ -617,7 +629,8 @@ static int nbzinb_bwd_impl(int zinb, const float* logit_scale, int64_t ld_s, con
                            const float* rowmax, const float* rowsum, const float* S, const float* g_ll,
                            float g_scalar, int64_t B, int64_t G, float* dlogit_scale, int64_t ld_ds,
                            float* dlogit_dropout, int64_t ld_dp, float* dlibrary, float* dpx_r, float* dbias_scale,
-                           float* dbias_dropout, float* workspace, int64_t workspace_bytes, void* stream, int overwrite) {
+                           float* dbias_dropout, float* workspace, int64_t workspace_bytes, void* stream, int overwrite,
+                           float* absmax = nullptr) {
   VAE_REQUIRE(!overwrite || workspace, "vae_nbzinb_bwd_overwrite: needs the workspace (deterministic mode)");
   VAE_REQUIRE(logit_scale && x && library && gene_table && rowmax && rowsum && S && dlogit_scale && dpx_r,
               "vae_nbzinb_bwd: null pointer");
@@ -640,7 +653,7 @@ static int nbzinb_bwd_impl(int zinb, const float* logit_scale, int64_t ld_s, con
 #define LAUNCH_BWD(Z, V, S_)                                                                                          \
   hipLaunchKernelGGL((nbzinb_bwd_kernel<Z, V, S_, XT>), grid, dim3(256), 0, st, logit_scale, ld_s, logit_dropout, ld_p, x,  \
                      ld_x, library, gene_table, rowmax, rowsum, S, g_ll, g_scalar, (int)B, (int)G, rows_per_block,    \
-                     dlogit_scale, ld_ds, dlogit_dropout, ld_dp, dlibrary, dpx_r, dbias_scale, dbias_dropout, workspace)
+                     dlogit_scale, ld_ds, dlogit_dropout, ld_dp, dlibrary, dpx_r, dbias_scale, dbias_dropout, workspace, absmax)
 #define LAUNCH_BWD2(Z, V) do { if (slab) LAUNCH_BWD(Z, V, true); else LAUNCH_BWD(Z, V, false); } while (0)
   VAE_REQUIRE(!U8 || vec, "vae_nbzinb_bwd_u8: needs G %% 4 == 0, leading dimensions %% 4 == 0 and aligned rows");
   if (U8) { if (zinb) LAUNCH_BWD2(true, true); else LAUNCH_BWD2(false, true); }
@@ -655,6 +668,21 @@ static int nbzinb_bwd_impl(int zinb, const float* logit_scale, int64_t ld_s, con
     VAE_CHECK_LAUNCH("vae_nbzinb_bwd(colreduce)");
   }
   return VAE_OK;
+}
+
+int vae_nbzinb_bwd_ex(int x_dtype, int zinb, const float* logit_scale, int64_t ld_s, const float* logit_dropout, int64_t ld_p,
+                      const void* x, int64_t ld_x, const float* library, const float* gene_table, const float* rowmax,
+                      const float* rowsum, const float* S, const float* g_ll, float g_scalar, int64_t B, int64_t G,
+                      float* dlogit_scale, int64_t ld_ds, float* dlogit_dropout, int64_t ld_dp, float* dlibrary, float* dpx_r,
+                      float* dbias_scale, float* dbias_dropout, float* workspace, int64_t workspace_bytes, float* absmax,
+                      void* stream) {
+  if (x_dtype == VAE_X_U8)
+    return nbzinb_bwd_impl<uint8_t>(zinb, logit_scale, ld_s, logit_dropout, ld_p, (const uint8_t*)x, ld_x, library, gene_table,
+                                    rowmax, rowsum, S, g_ll, g_scalar, B, G, dlogit_scale, ld_ds, dlogit_dropout, ld_dp,
+                                    dlibrary, dpx_r, dbias_scale, dbias_dropout, workspace, workspace_bytes, stream, 1, absmax);
+  return nbzinb_bwd_impl<float>(zinb, logit_scale, ld_s, logit_dropout, ld_p, (const float*)x, ld_x, library, gene_table, rowmax,
+                                rowsum, S, g_ll, g_scalar, B, G, dlogit_scale, ld_ds, dlogit_dropout, ld_dp, dlibrary, dpx_r,
+                                dbias_scale, dbias_dropout, workspace, workspace_bytes, stream, 1, absmax);
 }
 
 extern "C" int vae_nbzinb_bwd(int zinb, const float* logit_scale, int64_t ld_s, const float* logit_dropout, int64_t ld_p,

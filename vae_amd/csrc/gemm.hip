@@ -20,6 +20,7 @@
 // MFMAs of tile t; skinny shapes (K = genes or cells) are split over K into fp32 slabs that a
 // second kernel sums in a fixed order (deterministic, no float atomics).
 #include "common.h"
+#include "internal.h"
 
 #include <stdlib.h>
 
@@ -48,6 +49,7 @@ struct GemmArgs {
   int tiles_m, tiles_n;
   const float* sa;     // gemm_x3_kernel<NP = 2> (two f16 terms): device pointers to the power-of-two factors the
   const float* sb;     // operands are multiplied by before the split (null = 1); the product is scaled back
+  int scale_is_absmax; // sa / sb point at max|A| / max|B| (written by the producers); the kernel derives the factors
 };
 
 // ---- global -> register tile loaders (R*8/256 float4 per thread per operand, R = 64 or 128) ----
@@ -714,8 +716,8 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(GemmArgs g) {
   };
   float scA = 1.f, scB = 1.f;   // NP == 2: operand scales (uniform loads)
   if (NP == 2) {
-    if (g.sa) scA = *g.sa;
-    if (g.sb) scB = *g.sb;
+    if (g.sa) scA = g.scale_is_absmax ? vae_scale_from_absmax(*g.sa) : *g.sa;
+    if (g.sb) scB = g.scale_is_absmax ? vae_scale_from_absmax(*g.sb) : *g.sb;
   }
   auto put = [&](__bf16* base, int plane, int off, const float4& v, float sc) {
     const float f[4] = {v.x, v.y, v.z, v.w};
@@ -1021,7 +1023,7 @@ namespace {
 int gemm_impl(int layout, int precision, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B,
               int64_t ldb, float* C, int64_t ldc, const float* bias, const float* x_mean, int accumulate,
               float* workspace, int64_t workspace_bytes, void* stream, int* slabs_out, const float* scale_a = nullptr,
-              const float* scale_b = nullptr) {
+              const float* scale_b = nullptr, int scale_is_absmax = 0) {
   VAE_REQUIRE(layout >= 0 && layout <= 2, "vae_gemm: layout must be 0 (NT), 1 (NN) or 2 (TN), got %d", layout);
   VAE_REQUIRE(precision >= 0 && precision <= 3, "vae_gemm: precision must be 0 (fp32), 1 (bf16), 2 (bf16x3) or 3 (f16x2), got %d",
               precision);
@@ -1039,7 +1041,7 @@ int gemm_impl(int layout, int precision, int64_t M, int64_t N, int64_t K, const 
 
   GemmArgs g;
   g.A = A; g.B = B; g.C = C; g.bias = bias; g.mean = x_mean;
-  g.sa = scale_a; g.sb = scale_b;
+  g.sa = scale_a; g.sb = scale_b; g.scale_is_absmax = scale_is_absmax;
   g.lda = lda; g.ldb = ldb; g.ldc = ldc;
   g.M = (int)M; g.N = (int)N; g.K = (int)K;
   g.accumulate = accumulate;
@@ -1178,7 +1180,99 @@ __global__ __launch_bounds__(256) void absmax_scale_kernel(const float* __restri
     scale[0] = s;
   }
 }
+__global__ __launch_bounds__(256) void absmax_raw_kernel(const float* __restrict__ X, int64_t ld, int64_t rows, int cols,
+                                                         float* __restrict__ slot) {
+  __shared__ float red[4];
+  float m = 0.f;
+  const int64_t total = rows * cols;
+  if ((cols & 3) == 0 && (ld & 3) == 0 && (reinterpret_cast<uintptr_t>(X) & 15u) == 0) {
+    const int c4 = cols >> 2;
+    const int64_t t4 = rows * c4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < t4; i += (int64_t)gridDim.x * 256) {
+      const int64_t r = i / c4;
+      const float4 v = *reinterpret_cast<const float4*>(X + r * ld + 4 * (i - r * c4));
+      m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
+  } else {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+      const int64_t r = i / cols;
+      m = fmaxf(m, fabsf(X[r * ld + (i - r * cols)]));
+    }
+  }
+  m = block_max<4>(m, red);
+  if (threadIdx.x == 0) vae_atomic_absmax(slot, m);
+}
 }  // namespace
+
+namespace {
+// max|w| of two dense arrays (the two gene-sized weight matrices) in ONE launch: blocks [0, nb0) scan w0, the rest w1,
+// four 16-byte loads in flight per lane; block 0 first clears `nzero` other slots (the activations' maxima of the
+// step that starts here -- they are only written by later kernels of the stream).
+__global__ __launch_bounds__(256) void absmax_weights_kernel(const float* __restrict__ w0, int64_t n0, int nb0,
+                                                             const float* __restrict__ w1, int64_t n1, float* slot0,
+                                                             float* slot1, float* zero_slots, int nzero) {
+  __shared__ float red[4];
+  if (blockIdx.x == 0 && (int)threadIdx.x < nzero) zero_slots[threadIdx.x] = 0.f;
+  const bool first = (int)blockIdx.x < nb0;
+  const float* w = first ? w0 : w1;
+  const int64_t n4 = (first ? n0 : n1) >> 2;
+  const int64_t nb = first ? nb0 : (int)gridDim.x - nb0, bi = first ? blockIdx.x : blockIdx.x - nb0;
+  float m = 0.f;
+  const int64_t stride = nb * 256;
+  int64_t i = bi * 256 + threadIdx.x;
+  for (; i + 3 * stride < n4; i += 4 * stride) {
+    const float4 a = reinterpret_cast<const float4*>(w)[i], b = reinterpret_cast<const float4*>(w)[i + stride];
+    const float4 c = reinterpret_cast<const float4*>(w)[i + 2 * stride], d = reinterpret_cast<const float4*>(w)[i + 3 * stride];
+    m = fmaxf(m, fmaxf(fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w))),
+                       fmaxf(fmaxf(fabsf(b.x), fabsf(b.y)), fmaxf(fabsf(b.z), fabsf(b.w)))));
+    m = fmaxf(m, fmaxf(fmaxf(fmaxf(fabsf(c.x), fabsf(c.y)), fmaxf(fabsf(c.z), fabsf(c.w))),
+                       fmaxf(fmaxf(fabsf(d.x), fabsf(d.y)), fmaxf(fabsf(d.z), fabsf(d.w)))));
+  }
+  for (; i < n4; i += stride) {
+    const float4 a = reinterpret_cast<const float4*>(w)[i];
+    m = fmaxf(m, fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w))));
+  }
+  m = block_max<4>(m, red);
+  if (threadIdx.x == 0) vae_atomic_absmax(first ? slot0 : slot1, m);
+}
+}  // namespace
+
+// max|w0|, max|w1| raised into slot0 / slot1 (the caller guarantees they start at 0) and `nzero` floats at zero_slots
+// cleared, one launch.  n0, n1 multiples of 4, 16-byte aligned arrays.
+int vae_absmax_weights(const float* w0, int64_t n0, const float* w1, int64_t n1, float* slot0, float* slot1, float* zero_slots,
+                       int nzero, void* stream) {
+  VAE_REQUIRE(w0 && w1 && slot0 && slot1 && n0 > 0 && n1 > 0 && n0 % 4 == 0 && n1 % 4 == 0 && vae_aligned16(w0) &&
+                  vae_aligned16(w1) && nzero >= 0 && nzero <= 256 && (nzero == 0 || zero_slots),
+              "vae_absmax_weights: bad arguments");
+  const int total = 1024;
+  int nb0 = (int)((double)total * (double)n0 / (double)(n0 + n1));
+  if (nb0 < 1) nb0 = 1;
+  if (nb0 > total - 1) nb0 = total - 1;
+  hipLaunchKernelGGL(absmax_weights_kernel, dim3(total), dim3(256), 0, (hipStream_t)stream, w0, n0, nb0, w1, n1, slot0, slot1,
+                     zero_slots, nzero);
+  VAE_CHECK_LAUNCH("vae_absmax_weights");
+  return VAE_OK;
+}
+
+// ---- internal (internal.h): used by step.hip --------------------------------------------------
+// slot = max(slot, max|X|): one launch, integer atomic; the caller zeroes the slot once per step.
+int vae_absmax_accumulate(const float* X, int64_t rows, int64_t cols, int64_t ld, float* slot, void* stream) {
+  VAE_REQUIRE(X && slot && rows > 0 && cols > 0 && cols < (1 << 30) && ld >= cols, "vae_absmax_accumulate: bad arguments");
+  int blocks = (int)((rows * cols + 8191) / 8192);
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(absmax_raw_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, X, ld, rows, (int)cols, slot);
+  VAE_CHECK_LAUNCH("vae_absmax_accumulate");
+  return VAE_OK;
+}
+// vae_gemm / vae_gemm_slabs on two scaled f16 terms, the scales derived in the kernel from max|A|, max|B| slots
+int vae_gemm_f16x2(int layout, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* absmax_a,
+                   const float* B, int64_t ldb, const float* absmax_b, float* C, int64_t ldc, const float* bias,
+                   int accumulate, float* workspace, int64_t workspace_bytes, void* stream, int* slabs_out) {
+  VAE_REQUIRE(absmax_a && absmax_b, "vae_gemm_f16x2: null absmax slot");
+  return gemm_impl(layout, 3, M, N, K, A, lda, B, ldb, slabs_out ? nullptr : C, slabs_out ? N : ldc, slabs_out ? nullptr : bias,
+                   nullptr, slabs_out ? 0 : accumulate, workspace, workspace_bytes, stream, slabs_out, absmax_a, absmax_b, 1);
+}
 
 extern "C" int64_t vae_absmax_workspace_bytes(void) { return 1024 * (int64_t)sizeof(float); }
 

@@ -143,6 +143,7 @@ struct MidFwd {
   float *heads_z, *heads_l, *qz_v, *z, *kl_z, *ql_v, *library, *kl_l;
   float *dec_pre, *dec_h, *ln_md, *ln_rd;
   VaeDropout drop;                                       // nn.Dropout after each LayerNorm (off: scale == 0)
+  float* absmax_px;                                      // nullable: raised to max|dec_h| (scale of the f16x2 GEMMs)
 };
 
 // softplus variance, sample and KL for one encoder, executed by ONE wave (lane j = latent j).
@@ -319,6 +320,7 @@ __global__ __launch_bounds__(T) void mid_fwd_kernel(MidFwd a) {
   STAMP(5);
   // 5. first decoder layer: Linear(L -> Hd) + GELU + LayerNorm, weight rows from LDS
   float gd[ME];
+  float am = 0.f;
 #pragma unroll
   for (int i = 0; i < ME; ++i) {
     const int n = t + T * i;
@@ -340,6 +342,19 @@ __global__ __launch_bounds__(T) void mid_fwd_kernel(MidFwd a) {
       float h = (gd[i] - mu[0]) * rs[0] * dgam[i] + dbet[i];
       if (a.drop.on()) h *= a.drop.mult(VAE_SITE_DEC(0), b, Hd, n);
       a.dec_h[(int64_t)b * Hd + n] = h;
+      am = fmaxf(am, fabsf(h));
+    }
+  }
+  if (a.absmax_px) {  // workgroup maximum of |dec_h| -> one integer atomic
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) am = fmaxf(am, __shfl_xor(am, o, WAVE));
+    __syncthreads();
+    if (lane == 0) red[wave] = am;
+    __syncthreads();
+    if (t == 0) {
+      float m = red[0];
+      for (int j = 1; j < NWV; ++j) m = fmaxf(m, red[j]);
+      vae_atomic_absmax(a.absmax_px, m);
     }
   }
   if (t == 0) {
@@ -363,6 +378,9 @@ struct MidBwd {
   float *dq_z, *dq_l;                                    // (B, L+1), (B, 2)
   float *dbet_e, *dgam_e, *dpre_e;                       // (B, H+Hl) rows
   VaeDropout drop;
+  float* absmax_dpre;                                    // nullable: raised to max|dpre_e|
+  float* clear_slots; int nclear;                        // nullable: floats block 0 zeroes (the weight maxima: their
+                                                         // last reader, the dgrad GEMM, has run; the next forward refills)
 };
 
 // Backward of reparam_wave, by one wave.  Mirrors reparam_kl_bwd_kernel (rowops.hip).
@@ -397,6 +415,7 @@ __global__ __launch_bounds__(T) void mid_bwd_kernel(MidBwd a) {
   const int H = a.H, Hl = a.Hl, HE = a.H + a.Hl, L = a.L, Hd = a.Hd;
 
   const int LP = L | 1;
+  if (b == 0 && a.clear_slots && t < a.nclear) a.clear_slots[t] = 0.f;
   stage_dec_w(a.d_w, Hd, L, LP, dyn);
   // 1. d(dec_h): sum of the dgrad slabs; LayerNorm + GELU backward of the decoder layer
   const float mud = a.ln_md[b], rsd = a.ln_rd[b];
@@ -515,6 +534,7 @@ __global__ __launch_bounds__(T) void mid_bwd_kernel(MidBwd a) {
     }
   }
   block_sums<4>(q4, red);
+  float am = 0.f;
   q4[0] /= (float)H; q4[1] /= (float)H;
   q4[2] /= (float)Hl; q4[3] /= (float)Hl;
 #pragma unroll
@@ -523,7 +543,21 @@ __global__ __launch_bounds__(T) void mid_bwd_kernel(MidBwd a) {
     if (e < HE) {
       const bool zh = e < H;
       const float dg = (zh ? rs0 : rs1) * (dx[i] - (zh ? q4[0] : q4[2]) - xh[i] * (zh ? q4[1] : q4[3]));
-      a.dpre_e[(int64_t)b * HE + e] = dg * gelu_grad(pv[i]);
+      const float o = dg * gelu_grad(pv[i]);
+      a.dpre_e[(int64_t)b * HE + e] = o;
+      am = fmaxf(am, fabsf(o));
+    }
+  }
+  if (a.absmax_dpre) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) am = fmaxf(am, __shfl_xor(am, o, WAVE));
+    __syncthreads();
+    if ((t & 63) == 0) red[t >> 6] = am;
+    __syncthreads();
+    if (t == 0) {
+      float m = red[0];
+      for (int j = 1; j < NWV; ++j) m = fmaxf(m, red[j]);
+      vae_atomic_absmax(a.absmax_dpre, m);
     }
   }
 }
@@ -634,8 +668,10 @@ bool vae_mid_supported(const vae_step_config& c) {
 int vae_mid_forward(const vae_step_config& c, const vae_step_tensors* p, const float* slabs, int nslab, const float* eps_z,
                     const float* eps_l, float* pre_enc0, float* h_enc0, float* ln_mz, float* ln_rz, float* ln_ml,
                     float* ln_rl, float* heads_z, float* heads_l, float* qz_v, float* z, float* kl_z, float* ql_v,
-                    float* library, float* kl_l, float* dec_pre, float* dec_h, float* ln_md, float* ln_rd, void* stream) {
+                    float* library, float* kl_l, float* dec_pre, float* dec_h, float* ln_md, float* ln_rd, float* absmax_px,
+                    void* stream) {
   MidFwd a;
+  a.absmax_px = absmax_px;
   a.slabs = slabs; a.nslab = nslab; a.slab_stride = c.B * (c.H + c.Hl);
   a.enc_b0 = p->enc_b0;
   a.gz = p->encz_ln_g[0]; a.bz = p->encz_ln_b[0]; a.gl = p->encl_ln_g; a.bl = p->encl_ln_b;
@@ -661,8 +697,11 @@ int vae_mid_backward(const vae_step_config& c, const vae_step_tensors* p, const 
                      const float* heads_l, const float* qz_v, const float* ql_v, const float* dlibrary,
                      const float* pre_enc0, const float* ln_mz, const float* ln_rz, const float* ln_ml,
                      const float* ln_rl, const float* z, const float* h_enc0, float* dbet_d, float* dgam_d,
-                     float* dpre_d, float* dq_z, float* dq_l, float* dbet_e, float* dgam_e, float* dpre_e, void* stream) {
+                     float* dpre_d, float* dq_z, float* dq_l, float* dbet_e, float* dgam_e, float* dpre_e,
+                     float* absmax_dpre, float* clear_slots, int nclear, void* stream) {
   MidBwd a;
+  a.absmax_dpre = absmax_dpre;
+  a.clear_slots = clear_slots; a.nclear = nclear;
   a.slabs = slabs; a.nslab = nslab; a.slab_stride = c.B * c.Hd;
   a.dec_pre = dec_pre; a.ln_md = ln_md; a.ln_rd = ln_rd; a.gd = p->dec_ln_g[0];
   a.d_w = p->dec_w[0];

@@ -10,6 +10,7 @@
 #include "../../include/vae_amd.h"
 #include "common.h"
 #include "philox.h"
+#include "internal.h"
 
 namespace {
 
@@ -55,9 +56,17 @@ __device__ __forceinline__ float4 load4(const uint8_t* row, int i) {
 template <bool REG, typename XT>
 __global__ __launch_bounds__(256) void normalize_rows_kernel(const XT* __restrict__ x, int64_t ld, int B, int G,
                                                              int vec, float* __restrict__ mean,
-                                                             float* __restrict__ xn, int64_t ld_xn) {
+                                                             float* __restrict__ xn, int64_t ld_xn,
+                                                             float* __restrict__ absmax) {
   constexpr int EPT = 20;
   __shared__ float red[4];
+  float am = 0.f;   // max|xn| of this thread's elements (absmax != null)
+  auto track = [&](float v) { am = fmaxf(am, fabsf(v)); return v; };
+  auto finish = [&]() {
+    if (!absmax) return;
+    am = block_max<4>(am, red);
+    if (threadIdx.x == 0) vae_atomic_absmax(absmax, am);
+  };
   const int b = blockIdx.x;
   const XT* row = x + (int64_t)b * ld;
   float* orow = xn + (int64_t)b * ld_xn;
@@ -81,11 +90,13 @@ __global__ __launch_bounds__(256) void normalize_rows_kernel(const XT* __restric
       const int i = threadIdx.x + 256 * j;
       if (i < n4) {
         float4 o;
-        o.x = v[j].x / m - 1.f; o.y = v[j].y / m - 1.f; o.z = v[j].z / m - 1.f; o.w = v[j].w / m - 1.f;
+        o.x = track(v[j].x / m - 1.f); o.y = track(v[j].y / m - 1.f);
+        o.z = track(v[j].z / m - 1.f); o.w = track(v[j].w / m - 1.f);
         reinterpret_cast<float4*>(orow)[i] = o;
       }
     }
-    for (int i = (n4 << 2) + threadIdx.x; i < G; i += 256) orow[i] = (float)row[i] / m - 1.f;
+    for (int i = (n4 << 2) + threadIdx.x; i < G; i += 256) orow[i] = track((float)row[i] / m - 1.f);
+    finish();
     return;
   }
   float s = 0.f;
@@ -100,10 +111,11 @@ __global__ __launch_bounds__(256) void normalize_rows_kernel(const XT* __restric
   if (threadIdx.x == 0) mean[b] = m;
   for (int i = threadIdx.x; i < n4; i += 256) {
     float4 v = load4(row, i);
-    v.x = v.x / m - 1.f; v.y = v.y / m - 1.f; v.z = v.z / m - 1.f; v.w = v.w / m - 1.f;
+    v.x = track(v.x / m - 1.f); v.y = track(v.y / m - 1.f); v.z = track(v.z / m - 1.f); v.w = track(v.w / m - 1.f);
     reinterpret_cast<float4*>(orow)[i] = v;
   }
-  for (int i = (n4 << 2) + threadIdx.x; i < G; i += 256) orow[i] = (float)row[i] / m - 1.f;
+  for (int i = (n4 << 2) + threadIdx.x; i < G; i += 256) orow[i] = track((float)row[i] / m - 1.f);
+  finish();
 }
 
 // ---------------------------------------------------------------------------------------
@@ -414,8 +426,10 @@ template <typename XT>
 __global__ __launch_bounds__(256) void normalize_rows_masked_kernel(const XT* __restrict__ x, int64_t ld, int B, int G,
                                                                     const uint32_t* __restrict__ thr, uint64_t seed,
                                                                     uint32_t step, float* __restrict__ mean,
-                                                                    float* __restrict__ xn, int64_t ld_xn) {
+                                                                    float* __restrict__ xn, int64_t ld_xn,
+                                                                    float* __restrict__ absmax) {
   __shared__ float red[4];
+  float am = 0.f;
   const int b = blockIdx.x;
   const XT* row = x + (int64_t)b * ld;
   float* orow = xn + (int64_t)b * ld_xn;
@@ -439,14 +453,19 @@ __global__ __launch_bounds__(256) void normalize_rows_masked_kernel(const XT* __
   for (int i = threadIdx.x; i < n4; i += 256) {
     float4 v = masked(i);
     v.x = v.x / m - 1.f; v.y = v.y / m - 1.f; v.z = v.z / m - 1.f; v.w = v.w / m - 1.f;
+    am = fmaxf(fmaxf(am, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
     reinterpret_cast<float4*>(orow)[i] = v;
+  }
+  if (absmax) {
+    am = block_max<4>(am, red);
+    if (threadIdx.x == 0) vae_atomic_absmax(absmax, am);
   }
 }
 
 template <typename XT>
 static int gene_dropout_impl(const XT* x, int64_t ldx, int64_t B, int64_t G, float p, float alpha, uint64_t seed,
                              uint32_t step, float* running, int* counts, uint32_t* thr, float* stats, float* mean, float* xn,
-                             int64_t ld_xn, void* stream) {
+                             int64_t ld_xn, float* absmax, void* stream) {
   VAE_REQUIRE(x && running && counts && thr && stats && mean && xn && B > 0 && G > 0 && ldx >= G && ld_xn >= G,
               "vae_gene_dropout: bad arguments");
   VAE_REQUIRE(p > 0.f && p <= 1.f && alpha >= 0.f && alpha <= 1.f, "vae_gene_dropout: p in (0, 1], alpha in [0, 1]");
@@ -462,46 +481,60 @@ static int gene_dropout_impl(const XT* x, int64_t ldx, int64_t B, int64_t G, flo
   hipLaunchKernelGGL(gene_prob_kernel, dim3(1), dim3(1024), 0, st, counts, (int)B, (int)G, p, alpha, running, thr, stats);
   VAE_CHECK_LAUNCH("vae_gene_dropout(prob)");
   hipLaunchKernelGGL((normalize_rows_masked_kernel<XT>), dim3((unsigned)B), dim3(256), 0, st, x, ldx, (int)B, (int)G, thr,
-                     seed, step, mean, xn, ld_xn);
+                     seed, step, mean, xn, ld_xn, absmax);
   VAE_CHECK_LAUNCH("vae_gene_dropout(normalize)");
   return VAE_OK;
+}
+
+int vae_gene_dropout_ex(const void* x, int x_dtype, int64_t ldx, int64_t B, int64_t G, float p, float alpha, uint64_t seed,
+                        uint32_t step, float* running, int32_t* counts, uint32_t* threshold, float* stats, float* mean,
+                        float* xn, int64_t ld_xn, float* absmax, void* stream) {
+  VAE_REQUIRE(x_dtype == VAE_X_F32 || x_dtype == VAE_X_U8, "vae_gene_dropout: bad x_dtype");
+  if (x_dtype == VAE_X_U8)
+    return gene_dropout_impl<uint8_t>((const uint8_t*)x, ldx, B, G, p, alpha, seed, step, running, counts, threshold, stats,
+                                      mean, xn, ld_xn, absmax, stream);
+  return gene_dropout_impl<float>((const float*)x, ldx, B, G, p, alpha, seed, step, running, counts, threshold, stats, mean,
+                                  xn, ld_xn, absmax, stream);
 }
 
 extern "C" int vae_gene_dropout(const void* x, int x_dtype, int64_t ldx, int64_t B, int64_t G, float p, float alpha,
                                 uint64_t seed, uint32_t step, float* running, int32_t* counts, uint32_t* threshold,
                                 float* stats, float* mean, float* xn, int64_t ld_xn, void* stream) {
-  VAE_REQUIRE(x_dtype == VAE_X_F32 || x_dtype == VAE_X_U8, "vae_gene_dropout: bad x_dtype");
-  if (x_dtype == VAE_X_U8)
-    return gene_dropout_impl<uint8_t>((const uint8_t*)x, ldx, B, G, p, alpha, seed, step, running, counts, threshold, stats,
-                                      mean, xn, ld_xn, stream);
-  return gene_dropout_impl<float>((const float*)x, ldx, B, G, p, alpha, seed, step, running, counts, threshold, stats, mean,
-                                  xn, ld_xn, stream);
+  return vae_gene_dropout_ex(x, x_dtype, ldx, B, G, p, alpha, seed, step, running, counts, threshold, stats, mean, xn, ld_xn,
+                             nullptr, stream);
 }
 
 template <typename XT>
-static int normalize_rows_impl(const XT* x, int64_t ldx, int64_t B, int64_t G, float* mean, float* xn, int64_t ld_xn,
+static int normalize_rows_impl(const XT* x, int64_t ldx, int64_t B, int64_t G, float* mean, float* xn, int64_t ld_xn, float* absmax,
                                void* stream) {
   VAE_REQUIRE(x && mean && xn && B > 0 && G > 0 && ldx >= G && ld_xn >= G, "vae_normalize_rows: bad arguments");
   const bool x_ok = sizeof(XT) == 1 ? ((reinterpret_cast<uintptr_t>(x) & 3u) == 0) : vae_aligned16(x);
   const int vec = (ldx % 4 == 0) && (ld_xn % 4 == 0) && x_ok && vae_aligned16(xn);
   if (vec && G <= 256 * 4 * 20)
     hipLaunchKernelGGL((normalize_rows_kernel<true, XT>), dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, x, ldx,
-                       (int)B, (int)G, vec, mean, xn, ld_xn);
+                       (int)B, (int)G, vec, mean, xn, ld_xn, absmax);
   else
     hipLaunchKernelGGL((normalize_rows_kernel<false, XT>), dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, x, ldx,
-                       (int)B, (int)G, vec, mean, xn, ld_xn);
+                       (int)B, (int)G, vec, mean, xn, ld_xn, absmax);
   VAE_CHECK_LAUNCH("vae_normalize_rows");
   return VAE_OK;
 }
 
+int vae_normalize_rows_ex(const void* x, int x_dtype, int64_t ldx, int64_t B, int64_t G, float* mean, float* xn,
+                          int64_t ld_xn, float* absmax, void* stream) {
+  if (x_dtype == VAE_X_U8)
+    return normalize_rows_impl<uint8_t>((const uint8_t*)x, ldx, B, G, mean, xn, ld_xn, absmax, stream);
+  return normalize_rows_impl<float>((const float*)x, ldx, B, G, mean, xn, ld_xn, absmax, stream);
+}
+
 extern "C" int vae_normalize_rows(const float* x, int64_t ldx, int64_t B, int64_t G, float* mean, float* xn,
                                   int64_t ld_xn, void* stream) {
-  return normalize_rows_impl<float>(x, ldx, B, G, mean, xn, ld_xn, stream);
+  return normalize_rows_impl<float>(x, ldx, B, G, mean, xn, ld_xn, nullptr, stream);
 }
 
 extern "C" int vae_normalize_rows_u8(const uint8_t* x, int64_t ldx, int64_t B, int64_t G, float* mean, float* xn,
                                      int64_t ld_xn, void* stream) {
-  return normalize_rows_impl<uint8_t>(x, ldx, B, G, mean, xn, ld_xn, stream);
+  return normalize_rows_impl<uint8_t>(x, ldx, B, G, mean, xn, ld_xn, nullptr, stream);
 }
 
 extern "C" int vae_gelu_ln_fwd(const float* pre, int64_t ld_pre, const float* gamma, const float* beta, int64_t B,

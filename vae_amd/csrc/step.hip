@@ -5,6 +5,7 @@
 #include "../../include/vae_amd.h"
 #include "common.h"
 #include "middle.h"
+#include "internal.h"
 #include "philox.h"
 
 #include <string.h>
@@ -21,6 +22,7 @@ struct Layout {
   int64_t dz_extra, dlibrary, dheads_z, dheads_l, dpre_enc0, dh, dpx, dz;
   int64_t dbet_d, dgam_d, dbet_e, dgam_e;  // per-cell LayerNorm-gradient rows of the fused middle
   int64_t xn_z, mean_z, gene_thr, gene_counts;  // GeneDropout: the z-encoder's own normalised counts (-1: off)
+  int64_t amax;            // max|operand| slots of the two-f16-term GEMMs (AM_*)
   int64_t scratch;        // split-K slabs / column-sum slabs (shared, used by one launch at a time)
   int64_t scratch_floats;
   int64_t total;
@@ -58,6 +60,7 @@ bool make_layout(const vae_step_config& c, Layout* lo) {
   lo->dpre_enc0 = take(B * (H + Hl)); lo->dh = take(B * H); lo->dpx = take(B * Hd); lo->dz = take(B * L);
   lo->dbet_d = take(B * Hd); lo->dgam_d = take(B * Hd);
   lo->dbet_e = take(B * (H + Hl)); lo->dgam_e = take(B * (H + Hl));
+  lo->amax = take(8);
   lo->xn_z = lo->mean_z = lo->gene_thr = lo->gene_counts = -1;
   if (c.input_dropout_rate > 0.f) {
     lo->xn_z = take(B * lo->ld_xn);
@@ -91,18 +94,39 @@ bool make_layout(const vae_step_config& c, Layout* lo) {
     if (rc__ != VAE_OK) return rc__; \
   } while (0)
 
+// max|operand| slots (workspace floats at lo.amax): written by the producers with integer atomics, read by the GEMMs
+// Slots 0..AM_NACT-1 (activations / gradients) are cleared by the first kernel of every forward; the two weight slots
+// are cleared after their last reader of the step (mid_bwd_kernel; a memset on the multi-launch path), so that the next
+// forward sees the weights an optimiser may have changed.  The workspace must be zero-filled once before its first use.
+enum { AM_XN = 0, AM_XNZ, AM_PX, AM_DLOGITS, AM_DPRE, AM_NACT, AM_WENC = AM_NACT, AM_WHEADS, AM_COUNT };
+
 struct Ctx {
   const vae_step_config& c;
   float* ws;
   Layout lo;
   void* st;
+  // the two-f16-term pipeline needs 16-byte rows everywhere; ragged shapes run as VAE_FP32
+  bool fx() const { return c.precision == VAE_FP32_F16X2 && c.G % 4 == 0 && c.Hd % 4 == 0 && (c.H + c.Hl) % 4 == 0; }
+  float* am(int slot) const { return fx() ? ws + lo.amax + slot : nullptr; }
+  // one of the five gene-sized products: two-f16-term split when the step runs in VAE_FP32_F16X2, else as `gemm`;
+  // slabs_out != null leaves split-K slabs in the scratch (no bias) for the fused middle
+  int big(int layout, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, int slot_a, const float* Bm, int64_t ldb,
+          int slot_b, float* C, int64_t ldc, const float* bias, int* slabs_out) const {
+    if (fx())
+      return vae_gemm_f16x2(layout, M, N, K, A, lda, am(slot_a), Bm, ldb, am(slot_b), C, ldc, bias, 0, ws + lo.scratch,
+                            lo.scratch_floats * 4, st, slabs_out);
+    if (slabs_out)
+      return vae_gemm_slabs(layout, c.precision, M, N, K, A, lda, Bm, ldb, ws + lo.scratch, lo.scratch_floats * 4, slabs_out, st);
+    return vae_gemm(layout, c.precision, M, N, K, A, lda, Bm, ldb, C, ldc, bias, nullptr, 0, ws + lo.scratch,
+                    lo.scratch_floats * 4, st);
+  }
   // nn.Dropout after a hidden LayerNorm (forward: the activation; backward: the gradient arriving there)
   int drop(float* x, int64_t ld, int64_t W, uint32_t site) const {
     return vae_dropout_apply(x, ld, c.B, W, c.dropout_rate, c.rng_seed, c.rng_step, site, st);
   }
   int gemm(int layout, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* Bm, int64_t ldb,
            float* C, int64_t ldc, const float* bias, const float* mean, int acc) const {
-    return vae_gemm(layout, c.precision, M, N, K, A, lda, Bm, ldb, C, ldc, bias, mean, acc, ws + lo.scratch,
+    return vae_gemm(layout, fx() ? VAE_FP32 : c.precision, M, N, K, A, lda, Bm, ldb, C, ldc, bias, mean, acc, ws + lo.scratch,
                     lo.scratch_floats * 4, st);
   }
 };
@@ -116,6 +140,8 @@ int check_common(const vae_step_config* cfg, const void* a, const void* b, const
   if (cfg->G > vae_nbzinb_max_genes())
     return vae_set_error(VAE_ERR_ARG, "%s: G=%lld exceeds %lld", who, (long long)cfg->G, (long long)vae_nbzinb_max_genes());
   if (!(cfg->l_var > 0.f)) return vae_set_error(VAE_ERR_ARG, "%s: l_var must be positive", who);
+  if (cfg->precision != VAE_FP32 && cfg->precision != VAE_BF16 && cfg->precision != VAE_FP32_F16X2)
+    return vae_set_error(VAE_ERR_ARG, "%s: precision must be VAE_FP32, VAE_BF16 or VAE_FP32_F16X2", who);
   if (!(cfg->dropout_rate >= 0.f && cfg->dropout_rate < 1.f))
     return vae_set_error(VAE_ERR_ARG, "%s: dropout_rate must be in [0, 1)", who);
   if (!(cfg->input_dropout_rate >= 0.f && cfg->input_dropout_rate <= 1.f))
@@ -154,6 +180,7 @@ extern "C" int64_t vae_elbo_step_ws_offset(const vae_step_config* cfg, int slice
     case VAE_WS_DZ_EXTRA: return lo.dz_extra;
     case VAE_WS_RECON: return lo.recon;
     case VAE_WS_GENE_THRESHOLD: return lo.gene_thr;
+    case VAE_WS_OPERAND_MAXIMA: return lo.amax;
     default: return -1;
   }
 }
@@ -170,41 +197,42 @@ extern "C" int vae_elbo_step_forward(const vae_step_config* cfg, const vae_step_
   const int64_t B = c.B, G = c.G, H = c.H, Hl = c.Hl, L = c.L, Hd = c.Hd, HE = c.H + c.Hl;
   const int64_t NH = c.zinb ? 2 * G : G;
 
+  if (k.fx())  // weight maxima of the two-f16-term products; the same launch clears the activations' slots of this step
+    TRY(vae_absmax_weights(p->enc_w0, HE * G, p->heads_w, NH * Hd, k.am(AM_WENC), k.am(AM_WHEADS), k.am(0), AM_NACT, stream));
   // encoders: x/mean-1 -> Linear(G, H+Hl) -> GELU -> LayerNorm (z and library halves)
-  if (u8) TRY(vae_normalize_rows_u8(x8, ldx, B, G, ws + lo.mean, ws + lo.xn, lo.ld_xn, stream));
-  else TRY(vae_normalize_rows(x, ldx, B, G, ws + lo.mean, ws + lo.xn, lo.ld_xn, stream));
+  TRY(vae_normalize_rows_ex(xv, c.x_dtype, ldx, B, G, ws + lo.mean, ws + lo.xn, lo.ld_xn, k.am(AM_XN), stream));
   // GeneDropout (training): the z-encoder reads its own masked + normalised counts, the library encoder xn
   const bool gd = c.input_dropout_rate > 0.f;
   if (gd)
-    TRY(vae_gene_dropout(xv, c.x_dtype, ldx, B, G, c.input_dropout_rate, c.input_dropout_alpha, c.rng_seed, c.rng_step,
-                         c.gene_running, (int32_t*)(ws + lo.gene_counts), (uint32_t*)(ws + lo.gene_thr),
-                         ws + lo.gene_thr + G, ws + lo.mean_z, ws + lo.xn_z, lo.ld_xn, stream));
+    TRY(vae_gene_dropout_ex(xv, c.x_dtype, ldx, B, G, c.input_dropout_rate, c.input_dropout_alpha, c.rng_seed, c.rng_step,
+                            c.gene_running, (int32_t*)(ws + lo.gene_counts), (uint32_t*)(ws + lo.gene_thr),
+                            ws + lo.gene_thr + G, ws + lo.mean_z, ws + lo.xn_z, lo.ld_xn, k.am(AM_XNZ), stream));
   const float* px;
   if (vae_mid_supported(c)) {
     // one launch from the encoder slabs to the decoder hidden layer
     int nslab = 0;
     const float* slabs = ws + lo.scratch;
     if (gd) {  // two products (different inputs), left without bias in pre_enc0 = a single "slab"
-      TRY(k.gemm(VAE_NT, B, H, G, ws + lo.xn_z, lo.ld_xn, p->enc_w0, G, ws + lo.pre_enc0, HE, nullptr, nullptr, 0));
-      TRY(k.gemm(VAE_NT, B, Hl, G, ws + lo.xn, lo.ld_xn, p->enc_w0 + H * G, G, ws + lo.pre_enc0 + H, HE, nullptr, nullptr, 0));
+      TRY(k.big(VAE_NT, B, H, G, ws + lo.xn_z, lo.ld_xn, AM_XNZ, p->enc_w0, G, AM_WENC, ws + lo.pre_enc0, HE, nullptr, nullptr));
+      TRY(k.big(VAE_NT, B, Hl, G, ws + lo.xn, lo.ld_xn, AM_XN, p->enc_w0 + H * G, G, AM_WENC, ws + lo.pre_enc0 + H, HE, nullptr,
+                nullptr));
       slabs = ws + lo.pre_enc0;
       nslab = 1;
     } else {
-      TRY(vae_gemm_slabs(VAE_NT, c.precision, B, HE, G, ws + lo.xn, lo.ld_xn, p->enc_w0, G, ws + lo.scratch,
-                         lo.scratch_floats * 4, &nslab, stream));
+      TRY(k.big(VAE_NT, B, HE, G, ws + lo.xn, lo.ld_xn, AM_XN, p->enc_w0, G, AM_WENC, nullptr, HE, nullptr, &nslab));
     }
     TRY(vae_mid_forward(c, p, slabs, nslab, eps_z, eps_l, ws + lo.pre_enc0, ws + lo.h_enc0, ws + lo.ln_mz[0],
                         ws + lo.ln_rz[0], ws + lo.ln_ml, ws + lo.ln_rl, ws + lo.heads_z, ws + lo.heads_l, ws + lo.qz_v,
                         ws + lo.z, ws + lo.kl_z, ws + lo.ql_v, ws + lo.library, ws + lo.kl_l, ws + lo.dec_pre[0],
-                        ws + lo.dec_h[0], ws + lo.ln_md[0], ws + lo.ln_rd[0], stream));
+                        ws + lo.dec_h[0], ws + lo.ln_md[0], ws + lo.ln_rd[0], k.am(AM_PX), stream));
     px = ws + lo.dec_h[0];
   } else {
     if (gd) {
-      TRY(k.gemm(VAE_NT, B, H, G, ws + lo.xn_z, lo.ld_xn, p->enc_w0, G, ws + lo.pre_enc0, HE, p->enc_b0, nullptr, 0));
-      TRY(k.gemm(VAE_NT, B, Hl, G, ws + lo.xn, lo.ld_xn, p->enc_w0 + H * G, G, ws + lo.pre_enc0 + H, HE, p->enc_b0 + H,
-                 nullptr, 0));
+      TRY(k.big(VAE_NT, B, H, G, ws + lo.xn_z, lo.ld_xn, AM_XNZ, p->enc_w0, G, AM_WENC, ws + lo.pre_enc0, HE, p->enc_b0, nullptr));
+      TRY(k.big(VAE_NT, B, Hl, G, ws + lo.xn, lo.ld_xn, AM_XN, p->enc_w0 + H * G, G, AM_WENC, ws + lo.pre_enc0 + H, HE,
+                p->enc_b0 + H, nullptr));
     } else {
-      TRY(k.gemm(VAE_NT, B, HE, G, ws + lo.xn, lo.ld_xn, p->enc_w0, G, ws + lo.pre_enc0, HE, p->enc_b0, nullptr, 0));
+      TRY(k.big(VAE_NT, B, HE, G, ws + lo.xn, lo.ld_xn, AM_XN, p->enc_w0, G, AM_WENC, ws + lo.pre_enc0, HE, p->enc_b0, nullptr));
     }
     TRY(vae_gelu_ln_fwd(ws + lo.pre_enc0, HE, p->encz_ln_g[0], p->encz_ln_b[0], B, H, ws + lo.h_enc0, HE,
                         ws + lo.ln_mz[0], ws + lo.ln_rz[0], stream));
@@ -240,7 +268,8 @@ extern "C" int vae_elbo_step_forward(const vae_step_config* cfg, const vae_step_
     }
   }
   // decoder heads -> fused softmax / library scale / NB-ZINB / row sum -> ELBO scalars
-  TRY(k.gemm(VAE_NT, B, NH, Hd, px, Hd, p->heads_w, Hd, ws + lo.logits, NH, p->heads_b, nullptr, 0));
+  if (k.fx() && !vae_mid_supported(c)) TRY(vae_absmax_accumulate(px, B, Hd, Hd, k.am(AM_PX), stream));
+  TRY(k.big(VAE_NT, B, NH, Hd, px, Hd, AM_PX, p->heads_w, Hd, AM_WHEADS, ws + lo.logits, NH, p->heads_b, nullptr));
   TRY(vae_gene_table(p->px_r, G, ws + lo.table, stream));
   if (u8) TRY(vae_nbzinb_fwd_u8(c.zinb, ws + lo.logits, NH, c.zinb ? ws + lo.logits + G : nullptr, NH, x8, ldx, ws + lo.library,
                      ws + lo.table, B, G, ws + lo.ll, ws + lo.rowmax, ws + lo.rowsum, ws + lo.S, stream));
@@ -284,28 +313,24 @@ extern "C" int vae_elbo_step_backward(const vae_step_config* cfg, const vae_step
   float* lp = c.zinb ? logits + G : nullptr;
 
   // epilogue backward: logits := dlogits (in place); d px_r and the head-bias gradients are overwritten
-  if (u8) TRY(vae_nbzinb_bwd_u8(c.zinb, logits, NH, lp, NH, x8, ldx, ws + lo.library, ws + lo.table, ws + lo.rowmax, ws + lo.rowsum,
-                     ws + lo.S, nullptr, g_ll, B, G, logits, NH, lp, NH, ws + lo.dlibrary, g->px_r, g->heads_b,
-                     c.zinb ? g->heads_b + G : nullptr, ws + lo.scratch, lo.scratch_floats * 4, 1, stream));
-  else TRY(vae_nbzinb_bwd_overwrite(c.zinb, logits, NH, lp, NH, x, ldx, ws + lo.library, ws + lo.table, ws + lo.rowmax, ws + lo.rowsum,
-                     ws + lo.S, nullptr, g_ll, B, G, logits, NH, lp, NH, ws + lo.dlibrary, g->px_r, g->heads_b,
-                     c.zinb ? g->heads_b + G : nullptr, ws + lo.scratch, lo.scratch_floats * 4, stream));
+  TRY(vae_nbzinb_bwd_ex(c.x_dtype, c.zinb, logits, NH, lp, NH, xv, ldx, ws + lo.library, ws + lo.table, ws + lo.rowmax,
+                        ws + lo.rowsum, ws + lo.S, nullptr, g_ll, B, G, logits, NH, lp, NH, ws + lo.dlibrary, g->px_r, g->heads_b,
+                        c.zinb ? g->heads_b + G : nullptr, ws + lo.scratch, lo.scratch_floats * 4, k.am(AM_DLOGITS), stream));
   const float* px = ws + lo.dec_h[c.n_layers - 1];
-  TRY(k.gemm(VAE_TN, NH, Hd, B, logits, NH, px, Hd, g->heads_w, Hd, nullptr, nullptr, 0));  // dW = dlogits^T px
+  TRY(k.big(VAE_TN, NH, Hd, B, logits, NH, AM_DLOGITS, px, Hd, AM_PX, g->heads_w, Hd, nullptr, nullptr));  // dW = dlogits^T px
   if (event_heads_ready) {
     if (hipEventRecord((hipEvent_t)event_heads_ready, (hipStream_t)stream) != hipSuccess)
       return vae_set_error(VAE_ERR_LAUNCH, "vae_elbo_step_backward: hipEventRecord failed");
   }
   if (vae_mid_supported(c)) {
     int nslab = 0;
-    TRY(vae_gemm_slabs(VAE_NN, c.precision, B, Hd, NH, logits, NH, p->heads_w, Hd, ws + lo.scratch, lo.scratch_floats * 4,
-                       &nslab, stream));
+    TRY(k.big(VAE_NN, B, Hd, NH, logits, NH, AM_DLOGITS, p->heads_w, Hd, AM_WHEADS, nullptr, Hd, nullptr, &nslab));
     TRY(vae_mid_backward(c, p, g, ws + lo.scratch, nslab, eps_z, eps_l, use_dz_extra ? ws + lo.dz_extra : nullptr, g_kl,
                          ws + lo.dec_pre[0], ws + lo.ln_md[0], ws + lo.ln_rd[0], ws + lo.heads_z, ws + lo.heads_l,
                          ws + lo.qz_v, ws + lo.ql_v, ws + lo.dlibrary, ws + lo.pre_enc0, ws + lo.ln_mz[0], ws + lo.ln_rz[0],
                          ws + lo.ln_ml, ws + lo.ln_rl, ws + lo.z, ws + lo.h_enc0, ws + lo.dbet_d, ws + lo.dgam_d,
                          ws + lo.dpx, ws + lo.dheads_z, ws + lo.dheads_l, ws + lo.dbet_e, ws + lo.dgam_e,
-                         ws + lo.dpre_enc0, stream));
+                         ws + lo.dpre_enc0, k.am(AM_DPRE), k.am(AM_WENC), k.fx() ? 2 : 0, stream));
   } else {
     // the unfused kernels ACCUMULATE the LayerNorm / bias gradients with atomics: clear them first
     auto zero = [&](float* q, int64_t n) {
@@ -319,7 +344,7 @@ extern "C" int vae_elbo_step_backward(const vae_step_config* cfg, const vae_step
     }
     TRY(zero(g->encl_ln_g, Hl)); TRY(zero(g->encl_ln_b, Hl)); TRY(zero(g->enc_b0, HE));
     TRY(zero(g->hz_b, L + 1)); TRY(zero(g->hl_b, 2));
-    TRY(k.gemm(VAE_NN, B, Hd, NH, logits, NH, p->heads_w, Hd, ws + lo.dpx, Hd, nullptr, nullptr, 0));
+    TRY(k.big(VAE_NN, B, Hd, NH, logits, NH, AM_DLOGITS, p->heads_w, Hd, AM_WHEADS, ws + lo.dpx, Hd, nullptr, nullptr));
 
     // decoder hidden layers
     float* dcur = ws + lo.dpx;
@@ -372,12 +397,17 @@ extern "C" int vae_elbo_step_backward(const vae_step_config* cfg, const vae_step
                         ws + lo.dpre_enc0, HE, g->encz_ln_g[0], g->encz_ln_b[0], g->enc_b0, stream));
     TRY(vae_gelu_ln_bwd(ws + lo.dpre_enc0 + H, HE, ws + lo.pre_enc0 + H, HE, ws + lo.ln_ml, ws + lo.ln_rl, p->encl_ln_g, B,
                         Hl, ws + lo.dpre_enc0 + H, HE, g->encl_ln_g, g->encl_ln_b, g->enc_b0 + H, stream));
+    if (k.fx()) {
+      TRY(vae_absmax_accumulate(ws + lo.dpre_enc0, B, HE, HE, k.am(AM_DPRE), stream));
+      TRY(zero(k.am(AM_WENC), 2));   // the weight maxima: refilled by the next forward
+    }
   }
   if (c.input_dropout_rate > 0.f) {  // GeneDropout: each encoder's weight gradient over its own input
-    TRY(k.gemm(VAE_TN, H, G, B, ws + lo.dpre_enc0, HE, ws + lo.xn_z, lo.ld_xn, g->enc_w0, G, nullptr, nullptr, 0));
-    TRY(k.gemm(VAE_TN, Hl, G, B, ws + lo.dpre_enc0 + H, HE, ws + lo.xn, lo.ld_xn, g->enc_w0 + H * G, G, nullptr, nullptr, 0));
+    TRY(k.big(VAE_TN, H, G, B, ws + lo.dpre_enc0, HE, AM_DPRE, ws + lo.xn_z, lo.ld_xn, AM_XNZ, g->enc_w0, G, nullptr, nullptr));
+    TRY(k.big(VAE_TN, Hl, G, B, ws + lo.dpre_enc0 + H, HE, AM_DPRE, ws + lo.xn, lo.ld_xn, AM_XN, g->enc_w0 + H * G, G, nullptr,
+              nullptr));
   } else {
-    TRY(k.gemm(VAE_TN, HE, G, B, ws + lo.dpre_enc0, HE, ws + lo.xn, lo.ld_xn, g->enc_w0, G, nullptr, nullptr, 0));
+    TRY(k.big(VAE_TN, HE, G, B, ws + lo.dpre_enc0, HE, AM_DPRE, ws + lo.xn, lo.ld_xn, AM_XN, g->enc_w0, G, nullptr, nullptr));
   }
   return VAE_OK;
 }

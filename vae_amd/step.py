@@ -76,10 +76,14 @@ class ElboStep:
     """
 
     def __init__(self, arena: ParamArena, *, l_mean: float, l_var: float, kl_weight: float = 1.0,
-                 gene_loss_coeff: float = 5e-3, precision: int = ops.FP32, dropout_rate: float = 0.0, seed: int = 0,
+                 gene_loss_coeff: float = 5e-3, precision: int = ops.F16X2, dropout_rate: float = 0.0, seed: int = 0,
                  input_dropout_rate: float = 0.0, input_dropout_alpha: float = 0.95,
                  gene_running: Optional[torch.Tensor] = None):
-        """``dropout_rate``: p of the nn.Dropout after the z-encoder / decoder LayerNorms (modules.py:115),
+        """``precision``: ``ops.F16X2`` (default; fp32-grade: the five gene-sized products on two scaled f16 terms and
+        three matrix-core products, everything else as ``ops.FP32``), ``ops.FP32`` (three bf16 terms, six products:
+        element-wise fp32-grade for any operand range) or ``ops.BF16``.
+
+        ``dropout_rate``: p of the nn.Dropout after the z-encoder / decoder LayerNorms (modules.py:115),
         applied by ``run(..., train=True)`` with masks from the library's Philox stream keyed by ``seed``
         (give every rank its own) and the step counter ``rng_step``.
 
@@ -96,7 +100,7 @@ class ElboStep:
         self.zinb = arena.likelihood == "zinb"
         self.l_mean, self.l_var = float(l_mean), float(l_var)
         self.kl_weight, self.coeff = float(kl_weight), float(gene_loss_coeff)
-        self.precision = precision
+        self.precision = int(os.environ.get("VAE_STEP_PRECISION", precision))   # env: A/B the GEMM precision of a run
         if not 0.0 <= float(dropout_rate) < 1.0:
             raise ValueError(f"ElboStep: dropout_rate must be in [0, 1), got {dropout_rate}")
         self.dropout_rate, self.seed, self.rng_step = float(dropout_rate), int(seed) & (2 ** 64 - 1), 0
@@ -142,7 +146,7 @@ class ElboStep:
             nbytes = self.lib.vae_elbo_step_workspace_bytes(C.byref(cfg))
             if nbytes <= 0:
                 raise RuntimeError("vae_amd: bad step configuration")
-            ws = torch.empty(nbytes // 4, dtype=torch.float32, device=self.a.device)
+            ws = torch.zeros(nbytes // 4, dtype=torch.float32, device=self.a.device)   # zero once: operand-maxima slots
             off = {n: self.lib.vae_elbo_step_ws_offset(C.byref(cfg), i) for i, n in enumerate(_lib.WS_SLICES)}
             L = self.L
             v = dict(
@@ -158,6 +162,7 @@ class ElboStep:
                 scalars=ws[off["SCALARS"]:off["SCALARS"] + 5],
                 dz_extra=ws[off["DZ_EXTRA"]:off["DZ_EXTRA"] + B * L].view(B, L),
                 recon=ws[off["RECON"]:off["RECON"] + B],
+                weight_maxima=ws[off["OPERAND_MAXIMA"] + 5:off["OPERAND_MAXIMA"] + 7],
             )
             if gene_drop:   # keep thresholds floor(p_g * 2^32) as int32 bit patterns, then mean_g(p_g)
                 o = off["GENE_THRESHOLD"]
@@ -232,6 +237,8 @@ class ElboStep:
             out["loss"] = s[4]
         if not backward:
             self._last_fwd = (B, cfg, ws, nbytes)
+            if self.precision == ops.F16X2:
+                v["weight_maxima"].zero_()   # no backward will clear them: the weights may change before the next forward
             return out
         self._last_fwd = None   # the backward overwrites the logits in place
 

@@ -68,7 +68,7 @@ class LitVAE(nn.Module):
         library_var: Optional[float] = None,
         subject_batch_size: int = 1,
         use_gdro: bool = False,
-        precision: int = ops.FP32,
+        precision: int = ops.F16X2,
     ):
         super().__init__()
         self.network = network

@@ -49,7 +49,7 @@ def main(train_idx: List[int], test_idx: List[int], cell_class: str, additional_
     x_all = x_all.to(device=device, dtype=torch.float32)
     network = VAE(n_input=x_all.shape[1], cell_properties=cell_properties, batch_properties=None, **mcfg)
     lib_mean, lib_var = library_size_stats(x_all)
-    precision = ops.BF16 if str(rcfg["precision"]).startswith("bf16") else ops.FP32
+    precision = ops.BF16 if str(rcfg["precision"]).startswith("bf16") else ops.F16X2
     use_heads = cell_prop_vals is not None
     task = LitVAE(network, cell_properties=cell_properties if use_heads else None, library_mean=lib_mean,
                   library_var=lib_var, precision=precision,
