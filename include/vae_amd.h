@@ -275,9 +275,8 @@ enum { VAE_WS_QZ_HEADS = 0, /* (B, L+1): [:, :L] = qz_m                         
        VAE_WS_DZ_EXTRA,/* (B, L): written by the CALLER between forward and backward (cell heads)  */
        VAE_WS_RECON,   /* (B) = -ll                                                                */
        VAE_WS_GENE_THRESHOLD, /* (G) uint32 keep thresholds of GeneDropout, then 1 float mean_g(p_g); -1 when off */
-       VAE_WS_OPERAND_MAXIMA, /* 8 floats: max|operand| slots of VAE_FP32_F16X2 (kernels maintain them; the workspace
-                               * must be zero-filled once before its first use, and slots 5..6 -- the weight maxima --
-                               * cleared by the caller if the weights change without a backward in between)      */
+       VAE_WS_OPERAND_MAXIMA, /* start of the partial maxima of the VAE_FP32_F16X2 operands: rewritten in full by the
+                               * kernels of every step, nothing for the caller to initialise or clear            */
        VAE_WS_NSLICES };
 int64_t vae_elbo_step_workspace_bytes(const vae_step_config* cfg);
 int64_t vae_elbo_step_ws_offset(const vae_step_config* cfg, int slice);

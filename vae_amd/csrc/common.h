@@ -28,12 +28,15 @@ static inline bool vae_aligned16(const void* p) { return (reinterpret_cast<uintp
 #ifdef __HIPCC__
 constexpr int WAVE = 64;
 
-// Running maximum of |v| in a float slot that starts at 0: non-negative floats order like their bit patterns, so an
-// integer atomic does it -- order-independent, hence deterministic.  (A NaN ends up in the slot and disables the scale.)
-__device__ __forceinline__ void vae_atomic_absmax(float* slot, float v) {
-  const unsigned int bits = __float_as_uint(fabsf(v));
-  // most callers do not raise the maximum: a plain (possibly stale) read filters them, the atomic keeps it exact
-  if (bits > *reinterpret_cast<volatile unsigned int*>(slot)) atomicMax(reinterpret_cast<unsigned int*>(slot), bits);
+// Operand maxima of the two-f16-term products travel as ARRAYS of partial maxima: every wave (or workgroup) of the
+// kernel that produces an operand stores the largest magnitude it wrote into its own entry (plain stores: nothing to
+// clear, no atomics, trivially deterministic) and the GEMM that consumes the operand reduces the array in its prologue.
+// Wave-level form: every lane passes its candidate, lane 0 stores the wave's maximum.
+__device__ __forceinline__ void vae_wave_absmax_store(float* entry, float v) {
+  v = fabsf(v);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  if ((threadIdx.x & 63) == 0) *entry = v;
 }
 // The power of two that puts an operand with maximum magnitude m into [2^13, 2^14): the scale of the two-f16-term
 // products (gemm.hip).  1 for m = 0, inf or NaN.

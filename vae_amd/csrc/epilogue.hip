@@ -450,10 +450,10 @@ __global__ __launch_bounds__(256) void nbzinb_bwd_kernel(
 #pragma unroll
     for (int j = 0; j < 4; ++j) d0[j] = d1[j];
   }
-  if (absmax) {  // threads past G have left: LDS integer max of the rest, then one global integer atomic per workgroup
+  if (absmax) {  // threads past G have left: LDS integer max of the rest, then this workgroup's entry of the partial maxima
     atomicMax(&wg_absmax, __float_as_uint(am));
     __syncthreads();
-    if (threadIdx.x == 0) atomicMax(reinterpret_cast<unsigned int*>(absmax), wg_absmax);
+    if (threadIdx.x == 0) absmax[blockIdx.y * gridDim.x + blockIdx.x] = __uint_as_float(wg_absmax);
   }
   if (SLAB) {
     // partial column sums of this cell chunk: plain coalesced stores into slab[chunk][3][G];
@@ -621,6 +621,12 @@ extern "C" int64_t vae_nbzinb_bwd_workspace_bytes(int64_t B, int64_t G) {
   int strips, chunks, rpb;
   bwd_grid(B, G, &strips, &chunks, &rpb);
   return (int64_t)chunks * 3 * G * (int64_t)sizeof(float);
+}
+
+int64_t vae_nbzinb_bwd_workgroups(int64_t B, int64_t G) {
+  int strips, chunks, rpb;
+  bwd_grid(B, G, &strips, &chunks, &rpb);
+  return (int64_t)strips * chunks;
 }
 
 template <typename XT>

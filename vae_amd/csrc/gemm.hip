@@ -49,7 +49,8 @@ struct GemmArgs {
   int tiles_m, tiles_n;
   const float* sa;     // gemm_x3_kernel<NP = 2> (two f16 terms): device pointers to the power-of-two factors the
   const float* sb;     // operands are multiplied by before the split (null = 1); the product is scaled back
-  int scale_is_absmax; // sa / sb point at max|A| / max|B| (written by the producers); the kernel derives the factors
+  int na, nb;          // > 0: sa / sb are arrays of na / nb partial maxima of |A| / |B| written by the producers of the
+                       // operands; the kernel reduces them and derives the factors (0: sa / sb are the factors)
 };
 
 // ---- global -> register tile loaders (R*8/256 float4 per thread per operand, R = 64 or 128) ----
@@ -714,11 +715,42 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(GemmArgs g) {
       rb[i] = kk < tail ? *reinterpret_cast<const float4*>(pb[i]) : Z;
     }
   };
-  float scA = 1.f, scB = 1.f;   // NP == 2: operand scales (uniform loads)
-  if (NP == 2) {
-    if (g.sa) scA = g.scale_is_absmax ? vae_scale_from_absmax(*g.sa) : *g.sa;
-    if (g.sb) scB = g.scale_is_absmax ? vae_scale_from_absmax(*g.sb) : *g.sb;
-  }
+  float scA = 1.f, scB = 1.f;   // NP == 2: operand scales
+  // Maximum of n partial maxima (16-byte aligned array): 16-byte loads, four in flight per lane
+  auto partial_max = [&](const float* __restrict__ p, int n) {
+    float m = 0.f;
+    const float4* p4 = reinterpret_cast<const float4*>(p);
+    const int n4 = n >> 2;
+    auto m4 = [](const float4& v) { return fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)); };
+    int i = tid;
+    for (; i + 768 < n4; i += 1024) {
+      const float4 a = p4[i], b = p4[i + 256], c = p4[i + 512], d = p4[i + 768];
+      m = fmaxf(m, fmaxf(fmaxf(m4(a), m4(b)), fmaxf(m4(c), m4(d))));
+    }
+    for (; i < n4; i += 256) m = fmaxf(m, m4(p4[i]));
+    for (int j = (n4 << 2) + tid; j < n; j += 256) m = fmaxf(m, p[j]);
+    return m;
+  };
+  // Called once, after the first tile's loads are issued (its latency hides behind them) and before the first split
+  auto scales = [&]() {
+    if (NP != 2) return;
+    if (g.na > 0 || g.nb > 0) {  // reduce the producers' partial maxima (a few KB, L2-resident)
+      __shared__ float red_s[8];
+      float ma = partial_max(g.sa, g.na), mb = partial_max(g.sb, g.nb);
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        ma = fmaxf(ma, __shfl_xor(ma, o, 64));
+        mb = fmaxf(mb, __shfl_xor(mb, o, 64));
+      }
+      if (lane == 0) { red_s[wave] = ma; red_s[4 + wave] = mb; }
+      __syncthreads();
+      scA = vae_scale_from_absmax(fmaxf(fmaxf(red_s[0], red_s[1]), fmaxf(red_s[2], red_s[3])));
+      scB = vae_scale_from_absmax(fmaxf(fmaxf(red_s[4], red_s[5]), fmaxf(red_s[6], red_s[7])));
+    } else {
+      if (g.sa) scA = *g.sa;
+      if (g.sb) scB = *g.sb;
+    }
+  };
   auto put = [&](__bf16* base, int plane, int off, const float4& v, float sc) {
     const float f[4] = {v.x, v.y, v.z, v.w};
     if (NP == 2) {  // two f16 terms of the scaled value: hi = rn(a s), lo = rn(a s - hi): 22 significant bits
@@ -838,6 +870,7 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(GemmArgs g) {
   const int tail = kend > kbeg ? (kend - kbeg) % BK : 0;   // only the last slab of a K that is not a multiple of 32
   if (nfull > 0) fetch();
   else if (tail) fetch_tail(tail);
+  scales();
   for (int i = 0; i < nfull; ++i) {
 #ifdef VAE_ABL   // ablations for tools/micro/gemm_probe.hip: 1 = stage once, 2 = fetch once, 4 = no multiply
     if (!(VAE_ABL & 1) || i == 0) stage();
@@ -1023,7 +1056,7 @@ namespace {
 int gemm_impl(int layout, int precision, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B,
               int64_t ldb, float* C, int64_t ldc, const float* bias, const float* x_mean, int accumulate,
               float* workspace, int64_t workspace_bytes, void* stream, int* slabs_out, const float* scale_a = nullptr,
-              const float* scale_b = nullptr, int scale_is_absmax = 0) {
+              const float* scale_b = nullptr, int n_max_a = 0, int n_max_b = 0) {
   VAE_REQUIRE(layout >= 0 && layout <= 2, "vae_gemm: layout must be 0 (NT), 1 (NN) or 2 (TN), got %d", layout);
   VAE_REQUIRE(precision >= 0 && precision <= 3, "vae_gemm: precision must be 0 (fp32), 1 (bf16), 2 (bf16x3) or 3 (f16x2), got %d",
               precision);
@@ -1041,7 +1074,9 @@ int gemm_impl(int layout, int precision, int64_t M, int64_t N, int64_t K, const 
 
   GemmArgs g;
   g.A = A; g.B = B; g.C = C; g.bias = bias; g.mean = x_mean;
-  g.sa = scale_a; g.sb = scale_b; g.scale_is_absmax = scale_is_absmax;
+  VAE_REQUIRE((n_max_a <= 0 || vae_aligned16(scale_a)) && (n_max_b <= 0 || vae_aligned16(scale_b)),
+              "vae_gemm: partial maxima must be 16-byte aligned");
+  g.sa = scale_a; g.sb = scale_b; g.na = n_max_a; g.nb = n_max_b;
   g.lda = lda; g.ldb = ldb; g.ldc = ldc;
   g.M = (int)M; g.N = (int)N; g.K = (int)K;
   g.accumulate = accumulate;
@@ -1200,19 +1235,17 @@ __global__ __launch_bounds__(256) void absmax_raw_kernel(const float* __restrict
     }
   }
   m = block_max<4>(m, red);
-  if (threadIdx.x == 0) vae_atomic_absmax(slot, m);
+  if (threadIdx.x == 0) slot[blockIdx.x] = m;
 }
 }  // namespace
 
 namespace {
-// max|w| of two dense arrays (the two gene-sized weight matrices) in ONE launch: blocks [0, nb0) scan w0, the rest w1,
-// four 16-byte loads in flight per lane; block 0 first clears `nzero` other slots (the activations' maxima of the
-// step that starts here -- they are only written by later kernels of the stream).
+// max|w| of two dense arrays (the two gene-sized weight matrices) in ONE launch: blocks [0, nb0) scan w0 and write
+// part0[block], the rest scan w1 and write part1[block - nb0]; four 16-byte loads in flight per lane.
 __global__ __launch_bounds__(256) void absmax_weights_kernel(const float* __restrict__ w0, int64_t n0, int nb0,
-                                                             const float* __restrict__ w1, int64_t n1, float* slot0,
-                                                             float* slot1, float* zero_slots, int nzero) {
+                                                             const float* __restrict__ w1, int64_t n1, float* part0,
+                                                             float* part1) {
   __shared__ float red[4];
-  if (blockIdx.x == 0 && (int)threadIdx.x < nzero) zero_slots[threadIdx.x] = 0.f;
   const bool first = (int)blockIdx.x < nb0;
   const float* w = first ? w0 : w1;
   const int64_t n4 = (first ? n0 : n1) >> 2;
@@ -1233,45 +1266,38 @@ __global__ __launch_bounds__(256) void absmax_weights_kernel(const float* __rest
     m = fmaxf(m, fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w))));
   }
   m = block_max<4>(m, red);
-  if (threadIdx.x == 0) vae_atomic_absmax(first ? slot0 : slot1, m);
+  if (threadIdx.x == 0) (first ? part0 : part1)[bi] = m;
 }
 }  // namespace
 
-// max|w0|, max|w1| raised into slot0 / slot1 (the caller guarantees they start at 0) and `nzero` floats at zero_slots
-// cleared, one launch.  n0, n1 multiples of 4, 16-byte aligned arrays.
-int vae_absmax_weights(const float* w0, int64_t n0, const float* w1, int64_t n1, float* slot0, float* slot1, float* zero_slots,
-                       int nzero, void* stream) {
-  VAE_REQUIRE(w0 && w1 && slot0 && slot1 && n0 > 0 && n1 > 0 && n0 % 4 == 0 && n1 % 4 == 0 && vae_aligned16(w0) &&
-                  vae_aligned16(w1) && nzero >= 0 && nzero <= 256 && (nzero == 0 || zero_slots),
-              "vae_absmax_weights: bad arguments");
-  const int total = 1024;
-  int nb0 = (int)((double)total * (double)n0 / (double)(n0 + n1));
-  if (nb0 < 1) nb0 = 1;
-  if (nb0 > total - 1) nb0 = total - 1;
-  hipLaunchKernelGGL(absmax_weights_kernel, dim3(total), dim3(256), 0, (hipStream_t)stream, w0, n0, nb0, w1, n1, slot0, slot1,
-                     zero_slots, nzero);
+// part0[0 .. VAE_ABSMAX_W_SPLIT) / part1[0 .. VAE_ABSMAX_PARTIALS - VAE_ABSMAX_W_SPLIT) = partial maxima of |w0| / |w1|,
+// one launch.  n0, n1 multiples of 4, 16-byte aligned arrays.
+int vae_absmax_weights(const float* w0, int64_t n0, const float* w1, int64_t n1, float* part0, float* part1, void* stream) {
+  VAE_REQUIRE(w0 && w1 && part0 && part1 && n0 > 0 && n1 > 0 && n0 % 4 == 0 && n1 % 4 == 0 && vae_aligned16(w0) &&
+                  vae_aligned16(w1), "vae_absmax_weights: bad arguments");
+  hipLaunchKernelGGL(absmax_weights_kernel, dim3(VAE_ABSMAX_PARTIALS), dim3(256), 0, (hipStream_t)stream, w0, n0,
+                     VAE_ABSMAX_W_SPLIT, w1, n1, part0, part1);
   VAE_CHECK_LAUNCH("vae_absmax_weights");
   return VAE_OK;
 }
 
 // ---- internal (internal.h): used by step.hip --------------------------------------------------
-// slot = max(slot, max|X|): one launch, integer atomic; the caller zeroes the slot once per step.
-int vae_absmax_accumulate(const float* X, int64_t rows, int64_t cols, int64_t ld, float* slot, void* stream) {
-  VAE_REQUIRE(X && slot && rows > 0 && cols > 0 && cols < (1 << 30) && ld >= cols, "vae_absmax_accumulate: bad arguments");
-  int blocks = (int)((rows * cols + 8191) / 8192);
-  if (blocks > 2048) blocks = 2048;
-  if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(absmax_raw_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, X, ld, rows, (int)cols, slot);
-  VAE_CHECK_LAUNCH("vae_absmax_accumulate");
+// partial[0 .. VAE_ABSMAX_PARTIALS) = per-workgroup maxima of |X| (every entry written)
+int vae_absmax_partials(const float* X, int64_t rows, int64_t cols, int64_t ld, float* partial, void* stream) {
+  VAE_REQUIRE(X && partial && rows > 0 && cols > 0 && cols < (1 << 30) && ld >= cols, "vae_absmax_partials: bad arguments");
+  hipLaunchKernelGGL(absmax_raw_kernel, dim3(VAE_ABSMAX_PARTIALS), dim3(256), 0, (hipStream_t)stream, X, ld, rows, (int)cols,
+                     partial);
+  VAE_CHECK_LAUNCH("vae_absmax_partials");
   return VAE_OK;
 }
-// vae_gemm / vae_gemm_slabs on two scaled f16 terms, the scales derived in the kernel from max|A|, max|B| slots
-int vae_gemm_f16x2(int layout, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* absmax_a,
-                   const float* B, int64_t ldb, const float* absmax_b, float* C, int64_t ldc, const float* bias,
+// vae_gemm / vae_gemm_slabs on two scaled f16 terms, the scales derived in the kernel from the partial maxima of |A|, |B|
+int vae_gemm_f16x2(int layout, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* max_a, int n_max_a,
+                   const float* B, int64_t ldb, const float* max_b, int n_max_b, float* C, int64_t ldc, const float* bias,
                    int accumulate, float* workspace, int64_t workspace_bytes, void* stream, int* slabs_out) {
-  VAE_REQUIRE(absmax_a && absmax_b, "vae_gemm_f16x2: null absmax slot");
+  VAE_REQUIRE(max_a && max_b && n_max_a > 0 && n_max_b > 0, "vae_gemm_f16x2: operand maxima missing");
   return gemm_impl(layout, 3, M, N, K, A, lda, B, ldb, slabs_out ? nullptr : C, slabs_out ? N : ldc, slabs_out ? nullptr : bias,
-                   nullptr, slabs_out ? 0 : accumulate, workspace, workspace_bytes, stream, slabs_out, absmax_a, absmax_b, 1);
+                   nullptr, slabs_out ? 0 : accumulate, workspace, workspace_bytes, stream, slabs_out, max_a, max_b, n_max_a,
+                   n_max_b);
 }
 
 extern "C" int64_t vae_absmax_workspace_bytes(void) { return 1024 * (int64_t)sizeof(float); }

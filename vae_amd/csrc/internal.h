@@ -3,29 +3,35 @@
 #pragma once
 #include <stdint.h>
 
-// slot = max(slot, max|X|) with an integer atomic; the caller zeroes the slot once per step
-int vae_absmax_accumulate(const float* X, int64_t rows, int64_t cols, int64_t ld, float* slot, void* stream);
+// Operand maxima travel as arrays of partial maxima (common.h): the producer's waves / workgroups store, the GEMM reduces.
+#define VAE_ABSMAX_PARTIALS 1024   /* entries vae_absmax_partials writes; workgroups of vae_absmax_weights        */
+#define VAE_ABSMAX_W_SPLIT 440     /* of which the first weight array (encoder, 7.7 M of 18 M elements) gets these */
 
-// max|w0| / max|w1| of two dense 16-byte aligned arrays raised into slot0 / slot1 (which must start at 0) and nzero floats
-// at zero_slots cleared, one launch
-int vae_absmax_weights(const float* w0, int64_t n0, const float* w1, int64_t n1, float* slot0, float* slot1, float* zero_slots,
-                       int nzero, void* stream);
+// partial[0 .. VAE_ABSMAX_PARTIALS) = per-workgroup maxima of |X|
+int vae_absmax_partials(const float* X, int64_t rows, int64_t cols, int64_t ld, float* partial, void* stream);
+// part0[0 .. VAE_ABSMAX_W_SPLIT), part1[0 .. VAE_ABSMAX_PARTIALS - VAE_ABSMAX_W_SPLIT): partial maxima of two dense arrays
+int vae_absmax_weights(const float* w0, int64_t n0, const float* w1, int64_t n1, float* part0, float* part1, void* stream);
 
 // vae_gemm (slabs_out == null) / vae_gemm_slabs (slabs_out != null: partial slabs left in the workspace) on two scaled
 // f16 terms per element and three matrix-core products; the power-of-two scales are derived inside the kernel from the
-// max|A| / max|B| slots the producers of the operands filled
-int vae_gemm_f16x2(int layout, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* absmax_a,
-                   const float* B, int64_t ldb, const float* absmax_b, float* C, int64_t ldc, const float* bias,
+// n_max_a / n_max_b partial maxima of |A| / |B| that the producers of the operands stored
+int vae_gemm_f16x2(int layout, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* max_a, int n_max_a,
+                   const float* B, int64_t ldb, const float* max_b, int n_max_b, float* C, int64_t ldc, const float* bias,
                    int accumulate, float* workspace, int64_t workspace_bytes, void* stream, int* slabs_out);
 
-// vae_normalize_rows / _u8 (x_dtype) that also raises *absmax to max|xn| (absmax may be null)
+// Entries of the partial-maxima arrays the producers below fill (all of them, every call)
+#define VAE_NORM_WAVES 4           /* vae_normalize_rows_ex / vae_gene_dropout_ex: B * 4 entries      */
+#define VAE_MID_WAVES 8            /* vae_mid_forward / vae_mid_backward: B * 8 entries               */
+int64_t vae_nbzinb_bwd_workgroups(int64_t B, int64_t G);   /* vae_nbzinb_bwd_ex: one entry per workgroup */
+
+// vae_normalize_rows / _u8 (x_dtype) that also stores the per-wave maxima of |xn| (absmax may be null)
 int vae_normalize_rows_ex(const void* x, int x_dtype, int64_t ldx, int64_t B, int64_t G, float* mean, float* xn,
                           int64_t ld_xn, float* absmax, void* stream);
-// vae_gene_dropout that also raises *absmax to max|xn| of the masked, normalised counts
+// vae_gene_dropout that also stores the per-wave maxima of |xn| of the masked, normalised counts
 int vae_gene_dropout_ex(const void* x, int x_dtype, int64_t ldx, int64_t B, int64_t G, float p, float alpha, uint64_t seed,
                         uint32_t step, float* running, int32_t* counts, uint32_t* threshold, float* stats, float* mean,
                         float* xn, int64_t ld_xn, float* absmax, void* stream);
-// vae_nbzinb_bwd_overwrite / vae_nbzinb_bwd_u8(overwrite = 1) that also raises *absmax to max|dlogits|
+// vae_nbzinb_bwd_overwrite / vae_nbzinb_bwd_u8(overwrite = 1) that also stores the per-workgroup maxima of |dlogits|
 int vae_nbzinb_bwd_ex(int x_dtype, int zinb, const float* logit_scale, int64_t ld_s, const float* logit_dropout, int64_t ld_p,
                       const void* x, int64_t ld_x, const float* library, const float* gene_table, const float* rowmax,
                       const float* rowsum, const float* S, const float* g_ll, float g_scalar, int64_t B, int64_t G,

@@ -18,6 +18,7 @@
 #include "middle.h"
 #include "philox.h"
 #include "common.h"
+#include "internal.h"
 
 #include <stdlib.h>
 
@@ -32,6 +33,7 @@ namespace {
 
 constexpr int T = 512;   // threads per workgroup (the kernels are latency-bound: more lanes, fewer rounds per phase)
 constexpr int NWV = T / 64;
+static_assert(NWV == VAE_MID_WAVES, "step.hip sizes the partial maxima of the fused middle as B * VAE_MID_WAVES");
 constexpr int ME = 2;    // elements per thread: hidden widths up to 1024
 
 __device__ __forceinline__ float gelu_f(float v) { return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f)); }
@@ -143,7 +145,7 @@ struct MidFwd {
   float *heads_z, *heads_l, *qz_v, *z, *kl_z, *ql_v, *library, *kl_l;
   float *dec_pre, *dec_h, *ln_md, *ln_rd;
   VaeDropout drop;                                       // nn.Dropout after each LayerNorm (off: scale == 0)
-  float* absmax_px;                                      // nullable: raised to max|dec_h| (scale of the f16x2 GEMMs)
+  float* absmax_px;                                      // nullable: B * NWV per-wave maxima of |dec_h| (f16x2 GEMMs)
 };
 
 // softplus variance, sample and KL for one encoder, executed by ONE wave (lane j = latent j).
@@ -345,18 +347,7 @@ __global__ __launch_bounds__(T) void mid_fwd_kernel(MidFwd a) {
       am = fmaxf(am, fabsf(h));
     }
   }
-  if (a.absmax_px) {  // workgroup maximum of |dec_h| -> one integer atomic
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) am = fmaxf(am, __shfl_xor(am, o, WAVE));
-    __syncthreads();
-    if (lane == 0) red[wave] = am;
-    __syncthreads();
-    if (t == 0) {
-      float m = red[0];
-      for (int j = 1; j < NWV; ++j) m = fmaxf(m, red[j]);
-      vae_atomic_absmax(a.absmax_px, m);
-    }
-  }
+  if (a.absmax_px) vae_wave_absmax_store(a.absmax_px + b * NWV + wave, am);   // this wave's maximum of |dec_h|
   if (t == 0) {
     a.ln_md[b] = mu[0];
     a.ln_rd[b] = rs[0];
@@ -378,9 +369,7 @@ struct MidBwd {
   float *dq_z, *dq_l;                                    // (B, L+1), (B, 2)
   float *dbet_e, *dgam_e, *dpre_e;                       // (B, H+Hl) rows
   VaeDropout drop;
-  float* absmax_dpre;                                    // nullable: raised to max|dpre_e|
-  float* clear_slots; int nclear;                        // nullable: floats block 0 zeroes (the weight maxima: their
-                                                         // last reader, the dgrad GEMM, has run; the next forward refills)
+  float* absmax_dpre;                                    // nullable: B * NWV per-wave maxima of |dpre_e|
 };
 
 // Backward of reparam_wave, by one wave.  Mirrors reparam_kl_bwd_kernel (rowops.hip).
@@ -415,7 +404,6 @@ __global__ __launch_bounds__(T) void mid_bwd_kernel(MidBwd a) {
   const int H = a.H, Hl = a.Hl, HE = a.H + a.Hl, L = a.L, Hd = a.Hd;
 
   const int LP = L | 1;
-  if (b == 0 && a.clear_slots && t < a.nclear) a.clear_slots[t] = 0.f;
   stage_dec_w(a.d_w, Hd, L, LP, dyn);
   // 1. d(dec_h): sum of the dgrad slabs; LayerNorm + GELU backward of the decoder layer
   const float mud = a.ln_md[b], rsd = a.ln_rd[b];
@@ -548,18 +536,7 @@ __global__ __launch_bounds__(T) void mid_bwd_kernel(MidBwd a) {
       am = fmaxf(am, fabsf(o));
     }
   }
-  if (a.absmax_dpre) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) am = fmaxf(am, __shfl_xor(am, o, WAVE));
-    __syncthreads();
-    if ((t & 63) == 0) red[t >> 6] = am;
-    __syncthreads();
-    if (t == 0) {
-      float m = red[0];
-      for (int j = 1; j < NWV; ++j) m = fmaxf(m, red[j]);
-      vae_atomic_absmax(a.absmax_dpre, m);
-    }
-  }
+  if (a.absmax_dpre) vae_wave_absmax_store(a.absmax_dpre + b * NWV + (t >> 6), am);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -698,10 +675,9 @@ int vae_mid_backward(const vae_step_config& c, const vae_step_tensors* p, const 
                      const float* pre_enc0, const float* ln_mz, const float* ln_rz, const float* ln_ml,
                      const float* ln_rl, const float* z, const float* h_enc0, float* dbet_d, float* dgam_d,
                      float* dpre_d, float* dq_z, float* dq_l, float* dbet_e, float* dgam_e, float* dpre_e,
-                     float* absmax_dpre, float* clear_slots, int nclear, void* stream) {
+                     float* absmax_dpre, void* stream) {
   MidBwd a;
   a.absmax_dpre = absmax_dpre;
-  a.clear_slots = clear_slots; a.nclear = nclear;
   a.slabs = slabs; a.nslab = nslab; a.slab_stride = c.B * c.Hd;
   a.dec_pre = dec_pre; a.ln_md = ln_md; a.ln_rd = ln_rd; a.gd = p->dec_ln_g[0];
   a.d_w = p->dec_w[0];

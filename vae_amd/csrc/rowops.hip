@@ -63,9 +63,7 @@ __global__ __launch_bounds__(256) void normalize_rows_kernel(const XT* __restric
   float am = 0.f;   // max|xn| of this thread's elements (absmax != null)
   auto track = [&](float v) { am = fmaxf(am, fabsf(v)); return v; };
   auto finish = [&]() {
-    if (!absmax) return;
-    am = block_max<4>(am, red);
-    if (threadIdx.x == 0) vae_atomic_absmax(absmax, am);
+    if (absmax) vae_wave_absmax_store(absmax + blockIdx.x * VAE_NORM_WAVES + (threadIdx.x >> 6), am);
   };
   const int b = blockIdx.x;
   const XT* row = x + (int64_t)b * ld;
@@ -456,10 +454,7 @@ __global__ __launch_bounds__(256) void normalize_rows_masked_kernel(const XT* __
     am = fmaxf(fmaxf(am, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
     reinterpret_cast<float4*>(orow)[i] = v;
   }
-  if (absmax) {
-    am = block_max<4>(am, red);
-    if (threadIdx.x == 0) vae_atomic_absmax(absmax, am);
-  }
+  if (absmax) vae_wave_absmax_store(absmax + blockIdx.x * VAE_NORM_WAVES + (threadIdx.x >> 6), am);
 }
 
 template <typename XT>

@@ -12,6 +12,10 @@
 
 namespace {
 
+// Operands of the two-f16-term GEMMs whose largest magnitude the step tracks: the producing kernel's waves / workgroups
+// store partial maxima (plain stores, every entry, every step), the consuming GEMM reduces them in its prologue.
+enum { AM_XN = 0, AM_XNZ, AM_PX, AM_DLOGITS, AM_DPRE, AM_WENC, AM_WHEADS, AM_COUNT };
+
 struct Layout {
   // offsets in floats into the workspace
   int64_t mean, xn, ld_xn, pre_enc0, h_enc0, ln_mz[VAE_MAX_LAYERS], ln_rz[VAE_MAX_LAYERS], ln_ml, ln_rl;
@@ -22,7 +26,7 @@ struct Layout {
   int64_t dz_extra, dlibrary, dheads_z, dheads_l, dpre_enc0, dh, dpx, dz;
   int64_t dbet_d, dgam_d, dbet_e, dgam_e;  // per-cell LayerNorm-gradient rows of the fused middle
   int64_t xn_z, mean_z, gene_thr, gene_counts;  // GeneDropout: the z-encoder's own normalised counts (-1: off)
-  int64_t amax;            // max|operand| slots of the two-f16-term GEMMs (AM_*)
+  int64_t amax[8]; int amax_n[8];  // partial maxima of the operands of the two-f16-term GEMMs (AM_*): offset, entries
   int64_t scratch;        // split-K slabs / column-sum slabs (shared, used by one launch at a time)
   int64_t scratch_floats;
   int64_t total;
@@ -60,7 +64,13 @@ bool make_layout(const vae_step_config& c, Layout* lo) {
   lo->dpre_enc0 = take(B * (H + Hl)); lo->dh = take(B * H); lo->dpx = take(B * Hd); lo->dz = take(B * L);
   lo->dbet_d = take(B * Hd); lo->dgam_d = take(B * Hd);
   lo->dbet_e = take(B * (H + Hl)); lo->dgam_e = take(B * (H + Hl));
-  lo->amax = take(8);
+  {  // partial maxima of the two-f16-term operands: every entry is rewritten by its producer in every step
+    const bool mid = vae_mid_supported(c);
+    const int64_t n[AM_COUNT] = {B * VAE_NORM_WAVES, B * VAE_NORM_WAVES, mid ? B * VAE_MID_WAVES : VAE_ABSMAX_PARTIALS,
+                                 vae_nbzinb_bwd_workgroups(B, G), mid ? B * VAE_MID_WAVES : VAE_ABSMAX_PARTIALS,
+                                 VAE_ABSMAX_W_SPLIT, VAE_ABSMAX_PARTIALS - VAE_ABSMAX_W_SPLIT};
+    for (int i = 0; i < AM_COUNT; ++i) { lo->amax[i] = take(n[i]); lo->amax_n[i] = (int)n[i]; }
+  }
   lo->xn_z = lo->mean_z = lo->gene_thr = lo->gene_counts = -1;
   if (c.input_dropout_rate > 0.f) {
     lo->xn_z = take(B * lo->ld_xn);
@@ -94,12 +104,6 @@ bool make_layout(const vae_step_config& c, Layout* lo) {
     if (rc__ != VAE_OK) return rc__; \
   } while (0)
 
-// max|operand| slots (workspace floats at lo.amax): written by the producers with integer atomics, read by the GEMMs
-// Slots 0..AM_NACT-1 (activations / gradients) are cleared by the first kernel of every forward; the two weight slots
-// are cleared after their last reader of the step (mid_bwd_kernel; a memset on the multi-launch path), so that the next
-// forward sees the weights an optimiser may have changed.  The workspace must be zero-filled once before its first use.
-enum { AM_XN = 0, AM_XNZ, AM_PX, AM_DLOGITS, AM_DPRE, AM_NACT, AM_WENC = AM_NACT, AM_WHEADS, AM_COUNT };
-
 struct Ctx {
   const vae_step_config& c;
   float* ws;
@@ -107,13 +111,14 @@ struct Ctx {
   void* st;
   // the two-f16-term pipeline needs 16-byte rows everywhere; ragged shapes run as VAE_FP32
   bool fx() const { return c.precision == VAE_FP32_F16X2 && c.G % 4 == 0 && c.Hd % 4 == 0 && (c.H + c.Hl) % 4 == 0; }
-  float* am(int slot) const { return fx() ? ws + lo.amax + slot : nullptr; }
+  float* am(int slot) const { return fx() ? ws + lo.amax[slot] : nullptr; }
   // one of the five gene-sized products: two-f16-term split when the step runs in VAE_FP32_F16X2, else as `gemm`;
   // slabs_out != null leaves split-K slabs in the scratch (no bias) for the fused middle
   int big(int layout, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, int slot_a, const float* Bm, int64_t ldb,
           int slot_b, float* C, int64_t ldc, const float* bias, int* slabs_out) const {
     if (fx())
-      return vae_gemm_f16x2(layout, M, N, K, A, lda, am(slot_a), Bm, ldb, am(slot_b), C, ldc, bias, 0, ws + lo.scratch,
+      return vae_gemm_f16x2(layout, M, N, K, A, lda, am(slot_a), lo.amax_n[slot_a], Bm, ldb, am(slot_b), lo.amax_n[slot_b], C, ldc,
+                            bias, 0, ws + lo.scratch,
                             lo.scratch_floats * 4, st, slabs_out);
     if (slabs_out)
       return vae_gemm_slabs(layout, c.precision, M, N, K, A, lda, Bm, ldb, ws + lo.scratch, lo.scratch_floats * 4, slabs_out, st);
@@ -180,7 +185,7 @@ extern "C" int64_t vae_elbo_step_ws_offset(const vae_step_config* cfg, int slice
     case VAE_WS_DZ_EXTRA: return lo.dz_extra;
     case VAE_WS_RECON: return lo.recon;
     case VAE_WS_GENE_THRESHOLD: return lo.gene_thr;
-    case VAE_WS_OPERAND_MAXIMA: return lo.amax;
+    case VAE_WS_OPERAND_MAXIMA: return lo.amax[0];
     default: return -1;
   }
 }
@@ -198,7 +203,7 @@ extern "C" int vae_elbo_step_forward(const vae_step_config* cfg, const vae_step_
   const int64_t NH = c.zinb ? 2 * G : G;
 
   if (k.fx())  // weight maxima of the two-f16-term products; the same launch clears the activations' slots of this step
-    TRY(vae_absmax_weights(p->enc_w0, HE * G, p->heads_w, NH * Hd, k.am(AM_WENC), k.am(AM_WHEADS), k.am(0), AM_NACT, stream));
+    TRY(vae_absmax_weights(p->enc_w0, HE * G, p->heads_w, NH * Hd, k.am(AM_WENC), k.am(AM_WHEADS), stream));
   // encoders: x/mean-1 -> Linear(G, H+Hl) -> GELU -> LayerNorm (z and library halves)
   TRY(vae_normalize_rows_ex(xv, c.x_dtype, ldx, B, G, ws + lo.mean, ws + lo.xn, lo.ld_xn, k.am(AM_XN), stream));
   // GeneDropout (training): the z-encoder reads its own masked + normalised counts, the library encoder xn
@@ -268,7 +273,7 @@ extern "C" int vae_elbo_step_forward(const vae_step_config* cfg, const vae_step_
     }
   }
   // decoder heads -> fused softmax / library scale / NB-ZINB / row sum -> ELBO scalars
-  if (k.fx() && !vae_mid_supported(c)) TRY(vae_absmax_accumulate(px, B, Hd, Hd, k.am(AM_PX), stream));
+  if (k.fx() && !vae_mid_supported(c)) TRY(vae_absmax_partials(px, B, Hd, Hd, k.am(AM_PX), stream));
   TRY(k.big(VAE_NT, B, NH, Hd, px, Hd, AM_PX, p->heads_w, Hd, AM_WHEADS, ws + lo.logits, NH, p->heads_b, nullptr));
   TRY(vae_gene_table(p->px_r, G, ws + lo.table, stream));
   if (u8) TRY(vae_nbzinb_fwd_u8(c.zinb, ws + lo.logits, NH, c.zinb ? ws + lo.logits + G : nullptr, NH, x8, ldx, ws + lo.library,
@@ -299,9 +304,6 @@ extern "C" int vae_elbo_step_backward(const vae_step_config* cfg, const vae_step
                                       void* stream) {
   Layout lo;
   TRY(check_common(cfg, p, g, xv, ldx, eps_z, eps_l, ws, ws_bytes, &lo, "vae_elbo_step_backward"));
-  const bool u8 = cfg->x_dtype == VAE_X_U8;
-  const float* x = (const float*)xv;
-  const uint8_t* x8 = (const uint8_t*)xv;
   const vae_step_config& c = *cfg;
   const Ctx k{c, ws, lo, stream};
   const int64_t B = c.B, G = c.G, H = c.H, Hl = c.Hl, L = c.L, Hd = c.Hd, HE = c.H + c.Hl;
@@ -330,7 +332,7 @@ extern "C" int vae_elbo_step_backward(const vae_step_config* cfg, const vae_step
                          ws + lo.qz_v, ws + lo.ql_v, ws + lo.dlibrary, ws + lo.pre_enc0, ws + lo.ln_mz[0], ws + lo.ln_rz[0],
                          ws + lo.ln_ml, ws + lo.ln_rl, ws + lo.z, ws + lo.h_enc0, ws + lo.dbet_d, ws + lo.dgam_d,
                          ws + lo.dpx, ws + lo.dheads_z, ws + lo.dheads_l, ws + lo.dbet_e, ws + lo.dgam_e,
-                         ws + lo.dpre_enc0, k.am(AM_DPRE), k.am(AM_WENC), k.fx() ? 2 : 0, stream));
+                         ws + lo.dpre_enc0, k.am(AM_DPRE), stream));
   } else {
     // the unfused kernels ACCUMULATE the LayerNorm / bias gradients with atomics: clear them first
     auto zero = [&](float* q, int64_t n) {
@@ -398,8 +400,7 @@ extern "C" int vae_elbo_step_backward(const vae_step_config* cfg, const vae_step
     TRY(vae_gelu_ln_bwd(ws + lo.dpre_enc0 + H, HE, ws + lo.pre_enc0 + H, HE, ws + lo.ln_ml, ws + lo.ln_rl, p->encl_ln_g, B,
                         Hl, ws + lo.dpre_enc0 + H, HE, g->encl_ln_g, g->encl_ln_b, g->enc_b0 + H, stream));
     if (k.fx()) {
-      TRY(vae_absmax_accumulate(ws + lo.dpre_enc0, B, HE, HE, k.am(AM_DPRE), stream));
-      TRY(zero(k.am(AM_WENC), 2));   // the weight maxima: refilled by the next forward
+      TRY(vae_absmax_partials(ws + lo.dpre_enc0, B, HE, HE, k.am(AM_DPRE), stream));
     }
   }
   if (c.input_dropout_rate > 0.f) {  // GeneDropout: each encoder's weight gradient over its own input

@@ -146,7 +146,7 @@ class ElboStep:
             nbytes = self.lib.vae_elbo_step_workspace_bytes(C.byref(cfg))
             if nbytes <= 0:
                 raise RuntimeError("vae_amd: bad step configuration")
-            ws = torch.zeros(nbytes // 4, dtype=torch.float32, device=self.a.device)   # zero once: operand-maxima slots
+            ws = torch.empty(nbytes // 4, dtype=torch.float32, device=self.a.device)
             off = {n: self.lib.vae_elbo_step_ws_offset(C.byref(cfg), i) for i, n in enumerate(_lib.WS_SLICES)}
             L = self.L
             v = dict(
@@ -162,7 +162,6 @@ class ElboStep:
                 scalars=ws[off["SCALARS"]:off["SCALARS"] + 5],
                 dz_extra=ws[off["DZ_EXTRA"]:off["DZ_EXTRA"] + B * L].view(B, L),
                 recon=ws[off["RECON"]:off["RECON"] + B],
-                weight_maxima=ws[off["OPERAND_MAXIMA"] + 5:off["OPERAND_MAXIMA"] + 7],
             )
             if gene_drop:   # keep thresholds floor(p_g * 2^32) as int32 bit patterns, then mean_g(p_g)
                 o = off["GENE_THRESHOLD"]
@@ -237,8 +236,6 @@ class ElboStep:
             out["loss"] = s[4]
         if not backward:
             self._last_fwd = (B, cfg, ws, nbytes)
-            if self.precision == ops.F16X2:
-                v["weight_maxima"].zero_()   # no backward will clear them: the weights may change before the next forward
             return out
         self._last_fwd = None   # the backward overwrites the logits in place
 
