@@ -191,6 +191,22 @@ int vae_poisson_fwd(const float* x, int64_t ld_x, const float* rate, int64_t ld_
 int vae_poisson_bwd(const float* gout, int64_t ld_g, const float* x, int64_t ld_x, const float* rate, int64_t ld_rate,
                     int64_t B, int64_t G, float* drate, int64_t ld_d, void* stream);
 
+/* ---- input side: batches cut out of a uint8 cells x genes store held in HBM ----
+ * vae_gather_counts replaces SingleCellDataset._get_gene_vals_batch (data.py:406-415): out[b, g] =
+ * store[cell_rows[b] * ld_store + (gene_idx ? gene_idx[g] : g)] for b < B, g < G, written as uint8 (VAE_X_U8: what the
+ * fused step reads directly) or fp32 (VAE_X_F32).  store: device, n_cells rows of ld_store bytes
+ * (create_dataset.py:131-142); cell_rows: device int64 (B); gene_idx: device int32 (G) or null (the first G genes).
+ * Rows / genes outside the store give zeros (validate on the host); B <= 65535.                                      */
+int vae_gather_counts(const uint8_t* store, int64_t n_cells, int64_t ld_store, const int64_t* cell_rows, int64_t B,
+                      const int32_t* gene_idx, int64_t G, void* out, int out_dtype, int64_t ld_out, void* stream);
+/* vae_mixup_counts replaces the array arithmetic of SingleCellDataset._mixup (data.py:457-477):
+ * out[i, :] = alpha[i] * x[i, :] + (1 - alpha[i]) * x[partner[i], :], evaluated as numpy does (float64 products and
+ * sum without fused multiply-add, rounded once to fp32: bit-identical).  x: (B, G) uint8 or fp32 (x_dtype), also
+ * used for the (B, P) cell-property values and masks; partner: device int32 (B) in [0, B); alpha: device double (B);
+ * out must not alias x.                                                                                              */
+int vae_mixup_counts(const void* x, int x_dtype, int64_t ldx, int64_t B, int64_t G, const int32_t* partner,
+                     const double* alpha, float* out, int64_t ld_out, void* stream);
+
 /* element-wise log_nb_positive / log_zinb_positive (distributions.py:65-90 / :22-62), eps = 1e-8;
  * theta addressed as theta[b*ld_theta + g] (ld_theta = 0 broadcasts a (G,) vector)                */
 int vae_loglik_elem_fwd(int zinb, const float* x, int64_t ld_x, const float* mu, int64_t ld_mu, const float* theta,

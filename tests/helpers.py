@@ -65,3 +65,38 @@ def dropout_multiplier(p: float, seed: int, step: int, site: int, B: int, W: int
     keep = philox_word0(seed, step, site, elem) >= np.uint32(min(int(np.float32(p) * 4294967296.0), 4294967295))
     scale = np.float32(1.0 / (1.0 - float(np.float32(p))))
     return np.where(keep, scale, np.float32(0)).astype(np.float32).reshape(B, W)
+
+
+def synthetic_study(n_cells=3000, n_genes=1003, seed=11):
+    """A made-up study in the layout SingleCellDataset reads (data.py:41,63-66): ``{"obs": columns, "var": columns}``
+    plus the uint8 cells x genes store.  Sparse counts, a few unknown / NaN / out-of-range annotations."""
+    rng = np.random.RandomState(seed)
+    store = (rng.poisson(0.6, size=(n_cells, n_genes)) * (rng.rand(n_cells, n_genes) < 0.5)).astype(np.uint8)
+    age = rng.uniform(40, 95, n_cells)
+    age[rng.rand(n_cells) < 0.03] = np.nan
+    age[rng.rand(n_cells) < 0.02] = 1500.0
+    obs = {
+        "class": rng.choice(["OPC", "EN", "Astro"], n_cells, p=[0.7, 0.2, 0.1]),
+        "include_training": (rng.rand(n_cells) < 0.95).astype(np.int64),
+        "Dementia": rng.choice([0, 1, -1], n_cells, p=[0.45, 0.45, 0.1]),
+        "BRAAK_CERAD": rng.choice([0, 1, 2, -1], n_cells, p=[0.35, 0.35, 0.2, 0.1]),
+        "SubID": np.array([f"S{v:03d}" for v in rng.randint(0, 40, n_cells)]),
+        "Age": age,
+        "Sex": rng.choice(["M", "F", "U"], n_cells, p=[0.48, 0.48, 0.04]),
+        "Brain_bank": rng.choice(["A", "B", "C"], n_cells),
+    }
+    var = {
+        "gene_name": np.array([f"G{g}" for g in range(n_genes)]),
+        "percent_cells": rng.uniform(0, 5, n_genes) * (rng.rand(n_genes) < 0.97),
+        "gene_chrom": rng.choice(["1", "2", "X", "Y"], n_genes, p=[0.5, 0.4, 0.07, 0.03]),
+    }
+    var["gene_name"][5] = "MALAT1"
+    return store, {"obs": obs, "var": var}
+
+
+class HostOnlyStore:
+    """Stands in for vae_amd.data.CountStore in the CPU tests of the dataset's host logic (no gather)."""
+
+    def __init__(self, store):
+        self.n_cells, self.n_genes = store.shape
+        self.device = torch.device("cpu")

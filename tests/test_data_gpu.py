@@ -1,0 +1,185 @@
+"""Input side on the GPU (rows f2 / f4) through the C ABI: the device gather and device mixup are bit-identical to
+oracle/data_oracle.py (the reference's numpy, data.py:406-415 / 457-477), whole batches of SingleCellDataset follow
+the reference's random streams, and a DataModule feeds the fused training step."""
+import contextlib
+import copy
+import io
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import synthetic_study
+from oracle import data_oracle as DO
+from vae_amd import ops
+from vae_amd.data import CountStore, DataModule, SingleCellDataset
+
+pytestmark = pytest.mark.gpu
+
+CELL_PROPS = {"Age": {"discrete": False, "values": None, "stop_grad": False},
+              "Sex": {"discrete": True, "values": ["M", "F"], "stop_grad": True}}
+
+
+@pytest.mark.parametrize("n_genes", [1003, 1024])
+def test_gather_is_bit_exact(n_genes):
+    rng = np.random.RandomState(1)
+    host = rng.randint(0, 256, size=(300, n_genes)).astype(np.uint8)
+    store = CountStore(host)
+    cell_idx = np.arange(300)
+    rows = rng.randint(0, 300, size=37)
+    for gene_idx in (np.arange(n_genes), np.sort(rng.choice(n_genes, 517, replace=False)), rng.permutation(n_genes)[:64],
+                     np.arange(n_genes - 3)):
+        want = DO.gene_vals_batch(host, cell_idx, rows, gene_idx)
+        whole = len(gene_idx) == n_genes
+        gi = None if whole else torch.from_numpy(gene_idx.astype(np.int32)).cuda()
+        for dt in (torch.uint8, torch.float32):
+            got = store.gather(rows, gi, dt)
+            assert got.dtype == dt and got.shape == want.shape
+            assert np.array_equal(got.float().cpu().numpy(), want)
+            if dt == torch.uint8:
+                assert got.stride(0) % 4 == 0        # rows padded for the step's 4-byte loads
+    # the first G genes without an index array
+    got = ops.gather_counts(store.dev, torch.from_numpy(rows).cuda(), None, n_genes=n_genes - 3, dtype=torch.float32)
+    assert np.array_equal(got.cpu().numpy(), host[rows][:, :n_genes - 3].astype(np.float32))
+    with pytest.raises(IndexError):
+        store.gather([0, 300])
+    with pytest.raises(IndexError):
+        store.gather([-1])
+    # device-side indices are not validated: rows / genes outside the store come back as zeros, nothing faults
+    bad = ops.gather_counts(store.dev, torch.tensor([5, 300, -2], device="cuda"), torch.tensor([0, n_genes, 7], dtype=torch.int32,
+                                                                                               device="cuda"))
+    assert np.array_equal(bad.cpu().numpy(), np.array([[host[5, 0], 0, host[5, 7]], [0, 0, 0], [0, 0, 0]], np.uint8))
+
+
+def test_store_streams_a_raw_file_in_chunks(tmp_path):
+    rng = np.random.RandomState(2)
+    host = rng.randint(0, 256, size=(1000, 77)).astype(np.uint8)
+    path = str(tmp_path / "counts.dat")
+    host.tofile(path)
+    store = CountStore(path, n_genes=77, chunk_rows=96)      # 11 chunks through the two pinned buffers
+    assert (store.n_cells, store.n_genes) == (1000, 77)
+    assert np.array_equal(store.dev.cpu().numpy(), host)
+    with pytest.raises(ValueError):
+        CountStore(path, n_genes=78)
+
+
+@pytest.mark.parametrize("G", [1003, 20000])
+def test_mixup_is_bit_exact(G):
+    rng = np.random.RandomState(3)
+    B = 48
+    x8 = (rng.poisson(1.5, size=(B, G)) * (rng.rand(B, G) < 0.6)).astype(np.uint8)
+    alpha = rng.beta(0.25, 0.25, size=B)
+    alpha[:3] = [0.0, 1.0, 1e-300]
+    partner = rng.randint(0, B, size=B)
+    a = torch.from_numpy(alpha).cuda()
+    p = torch.from_numpy(partner.astype(np.int32)).cuda()
+    for x in (x8, x8.astype(np.float32) * np.float32(1.37)):
+        xf = x.astype(np.float32)
+        want = np.zeros_like(xf)
+        for i in range(B):
+            want[i, :] = alpha[i] * xf[i, :] + (1 - alpha[i]) * xf[partner[i], :]       # data.py:473
+        xt = torch.from_numpy(x).cuda()
+        got = ops.mixup_counts(xt, p, a)
+        assert np.array_equal(got.cpu().numpy().view(np.uint32), want.view(np.uint32))
+        # a strided view (rows padded) goes through the same path
+        if x.dtype == np.uint8:
+            pad = torch.zeros(B, (G + 3) // 4 * 4 + 4, dtype=torch.uint8, device="cuda")
+            pad[:, :G] = xt
+            assert torch.equal(ops.mixup_counts(pad[:, :G], p, a), got)
+    with pytest.raises(TypeError):
+        ops.mixup_counts(xt, p.long(), a)
+    with pytest.raises(TypeError):
+        ops.mixup_counts(xt, p, a.float())
+
+
+def _study_dataset(store_host, meta, **kw):
+    obs = {k: np.array(v) for k, v in meta["obs"].items()}
+    props = DO.cell_prop_info(obs, copy.deepcopy(CELL_PROPS))
+    args = dict(cell_properties=props, batch_size=64, cell_restrictions={"class": "OPC", "Sex": ["M", "F"]}, group_balancing="bcd", mixup=True,
+                training=True, metadata=meta, store=CountStore(store_host), min_group_cells=40)
+    args.update(kw)
+    return SingleCellDataset(None, None, np.arange(store_host.shape[0]), **args), props
+
+
+def test_training_batches_follow_the_reference_pipeline():
+    """dataset[...] == balanced sampler -> row gather -> mixup of the oracle under the same np.random seed, bit for bit."""
+    host, meta = synthetic_study()
+    gene_idx = np.sort(np.random.RandomState(5).choice(host.shape[1], 600, replace=False))
+    ds, props = _study_dataset(host, meta, gene_idx=gene_idx)
+    for seed in (0, 1):
+        np.random.seed(seed)
+        batch_idx, groups = DO.balanced_batch(ds.group_idx, ds.cell_per_group)
+        g = DO.gene_vals_batch(host, ds.cell_idx, batch_idx, gene_idx)
+        want_g, want_v, want_m, _, _ = DO.mixup(g, ds.labels[batch_idx], ds.mask[batch_idx], ds.cell_per_group)
+        np.random.seed(seed)
+        gene_vals, vals, mask, bl, bm, cell_idx, group_idx, subject = ds[[0, 1, 2]]
+        assert gene_vals.dtype == torch.float32 and gene_vals.is_cuda
+        assert np.array_equal(gene_vals.cpu().numpy().view(np.uint32), want_g.view(np.uint32))
+        assert np.array_equal(vals.cpu().numpy().view(np.uint32), want_v.view(np.uint32))
+        assert np.array_equal(mask.cpu().numpy().view(np.uint32), want_m.view(np.uint32))
+        assert bl is None and bm is None and group_idx == groups
+        assert np.array_equal(cell_idx, ds.cell_idx[batch_idx]) and np.array_equal(subject, ds.subjects[batch_idx])
+    assert ds.count == 2
+
+
+def test_validation_batches_and_library_prior():
+    host, meta = synthetic_study()
+    ds, _ = _study_dataset(host, meta, group_balancing=None, mixup=False, training=False, counts_dtype=torch.uint8)
+    idx = [3, 0, 17, 3]
+    gene_vals, vals, mask, _, _, cell_idx, group_idx, _ = ds[idx]
+    assert gene_vals.dtype == torch.uint8 and group_idx is None
+    assert np.array_equal(gene_vals.float().cpu().numpy(), DO.gene_vals_batch(host, ds.cell_idx, idx, ds.gene_idx))
+    assert np.array_equal(vals.cpu().numpy(), ds.labels[idx]) and np.array_equal(mask.cpu().numpy(), ds.mask[idx])
+    assert np.array_equal(cell_idx, ds.cell_idx[idx])
+    one = ds[5]
+    assert one[0].shape == (1, host.shape[1])
+    with pytest.raises(IndexError):
+        ds[[len(ds)]]
+    m, v = ds.library_size_stats(N=700)
+    wm, wv = DO.library_size_stats(host, ds.cell_idx, ds.gene_idx, N=700)
+    assert abs(m - wm) < 1e-5 * abs(wm) and abs(v - wv) < 1e-4 * abs(wv)
+
+
+def test_datamodule_feeds_the_fused_step():
+    """DataModule -> loaders -> LitVAE.training_step_fused: uint8 and float32 batches of the same cells give the same
+    loss, and train.main(datamodule=...) brings the loss down with the balanced sampler and mixup on."""
+    from vae_amd import train
+    from vae_amd.networks import VAE
+    from vae_amd.task import LitVAE
+    host, meta = synthetic_study(n_cells=4000, n_genes=512)
+    props = copy.deepcopy(CELL_PROPS)
+    kw = dict(batch_size=64, cell_properties=props, cell_restrictions={"class": "OPC"}, metadata=meta, min_group_cells=40)
+    store = CountStore(host)
+    dm = DataModule(None, None, np.arange(3200), np.arange(3200, 4000), group_balancing=None, mixup=False, store=store, **kw)
+    dm.setup("train")
+    assert dm.val_dataset.store is dm.train_dataset.store and dm.n_genes == 512
+    n_val = len(dm.val_dataset)
+    sizes = [b[0].shape[0] for b in dm.val_dataloader()]
+    assert sum(sizes) == n_val and sizes[:-1] == [64] * (len(sizes) - 1)          # sequential, last batch kept
+    assert len(dm.train_dataloader()) == len(dm.train_dataset) // 64             # drop_last
+    cfg = dict(n_layers=1, n_hidden=64, n_hidden_decoder=64, n_hidden_library=32, n_latent=8, n_latent_cell_decoder=8,
+               dropout_rate=0.0, input_dropout_rate=0.0, grad_reverse_dict={})
+    with contextlib.redirect_stdout(io.StringIO()):
+        torch.manual_seed(0)
+        net = VAE(n_input=512, cell_properties=dm.cell_properties, batch_properties=None, **cfg)
+        lm, lv = dm.train_dataset.library_size_stats()
+        task = LitVAE(net, cell_properties=dm.cell_properties, library_mean=lm, library_var=lv)
+    task.train(); task.attach_arena("cuda")
+    batch = dm.val_dataset[list(range(64))]
+    dm.val_dataset.counts_dtype = torch.uint8
+    batch8 = dm.val_dataset[list(range(64))]
+    assert batch8[0].dtype == torch.uint8
+    torch.manual_seed(1); a = task.training_step_fused(batch)
+    torch.manual_seed(1); b = task.training_step_fused(batch8)
+    assert float(a["loss"]) == float(b["loss"]) and np.isfinite(float(a["loss"]))
+    # the whole loop with the balanced sampler and mixup
+    with pytest.raises(ValueError):    # unknown 'U' in a discrete property: mixup would blend -100 into class indices
+        DataModule(None, None, np.arange(3200), np.arange(3200, 4000), group_balancing="bcd", mixup=True, store=store,
+                   **kw).setup("train")
+    kw["cell_properties"] = None
+    dm2 = DataModule(None, None, np.arange(3200), np.arange(3200, 4000), group_balancing="bcd", mixup=True, store=store, **kw)
+    tk = dict(model_cfg=cfg, task_cfg={"warmup_steps": 20.0, "learning_rate": 2e-3}, trainer_cfg={"precision": "32"})
+    with contextlib.redirect_stdout(io.StringIO()):
+        first = float(train.main(None, None, "OPC", datamodule=dm2, max_steps=1, **tk).logged["gene_loss"])
+        last = float(train.main(None, None, "OPC", datamodule=dm2, max_steps=150, **tk).logged["gene_loss"])
+    assert np.isfinite(last) and last < 0.9 * first, (first, last)

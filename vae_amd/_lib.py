@@ -13,6 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VAE_AMD_LIB") or os.path.join(_HERE, "lib", "libvae_amd.so")   # env: an alternative build
 
 _i64, _i32, _f32, _ptr = C.c_int64, C.c_int, C.c_float, C.c_void_p
+X_F32, X_U8 = 0, 1   # enum { VAE_X_F32, VAE_X_U8 } of include/vae_amd.h
 
 # name -> (restype, argtypes); mirrors include/vae_amd.h one to one
 SIGNATURES = {
@@ -30,6 +31,8 @@ SIGNATURES = {
     "vae_dropout_apply": (_i32, [_ptr, _i64, _i64, _i64, _f32, C.c_uint64, C.c_uint32, C.c_uint32, _ptr]),
     "vae_gene_dropout": (_i32, [_ptr, _i32, _i64, _i64, _i64, _f32, _f32, C.c_uint64, C.c_uint32, _ptr, _ptr, _ptr, _ptr, _ptr,
                                 _ptr, _i64, _ptr]),
+    "vae_gather_counts": (_i32, [_ptr, _i64, _i64, _ptr, _i64, _ptr, _i64, _ptr, _i32, _i64, _ptr]),
+    "vae_mixup_counts": (_i32, [_ptr, _i32, _i64, _i64, _i64, _ptr, _ptr, _ptr, _i64, _ptr]),
     "vae_poisson_fwd": (_i32, [_ptr, _i64, _ptr, _i64, _i64, _i64, _ptr, _i64, _ptr]),
     "vae_poisson_bwd": (_i32, [_ptr, _i64, _ptr, _i64, _ptr, _i64, _i64, _i64, _ptr, _i64, _ptr]),
     "vae_absmax_workspace_bytes": (_i64, []),

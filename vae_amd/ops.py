@@ -408,6 +408,51 @@ def poisson_bwd(gout: torch.Tensor, x: torch.Tensor, rate: torch.Tensor) -> torc
     return out
 
 
+def gather_counts(store: torch.Tensor, cell_rows: torch.Tensor, gene_idx: Optional[torch.Tensor] = None,
+                  n_genes: Optional[int] = None, dtype: torch.dtype = torch.uint8) -> torch.Tensor:
+    """Rows ``cell_rows`` (device int64) of a device-resident uint8 cells x genes ``store``, restricted to ``gene_idx``
+    (device int32) or to the first ``n_genes`` genes, as uint8 or float32 (data.py:406-415).  The indices are NOT
+    validated here (they are on the device): rows / genes outside the store come back as zeros."""
+    lib = _lib.load()
+    if not store.is_cuda or store.dtype != torch.uint8 or store.dim() != 2 or store.stride(1) != 1:
+        raise TypeError("vae_amd.ops.gather_counts: store must be a 2-D uint8 GPU tensor with a contiguous last dim")
+    if not cell_rows.is_cuda or cell_rows.dtype != torch.int64 or cell_rows.dim() != 1 or not cell_rows.is_contiguous():
+        raise TypeError("vae_amd.ops.gather_counts: cell_rows must be a contiguous 1-D int64 GPU tensor")
+    if gene_idx is not None:
+        if not gene_idx.is_cuda or gene_idx.dtype != torch.int32 or gene_idx.dim() != 1 or not gene_idx.is_contiguous():
+            raise TypeError("vae_amd.ops.gather_counts: gene_idx must be a contiguous 1-D int32 GPU tensor")
+        G = gene_idx.numel()
+    else:
+        G = store.shape[1] if n_genes is None else int(n_genes)
+    if dtype not in (torch.uint8, torch.float32):
+        raise TypeError("vae_amd.ops.gather_counts: dtype must be torch.uint8 or torch.float32")
+    B = cell_rows.numel()
+    if B == 0 or G == 0:
+        raise ValueError("vae_amd.ops.gather_counts: empty batch or empty gene set")
+    ld = (G + 3) // 4 * 4 if dtype == torch.uint8 else G      # uint8 rows padded to 4 bytes: the step's vector loads
+    buf = torch.empty(B, ld, dtype=dtype, device=store.device)
+    out = buf[:, :G]
+    _lib.check(lib.vae_gather_counts(_p(store), store.shape[0], store.stride(0), _p(cell_rows), B, _p(gene_idx), G, _p(out),
+                                     _lib.X_U8 if dtype == torch.uint8 else _lib.X_F32, ld, _stream()), "gather_counts")
+    return out
+
+
+def mixup_counts(x: torch.Tensor, partner: torch.Tensor, alpha: torch.Tensor) -> torch.Tensor:
+    """alpha[i] * x[i] + (1 - alpha[i]) * x[partner[i]] as numpy evaluates it (float64, rounded once to float32;
+    data.py:473-475).  x: (B, G) uint8 or float32; partner: int32 (B); alpha: float64 (B), all on the GPU."""
+    lib = _lib.load()
+    u8 = _chk_counts(x, "x")
+    B, G = x.shape
+    if not partner.is_cuda or partner.dtype != torch.int32 or partner.shape != (B,) or not partner.is_contiguous():
+        raise TypeError("vae_amd.ops.mixup_counts: partner must be a contiguous int32 GPU tensor of length B")
+    if not alpha.is_cuda or alpha.dtype != torch.float64 or alpha.shape != (B,) or not alpha.is_contiguous():
+        raise TypeError("vae_amd.ops.mixup_counts: alpha must be a contiguous float64 GPU tensor of length B")
+    out = torch.empty(B, G, dtype=torch.float32, device=x.device)
+    _lib.check(lib.vae_mixup_counts(_p(x), _lib.X_U8 if u8 else _lib.X_F32, _ld(x), B, G, _p(partner), _p(alpha), _p(out), G,
+                                    _stream()), "mixup_counts")
+    return out
+
+
 def loglik_elem_fwd(zinb: bool, x, mu, theta, pi) -> torch.Tensor:
     """Element-wise log_nb_positive / log_zinb_positive; theta is (G,) or (B,G)."""
     lib = _lib.load()

@@ -1,5 +1,7 @@
 """Training entry point with the reference's ``main`` signature (src/train.py:17-65), without
-Lightning and without the authors' data files: the count matrix is passed in.
+Lightning and without the authors' data files: the count matrix is passed in (``counts=``), or a
+``vae_amd.data.DataModule`` over a device-resident uint8 store (``datamodule=``; train.py:23-37 builds the same
+object from ``dataset_cfg``).
 
 The loop is the reference's: seed 43, VAE(**model_cfg), library prior from log1p(row sums)
 (data.py:233-244), AdamW + warm-up/decay schedule (task.py:532-565), gradient-norm clip 0.5
@@ -32,13 +34,15 @@ def main(train_idx: List[int], test_idx: List[int], cell_class: str, additional_
          cell_mask: Optional[torch.Tensor] = None, cell_properties: Optional[Dict] = None,
          model_cfg: Optional[Dict] = None, task_cfg: Optional[Dict] = None, trainer_cfg: Optional[Dict] = None,
          batch_size: int = 256, max_steps: int = 50_000, device: str = "cuda", log_every: int = 0,
-         fused_optimizer: bool = True):
+         fused_optimizer: bool = True, datamodule=None):
     """Train on ``counts[train_idx]`` (cells x genes, fp32, on ``device``); returns the LitVAE task.
 
     ``test_idx`` / ``cell_class`` / ``additional_restriction`` are accepted for signature parity;
     dataset restriction and validation belong to the data layer, which is out of scope here."""
+    if datamodule is not None:
+        return _main_datamodule(datamodule, model_cfg, task_cfg, trainer_cfg, max_steps, log_every, fused_optimizer)
     if counts is None:
-        raise ValueError("vae_amd.train.main: pass the count matrix (cells x genes) as `counts`")
+        raise ValueError("vae_amd.train.main: pass the count matrix (cells x genes) as `counts`, or a `datamodule`")
     torch.manual_seed(43)  # pl.seed_everything(43), train.py:20
     mcfg, tcfg, rcfg = dict(_model_cfg), dict(_task_cfg), dict(_trainer_cfg)
     mcfg.update(model_cfg or {}); tcfg.update(task_cfg or {}); rcfg.update(trainer_cfg or {})
@@ -90,4 +94,66 @@ def main(train_idx: List[int], test_idx: List[int], cell_class: str, additional_
             sched.step()
         if log_every and step % log_every == 0:
             print(f"step {step}: loss {float(out['loss']):.5f} gene_loss {float(out['gene_loss']):.3f}")
+    return task
+
+
+def _main_datamodule(dm, model_cfg, task_cfg, trainer_cfg, max_steps, log_every, fused_optimizer):
+    """train.py:17-65 over a ``vae_amd.data.DataModule``: seeds (pl.seed_everything(43) seeds python, numpy and
+    torch), ``dm.setup``, the library prior from the training set, VAE + LitVAE, then epochs of the train loader
+    until ``max_steps``; every batch is a device gather (+ mixup) followed by one fused step."""
+    import random
+    random.seed(43); np.random.seed(43); torch.manual_seed(43)
+    mcfg, tcfg, rcfg = dict(_model_cfg), dict(_task_cfg), dict(_trainer_cfg)
+    mcfg.update(model_cfg or {}); tcfg.update(task_cfg or {}); rcfg.update(trainer_cfg or {})
+    dm.setup("train")
+    ds = dm.train_dataset
+    lib_mean, lib_var = ds.library_size_stats()
+    use_heads = bool(dm.cell_properties)
+    cell_properties = dm.cell_properties if use_heads else {"_": {"discrete": True, "values": [0, 1], "stop_grad": True}}
+    mcfg["grad_reverse_dict"] = {k: v for k, v in mcfg.get("grad_reverse_dict", {}).items() if k in cell_properties}
+    if dm.batch_properties is not None:
+        raise NotImplementedError("vae_amd.train.main: batch covariates run on the module path only (INTEGRATION.md)")
+    network = VAE(n_input=ds.n_genes, cell_properties=cell_properties, batch_properties=None, **mcfg)
+    precision = ops.BF16 if str(rcfg["precision"]).startswith("bf16") else ops.F16X2
+    task = LitVAE(network, cell_properties=cell_properties if use_heads else None, library_mean=lib_mean,
+                  library_var=lib_var, precision=precision,
+                  **{k: v for k, v in tcfg.items() if k not in ("batch_properties",)})
+    task.train()
+    if dist.is_initialized():
+        task.dropout_seed += 0x9E3779B97F4A7C15 * dist.get_rank() % (2 ** 63)
+        np.random.seed(43 + dist.get_rank())       # every rank draws its own batches
+    arena = task.attach_arena(ds.device)
+    broadcast_parameters(arena)
+    reducer = GradAllReducer(arena) if dist.is_initialized() and dist.get_world_size() > 1 else None
+    if fused_optimizer:
+        warm = float(tcfg["warmup_steps"])
+        opt = FusedAdamW(arena, lr=tcfg["learning_rate"], weight_decay=tcfg["weight_decay"],
+                         max_grad_norm=rcfg["grad_clip_value"],
+                         lr_lambda=lambda s: (warm ** 0.5) * min((s + 1) ** -0.5, (s + 1) * warm ** -1.5),
+                         skip=() if use_heads else [k for k in arena.offsets if k.startswith("cell_decoder")])
+        sched = None
+    else:
+        opt_cfg = task.configure_optimizers()
+        opt, sched = opt_cfg["optimizer"], opt_cfg["lr_scheduler"]["scheduler"]
+    params = [p for p in network.parameters() if p.grad is not None]
+    step = 0
+    while step < max_steps:
+        n_before = step
+        for batch in dm.train_dataloader():
+            out = task.training_step_fused(batch, reducer=reducer)
+            if reducer is not None:
+                reducer.finish()
+            if sched is None:
+                opt.step()
+            else:
+                torch.nn.utils.clip_grad_norm_(params, rcfg["grad_clip_value"])
+                opt.step()
+                sched.step()
+            if log_every and step % log_every == 0:
+                print(f"step {step}: loss {float(out['loss']):.5f} gene_loss {float(out['gene_loss']):.3f}")
+            step += 1
+            if step >= max_steps:
+                break
+        if step == n_before:
+            raise ValueError("vae_amd.train.main: the training loader yields no batch (fewer cells than one batch)")
     return task
