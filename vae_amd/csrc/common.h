@@ -84,6 +84,23 @@ __device__ __forceinline__ float block_max(float v, float* scratch) {
   return t;
 }
 
+// Workgroup `bi` of `nb` (256 threads each) scans its share of n4 16-byte chunks of w and returns max|w| to every
+// thread; four 16-byte loads in flight per lane.  `red`: 4 floats of LDS.
+__device__ __forceinline__ float vae_absmax_scan(const float* __restrict__ w, int64_t n4, int64_t nb, int64_t bi, float* red) {
+  auto m4 = [](const float4& v) { return fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))); };
+  const float4* w4 = reinterpret_cast<const float4*>(w);
+  float m = 0.f;
+  const int64_t stride = nb * 256;
+  int64_t i = bi * 256 + threadIdx.x;
+  for (; i + 3 * stride < n4; i += 4 * stride) {
+    const float4 a = w4[i], b = w4[i + stride], c = w4[i + 2 * stride], d = w4[i + 3 * stride];
+    m = fmaxf(m, fmaxf(fmaxf(m4(a), m4(b)), fmaxf(m4(c), m4(d))));
+  }
+  for (; i < n4; i += stride) m = fmaxf(m, m4(w4[i]));
+  return block_max<4>(m, red);
+}
+
+
 // torch.nn.functional.softplus with beta=1, threshold=20 (distributions.py:42,47; modules.py:269)
 __device__ __forceinline__ float softplus20(float v) { return v > 20.f ? v : log1pf(expf(v)); }
 // its derivative as torch's softplus_backward evaluates it: z/(z+1), z = exp(v)

@@ -96,8 +96,7 @@ __device__ __forceinline__ float digamma_exact(float z) {
   const float iz = 1.f / z, iz2 = iz * iz;
   return r + logf(z) - 0.5f * iz - iz2 * (0.083333333333f - iz2 * (0.0083333333333f - iz2 * 0.003968253968f));
 }
-__global__ void gene_table_kernel(const float* __restrict__ px_r, int G, float* __restrict__ T) {
-  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void gene_table_entry(const float* __restrict__ px_r, int G, float* __restrict__ T, int g) {
   if (g >= G) return;
   const float th = expf(px_r[g]);
   T[ROW_TH * G + g] = th;
@@ -112,6 +111,27 @@ __global__ void gene_table_kernel(const float* __restrict__ px_r, int G, float* 
     lg += logf((th + (float)k) / (float)(k + 1));  // log of the rising-factorial ratio: no cancellation
     dg += 1.f / (th + (float)k);
   }
+}
+__global__ void gene_table_kernel(const float* __restrict__ px_r, int G, float* __restrict__ T) {
+  gene_table_entry(px_r, G, T, blockIdx.x * blockDim.x + threadIdx.x);
+}
+// First launch of a VAE_FP32_F16X2 forward: workgroups [0, VAE_ABSMAX_PARTIALS) scan the two gene-sized weight matrices
+// for the partial maxima their GEMMs need (blocks [0, VAE_ABSMAX_W_SPLIT) -> part0 of w0, the rest -> part1 of w1), the
+// workgroups after them build the gene table -- two independent jobs that otherwise cost a launch each.
+__global__ __launch_bounds__(256) void step_prologue_kernel(const float* __restrict__ w0, int64_t n0, const float* __restrict__ w1,
+                                                            int64_t n1, float* __restrict__ part0, float* __restrict__ part1,
+                                                            const float* __restrict__ px_r, int G, float* __restrict__ T) {
+  __shared__ float red[4];
+  const int blk = blockIdx.x;
+  if (blk >= VAE_ABSMAX_PARTIALS) {
+    gene_table_entry(px_r, G, T, (blk - VAE_ABSMAX_PARTIALS) * 256 + threadIdx.x);
+    return;
+  }
+  const bool first = blk < VAE_ABSMAX_W_SPLIT;
+  const int bi = first ? blk : blk - VAE_ABSMAX_W_SPLIT;
+  const float m = first ? vae_absmax_scan(w0, n0 >> 2, VAE_ABSMAX_W_SPLIT, bi, red)
+                        : vae_absmax_scan(w1, n1 >> 2, VAE_ABSMAX_PARTIALS - VAE_ABSMAX_W_SPLIT, bi, red);
+  if (threadIdx.x == 0) (first ? part0 : part1)[bi] = m;
 }
 
 // ---- one (cell, gene) element ------------------------------------------------------------
@@ -540,6 +560,18 @@ extern "C" int vae_gene_table(const float* px_r, int64_t G, float* table, void* 
   hipLaunchKernelGGL(gene_table_kernel, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, (hipStream_t)stream, px_r,
                      (int)G, table);
   VAE_CHECK_LAUNCH("vae_gene_table");
+  return VAE_OK;
+}
+
+// part0[0 .. VAE_ABSMAX_W_SPLIT) / part1[0 .. VAE_ABSMAX_PARTIALS - VAE_ABSMAX_W_SPLIT) = partial maxima of |w0| / |w1|
+// (n0, n1 multiples of 4, 16-byte aligned) and table = vae_gene_table(px_r), in one launch.
+int vae_step_prologue(const float* w0, int64_t n0, const float* w1, int64_t n1, float* part0, float* part1, const float* px_r,
+                      int64_t G, float* table, void* stream) {
+  VAE_REQUIRE(w0 && w1 && part0 && part1 && n0 > 0 && n1 > 0 && n0 % 4 == 0 && n1 % 4 == 0 && vae_aligned16(w0) &&
+                  vae_aligned16(w1) && px_r && table && G > 0, "vae_step_prologue: bad arguments");
+  hipLaunchKernelGGL(step_prologue_kernel, dim3(VAE_ABSMAX_PARTIALS + (unsigned)((G + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, w0, n0, w1, n1, part0, part1, px_r, (int)G, table);
+  VAE_CHECK_LAUNCH("vae_step_prologue");
   return VAE_OK;
 }
 

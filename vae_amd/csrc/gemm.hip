@@ -1239,48 +1239,6 @@ __global__ __launch_bounds__(256) void absmax_raw_kernel(const float* __restrict
 }
 }  // namespace
 
-namespace {
-// max|w| of two dense arrays (the two gene-sized weight matrices) in ONE launch: blocks [0, nb0) scan w0 and write
-// part0[block], the rest scan w1 and write part1[block - nb0]; four 16-byte loads in flight per lane.
-__global__ __launch_bounds__(256) void absmax_weights_kernel(const float* __restrict__ w0, int64_t n0, int nb0,
-                                                             const float* __restrict__ w1, int64_t n1, float* part0,
-                                                             float* part1) {
-  __shared__ float red[4];
-  const bool first = (int)blockIdx.x < nb0;
-  const float* w = first ? w0 : w1;
-  const int64_t n4 = (first ? n0 : n1) >> 2;
-  const int64_t nb = first ? nb0 : (int)gridDim.x - nb0, bi = first ? blockIdx.x : blockIdx.x - nb0;
-  float m = 0.f;
-  const int64_t stride = nb * 256;
-  int64_t i = bi * 256 + threadIdx.x;
-  for (; i + 3 * stride < n4; i += 4 * stride) {
-    const float4 a = reinterpret_cast<const float4*>(w)[i], b = reinterpret_cast<const float4*>(w)[i + stride];
-    const float4 c = reinterpret_cast<const float4*>(w)[i + 2 * stride], d = reinterpret_cast<const float4*>(w)[i + 3 * stride];
-    m = fmaxf(m, fmaxf(fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w))),
-                       fmaxf(fmaxf(fabsf(b.x), fabsf(b.y)), fmaxf(fabsf(b.z), fabsf(b.w)))));
-    m = fmaxf(m, fmaxf(fmaxf(fmaxf(fabsf(c.x), fabsf(c.y)), fmaxf(fabsf(c.z), fabsf(c.w))),
-                       fmaxf(fmaxf(fabsf(d.x), fabsf(d.y)), fmaxf(fabsf(d.z), fabsf(d.w)))));
-  }
-  for (; i < n4; i += stride) {
-    const float4 a = reinterpret_cast<const float4*>(w)[i];
-    m = fmaxf(m, fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w))));
-  }
-  m = block_max<4>(m, red);
-  if (threadIdx.x == 0) (first ? part0 : part1)[bi] = m;
-}
-}  // namespace
-
-// part0[0 .. VAE_ABSMAX_W_SPLIT) / part1[0 .. VAE_ABSMAX_PARTIALS - VAE_ABSMAX_W_SPLIT) = partial maxima of |w0| / |w1|,
-// one launch.  n0, n1 multiples of 4, 16-byte aligned arrays.
-int vae_absmax_weights(const float* w0, int64_t n0, const float* w1, int64_t n1, float* part0, float* part1, void* stream) {
-  VAE_REQUIRE(w0 && w1 && part0 && part1 && n0 > 0 && n1 > 0 && n0 % 4 == 0 && n1 % 4 == 0 && vae_aligned16(w0) &&
-                  vae_aligned16(w1), "vae_absmax_weights: bad arguments");
-  hipLaunchKernelGGL(absmax_weights_kernel, dim3(VAE_ABSMAX_PARTIALS), dim3(256), 0, (hipStream_t)stream, w0, n0,
-                     VAE_ABSMAX_W_SPLIT, w1, n1, part0, part1);
-  VAE_CHECK_LAUNCH("vae_absmax_weights");
-  return VAE_OK;
-}
-
 // ---- internal (internal.h): used by step.hip --------------------------------------------------
 // partial[0 .. VAE_ABSMAX_PARTIALS) = per-workgroup maxima of |X| (every entry written)
 int vae_absmax_partials(const float* X, int64_t rows, int64_t cols, int64_t ld, float* partial, void* stream) {

@@ -4,13 +4,15 @@
 #include <stdint.h>
 
 // Operand maxima travel as arrays of partial maxima (common.h): the producer's waves / workgroups store, the GEMM reduces.
-#define VAE_ABSMAX_PARTIALS 1024   /* entries vae_absmax_partials writes; workgroups of vae_absmax_weights        */
+#define VAE_ABSMAX_PARTIALS 1024   /* entries vae_absmax_partials writes; scanning workgroups of vae_step_prologue */
 #define VAE_ABSMAX_W_SPLIT 440     /* of which the first weight array (encoder, 7.7 M of 18 M elements) gets these */
 
 // partial[0 .. VAE_ABSMAX_PARTIALS) = per-workgroup maxima of |X|
 int vae_absmax_partials(const float* X, int64_t rows, int64_t cols, int64_t ld, float* partial, void* stream);
-// part0[0 .. VAE_ABSMAX_W_SPLIT), part1[0 .. VAE_ABSMAX_PARTIALS - VAE_ABSMAX_W_SPLIT): partial maxima of two dense arrays
-int vae_absmax_weights(const float* w0, int64_t n0, const float* w1, int64_t n1, float* part0, float* part1, void* stream);
+// part0[0 .. VAE_ABSMAX_W_SPLIT), part1[0 .. VAE_ABSMAX_PARTIALS - VAE_ABSMAX_W_SPLIT): partial maxima of two dense arrays,
+// and table = vae_gene_table(px_r, G), in one launch (epilogue.hip)
+int vae_step_prologue(const float* w0, int64_t n0, const float* w1, int64_t n1, float* part0, float* part1, const float* px_r,
+                      int64_t G, float* table, void* stream);
 
 // vae_gemm (slabs_out == null) / vae_gemm_slabs (slabs_out != null: partial slabs left in the workspace) on two scaled
 // f16 terms per element and three matrix-core products; the power-of-two scales are derived inside the kernel from the

@@ -202,8 +202,9 @@ extern "C" int vae_elbo_step_forward(const vae_step_config* cfg, const vae_step_
   const int64_t B = c.B, G = c.G, H = c.H, Hl = c.Hl, L = c.L, Hd = c.Hd, HE = c.H + c.Hl;
   const int64_t NH = c.zinb ? 2 * G : G;
 
-  if (k.fx())  // weight maxima of the two-f16-term products; the same launch clears the activations' slots of this step
-    TRY(vae_absmax_weights(p->enc_w0, HE * G, p->heads_w, NH * Hd, k.am(AM_WENC), k.am(AM_WHEADS), stream));
+  if (k.fx())  // weight maxima of the two-f16-term products and the gene table, one launch
+    TRY(vae_step_prologue(p->enc_w0, HE * G, p->heads_w, NH * Hd, k.am(AM_WENC), k.am(AM_WHEADS), p->px_r, G, ws + lo.table,
+                          stream));
   // encoders: x/mean-1 -> Linear(G, H+Hl) -> GELU -> LayerNorm (z and library halves)
   TRY(vae_normalize_rows_ex(xv, c.x_dtype, ldx, B, G, ws + lo.mean, ws + lo.xn, lo.ld_xn, k.am(AM_XN), stream));
   // GeneDropout (training): the z-encoder reads its own masked + normalised counts, the library encoder xn
@@ -275,7 +276,7 @@ extern "C" int vae_elbo_step_forward(const vae_step_config* cfg, const vae_step_
   // decoder heads -> fused softmax / library scale / NB-ZINB / row sum -> ELBO scalars
   if (k.fx() && !vae_mid_supported(c)) TRY(vae_absmax_partials(px, B, Hd, Hd, k.am(AM_PX), stream));
   TRY(k.big(VAE_NT, B, NH, Hd, px, Hd, AM_PX, p->heads_w, Hd, AM_WHEADS, ws + lo.logits, NH, p->heads_b, nullptr));
-  TRY(vae_gene_table(p->px_r, G, ws + lo.table, stream));
+  if (!k.fx()) TRY(vae_gene_table(p->px_r, G, ws + lo.table, stream));
   if (u8) TRY(vae_nbzinb_fwd_u8(c.zinb, ws + lo.logits, NH, c.zinb ? ws + lo.logits + G : nullptr, NH, x8, ldx, ws + lo.library,
                      ws + lo.table, B, G, ws + lo.ll, ws + lo.rowmax, ws + lo.rowsum, ws + lo.S, stream));
   else TRY(vae_nbzinb_fwd(c.zinb, ws + lo.logits, NH, c.zinb ? ws + lo.logits + G : nullptr, NH, x, ldx, ws + lo.library,
