@@ -100,3 +100,4 @@ class HostOnlyStore:
     def __init__(self, store):
         self.n_cells, self.n_genes = store.shape
         self.device = torch.device("cpu")
+        self.upload = lambda a: torch.from_numpy(np.ascontiguousarray(a))

@@ -194,9 +194,6 @@ extern "C" int vae_elbo_step_forward(const vae_step_config* cfg, const vae_step_
                                      const float* eps_z, const float* eps_l, float* ws, int64_t ws_bytes, void* stream) {
   Layout lo;
   TRY(check_common(cfg, p, p, xv, ldx, eps_z, eps_l, ws, ws_bytes, &lo, "vae_elbo_step_forward"));
-  const bool u8 = cfg->x_dtype == VAE_X_U8;
-  const float* x = (const float*)xv;
-  const uint8_t* x8 = (const uint8_t*)xv;
   const vae_step_config& c = *cfg;
   const Ctx k{c, ws, lo, stream};
   const int64_t B = c.B, G = c.G, H = c.H, Hl = c.Hl, L = c.L, Hd = c.Hd, HE = c.H + c.Hl;
@@ -277,10 +274,12 @@ extern "C" int vae_elbo_step_forward(const vae_step_config* cfg, const vae_step_
   if (k.fx() && !vae_mid_supported(c)) TRY(vae_absmax_partials(px, B, Hd, Hd, k.am(AM_PX), stream));
   TRY(k.big(VAE_NT, B, NH, Hd, px, Hd, AM_PX, p->heads_w, Hd, AM_WHEADS, ws + lo.logits, NH, p->heads_b, nullptr));
   if (!k.fx()) TRY(vae_gene_table(p->px_r, G, ws + lo.table, stream));
-  if (u8) TRY(vae_nbzinb_fwd_u8(c.zinb, ws + lo.logits, NH, c.zinb ? ws + lo.logits + G : nullptr, NH, x8, ldx, ws + lo.library,
-                     ws + lo.table, B, G, ws + lo.ll, ws + lo.rowmax, ws + lo.rowsum, ws + lo.S, stream));
-  else TRY(vae_nbzinb_fwd(c.zinb, ws + lo.logits, NH, c.zinb ? ws + lo.logits + G : nullptr, NH, x, ldx, ws + lo.library,
-                     ws + lo.table, B, G, ws + lo.ll, ws + lo.rowmax, ws + lo.rowsum, ws + lo.S, stream));
+  if (c.x_dtype == VAE_X_U8)
+    TRY(vae_nbzinb_fwd_u8(c.zinb, ws + lo.logits, NH, c.zinb ? ws + lo.logits + G : nullptr, NH, (const uint8_t*)xv, ldx,
+                          ws + lo.library, ws + lo.table, B, G, ws + lo.ll, ws + lo.rowmax, ws + lo.rowsum, ws + lo.S, stream));
+  else
+    TRY(vae_nbzinb_fwd(c.zinb, ws + lo.logits, NH, c.zinb ? ws + lo.logits + G : nullptr, NH, (const float*)xv, ldx,
+                       ws + lo.library, ws + lo.table, B, G, ws + lo.ll, ws + lo.rowmax, ws + lo.rowsum, ws + lo.S, stream));
   TRY(vae_elbo_reduce(ws + lo.ll, ws + lo.kl_z, ws + lo.kl_l, B, c.kl_weight, c.gene_loss_coeff, ws + lo.scalars,
                       ws + lo.recon, stream));
   return VAE_OK;

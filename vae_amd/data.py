@@ -32,6 +32,31 @@ _GROUP_SCHEMES = {"cd": ("CERAD", range(1, 5)), "bd": ("BRAAK_AD", range(7)), "b
                   "bcd": ("BRAAK_CERAD", range(9))}
 
 
+class _Uploader:
+    """Small host arrays (batch indices, mixup weights) -> device without a synchronising copy: a ring of pinned
+    staging buffers, each guarded by the event of the copy that last read it."""
+
+    def __init__(self, device, slots: int = 8):
+        self.device, self.slots, self.i = device, slots, 0
+        self.buf = [None] * slots
+        self.done = [None] * slots
+
+    def __call__(self, a: np.ndarray) -> torch.Tensor:
+        a = np.ascontiguousarray(a)
+        s = self.i = (self.i + 1) % self.slots
+        if self.done[s] is not None:
+            self.done[s].synchronize()
+        nbytes = max(a.nbytes, 1)
+        if self.buf[s] is None or self.buf[s].numel() < nbytes:
+            self.buf[s] = torch.empty(max(nbytes, 1 << 16), dtype=torch.uint8).pin_memory()
+        stage = self.buf[s][:a.nbytes]
+        stage.numpy()[...] = a.view(np.uint8).reshape(-1)
+        out = stage.to(self.device, non_blocking=True).view(torch.from_numpy(a[:0]).dtype).view(a.shape)
+        self.done[s] = torch.cuda.Event()
+        self.done[s].record()
+        return out
+
+
 class CountStore:
     """A uint8 cells x genes matrix resident in device memory.
 
@@ -76,6 +101,7 @@ class CountStore:
             torch.cuda.synchronize(dev)
         self.n_cells, self.n_genes = self.dev.shape
         self.device = self.dev.device
+        self.upload = _Uploader(self.device)
 
     def gather(self, cell_rows, gene_idx: Optional[torch.Tensor] = None, dtype: torch.dtype = torch.uint8) -> torch.Tensor:
         """Rows ``cell_rows`` (host sequence / array, validated here, or a device int64 tensor) -> (B, G)."""
@@ -85,7 +111,7 @@ class CountStore:
                 raise ValueError("vae_amd.data.CountStore.gather: cell_rows must be a non-empty 1-D sequence")
             if rows.min() < 0 or rows.max() >= self.n_cells:
                 raise IndexError(f"vae_amd.data.CountStore.gather: row outside [0, {self.n_cells})")
-            cell_rows = torch.from_numpy(rows).to(self.device)
+            cell_rows = self.upload(rows)
         return ops.gather_counts(self.dev, cell_rows, gene_idx, dtype=dtype)
 
 
@@ -320,8 +346,8 @@ class SingleCellDataset:
         alpha, partner = self._mixup_plan(N)
         if partner.max() >= N:
             raise ValueError("vae_amd.data: batch smaller than groups x cell_per_group, mixup partner outside the batch")
-        a = torch.from_numpy(alpha).to(self.device)
-        p = torch.from_numpy(partner.astype(np.int32)).to(self.device)
+        a = self.store.upload(alpha)
+        p = self.store.upload(partner.astype(np.int32))
         gene_vals = ops.mixup_counts(gene_vals, p, a)
         if cell_vals is not None:
             cell_vals = ops.mixup_counts(cell_vals, p, a)
@@ -342,8 +368,9 @@ class SingleCellDataset:
         cell_idx = self.cell_idx[rows]
         mix = self.mixup and self.training
         gene_vals = self.store.gather(cell_idx, self._gene_idx_dev, torch.uint8 if mix else self.counts_dtype)
-        rows_dev = torch.from_numpy(rows).to(self.device)
         cell_prop_vals = cell_mask = batch_labels = batch_mask = None
+        if self.labels is not None or self.batch_properties is not None:
+            rows_dev = self.store.upload(rows)
         if self.labels is not None:
             cell_prop_vals, cell_mask = self._labels_dev[rows_dev], self._mask_dev[rows_dev]
         if self.batch_properties is not None:
