@@ -2,7 +2,12 @@
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -DVAE_PROBE=600 tools/micro/gemm_probe.hip vae_amd/csrc/runtime.hip -o tools/micro/gemm_probe
 //   add -DVAE_ABL=<bits> to ablate: 1 = stage only once, 2 = fetch only once, 4 = no multiply
 //   ./gemm_probe [layout 0 (NT, decoder heads forward) | 1 (NN, decoder dgrad)]
+//   -DPROBE_CFG="128, 160, 4, 1" -DPROBE_BN=160 picks the tile / wave layout / planes; ./gemm_probe 0 4096 probes B = 4096
 #include "../../vae_amd/csrc/gemm.hip"
+#ifndef PROBE_CFG
+#define PROBE_CFG 128, 128, 2, 3
+#define PROBE_BN 128
+#endif
 #include <stdio.h>
 #include <vector>
 
@@ -10,9 +15,9 @@ template <int LAY>
 void run(GemmArgs g, int grid) {
   hipEvent_t a, b;
   hipEventCreate(&a); hipEventCreate(&b);
-  for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((gemm_x3_kernel<LAY, 128, 128, 2, 3>), dim3(grid), dim3(256), 0, 0, g);
+  for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((gemm_x3_kernel<LAY, PROBE_CFG>), dim3(grid), dim3(256), 0, 0, g);
   hipEventRecord(a);
-  for (int i = 0; i < 10; ++i) hipLaunchKernelGGL((gemm_x3_kernel<LAY, 128, 128, 2, 3>), dim3(grid), dim3(256), 0, 0, g);
+  for (int i = 0; i < 10; ++i) hipLaunchKernelGGL((gemm_x3_kernel<LAY, PROBE_CFG>), dim3(grid), dim3(256), 0, 0, g);
   hipEventRecord(b);
   hipDeviceSynchronize();
   float ms; hipEventElapsedTime(&ms, a, b);
@@ -21,14 +26,14 @@ void run(GemmArgs g, int grid) {
 
 int main(int argc, char** argv) {
   const int lay = argc > 1 ? atoi(argv[1]) : 0;
-  const int M = 512, N = 40000, K = 256;   // NT: A (M,K), B (N,K)
+  const int M = argc > 2 ? atoi(argv[2]) : 512, N = 40000, K = 256;   // NT: A (M,K), B (N,K)
   const size_t na = (size_t)M * K, nb = (size_t)N * K;
   float *A, *B, *C;
   hipMalloc(&A, na * 4); hipMalloc(&B, nb * 4); hipMalloc(&C, (size_t)M * N * 4);
   hipMemset(A, 0, na * 4); hipMemset(B, 0, nb * 4);
   GemmArgs g{};
   g.A = A; g.B = B; g.C = C; g.lda = K; g.ldb = K; g.ldc = N; g.M = M; g.N = N; g.K = K;
-  g.k_per_split = K; g.split = 1; g.vecA = g.vecB = 1; g.tiles_m = 4; g.tiles_n = (N + 127) / 128;
+  g.k_per_split = K; g.split = 1; g.vecA = g.vecB = 1; g.tiles_m = (M + 127) / 128; g.tiles_n = (N + PROBE_BN - 1) / PROBE_BN;
   if (lay == 1) { /* NN dgrad: M=512, N=256, K=40000 (A (M,K), B (K,N)) split 8 */
     g.lda = 40000; g.ldb = 256; g.ldc = 256; g.M = 512; g.N = 256; g.K = 40000;
     g.tiles_m = 4; g.tiles_n = 2; g.split = 50; g.k_per_split = 800;
