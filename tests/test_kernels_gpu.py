@@ -81,6 +81,52 @@ def test_gemm_slabs_sum_to_the_product(ops, layout, shape):
 
 
 @pytest.mark.parametrize("layout", [0, 1, 2])
+@pytest.mark.parametrize("shape", [(132, 260, 4096), (640, 1280, 256), (512, 384, 2048), (260, 136, 4100), (96, 257, 4101)])
+def test_gemm_two_f16_terms(ops, layout, shape):
+    """vae_gemm_scaled: operands scaled by a power of two and split into two f16 terms, three MFMA products -- error
+    against fp64 below the fp32 accumulation's own (rows of different magnitude inside f16's reach; ragged shapes take
+    the fp32 kernel)."""
+    M, N, K = shape
+    g = torch.Generator().manual_seed(41)
+    scale = torch.exp2(torch.randint(-6, 1, (M, 1), generator=g).double())
+    a64 = _rand((M, K), 16) * scale
+    b64 = _rand((K, N), 17, 0.05)
+    A = (a64 if layout != ops.TN else a64.t().contiguous()).float().cuda()
+    Bm = (b64.t().contiguous() if layout == ops.NT else b64).float().cuda()
+    bias = _rand((N,), 18).float().cuda()
+    ref = (A.double().cpu() if layout != ops.TN else A.double().cpu().t()) @ (Bm.double().cpu().t() if layout == ops.NT else Bm.double().cpu())
+    mag = (a64.abs() @ b64.abs()).numpy()
+    out = ops.gemm_scaled(layout, A, Bm, bias=bias)
+    err = np.abs(out.double().cpu().numpy() - (ref + bias.double().cpu()).numpy()) / (mag + 1.0)
+    assert err.max() < 4e-7 * max(1.0, np.sqrt(K) / 16)
+
+
+@pytest.mark.parametrize("shape", [(5, 4100, 128), (130, 8192, 256), (512, 40000, 256), (300, 6000, 512), (2100, 4100, 256),
+                                   (2048, 8192, 128)])
+def test_gemm_decoder_head_shape(ops, shape):
+    """NT products with a small K and a wide N (the decoder heads): from 2048 rows on the two-f16-term mode runs on the
+    A-stationary kernel (K % 128 == 0, N >= 4096), the rest on the tiled one -- bf16 mode equals the product of
+    bf16-rounded operands, the two-f16-term mode is fp32-grade; bias, ragged M / N, accumulate, a strided output.
+    (VAE_GEMM_ASTAT=2 sends every shape that fits through the A-stationary kernel, both modes: same assertions.)"""
+    M, N, K = shape
+    a64, b64, bias64 = _rand((M, K), 21), _rand((N, K), 22, 0.1), _rand((N,), 23)
+    A, Bm, bias = a64.float().cuda(), b64.float().cuda(), bias64.float().cuda()
+    ref_b = A.bfloat16().double().cpu() @ Bm.bfloat16().double().cpu().t() + bias64
+    out = ops.gemm(ops.NT, A, Bm, bias=bias, precision=ops.BF16)
+    assert rel_err(out.cpu().numpy(), ref_b.numpy()) < 1e-5
+    ref = A.double().cpu() @ Bm.double().cpu().t() + bias64
+    mag = (A.double().cpu().abs() @ Bm.double().cpu().abs().t()).numpy() + 1.0
+    big = torch.full((M, N + 8), 7.0, device="cuda")
+    out2 = ops.gemm_scaled(ops.NT, A, Bm, bias=bias, out=big[:, :N])
+    assert np.max(np.abs(out2.double().cpu().numpy() - ref.numpy()) / mag) < 4e-7
+    assert float(big[:, N:].min()) == 7.0 and float(big[:, N:].max()) == 7.0      # nothing written past N
+    out3 = ops.gemm_scaled(ops.NT, A, Bm, out=out2.clone(), accumulate=True)
+    assert np.max(np.abs(out3.double().cpu().numpy() - (2 * ref - bias64).numpy()) / mag) < 8e-7
+    out4 = ops.gemm(ops.NT, A, Bm, out=out.clone(), accumulate=True, precision=ops.BF16)
+    assert rel_err(out4.cpu().numpy(), (2 * ref_b - bias64).numpy()) < 2e-5
+
+
+@pytest.mark.parametrize("layout", [0, 1, 2])
 @pytest.mark.parametrize("shape", [(130, 200, 1000), (520, 384, 2004)])
 def test_gemm_bf16(ops, layout, shape):
     M, N, K = shape
