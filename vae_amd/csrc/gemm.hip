@@ -45,6 +45,7 @@ struct GemmArgs {
   int k_per_split;     // multiple of BK
   int split;
   int vecA, vecB;      // 16-byte vector loads allowed
+  int vecC;            // 16-byte vector stores allowed (C / the slabs 16-byte aligned, ldc % 4 == 0, N % 4 == 0)
   int accumulate;      // C += (only when split == 1)
   int tiles_m, tiles_n;
   const float* sa;     // gemm_x3_kernel<NP = 2> (two f16 terms): device pointers to the power-of-two factors the
@@ -896,13 +897,34 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(GemmArgs g) {
     out = g.C + (int64_t)s * g.M * g.N;
     ldc = g.N;
   }
+  // 16-byte stores: every 32 x 32 accumulator block goes through a private 32 x 40-float LDS patch of its wave (the
+  // operand planes are dead by now) and leaves as 4 instructions of 8 rows x 128 B instead of 16 of 2 rows x 128 B --
+  // a quarter of the vector-memory instructions against the 63-deep in-order queue of the wave.
+  constexpr bool PATCHED = (NP * (PLA + PLB) * 2 >= 4 * 32 * 40 * 4);
+  const bool vec_out = PATCHED && g.vecC && !(g.split == 1 && g.accumulate);
+  float* patch = reinterpret_cast<float*>(smem) + wave * (32 * 40);
+  if (vec_out) __syncthreads();   // every wave is done with the operand planes
 #pragma unroll
   for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
     for (int ni = 0; ni < TNN; ++ni) {
-      const int n = n0 + wn * (32 * TNN) + ni * 32 + l31;
+      const int nb = n0 + wn * (32 * TNN) + ni * 32;
+      const int n = nb + l31;
+      const float bv = (g.split == 1 && g.bias && n < g.N) ? g.bias[n] : 0.f;
+      if (vec_out && nb + 32 <= g.N) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          patch[((r & 3) + 8 * (r >> 2) + 4 * h) * 40 + l31] = (NP == 2 ? acc[mi][ni][r] * inv_sc : acc[mi][ni][r]) + bv;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int row = (lane >> 3) + 8 * i;
+          const int m = m0 + wm * (32 * TM) + mi * 32 + row;
+          const float4 v = *reinterpret_cast<const float4*>(patch + row * 40 + 4 * (lane & 7));
+          if (m < g.M) *reinterpret_cast<float4*>(out + (int64_t)m * ldc + nb + 4 * (lane & 7)) = v;
+        }
+        continue;
+      }
       if (n >= g.N) continue;
-      const float bv = (g.split == 1 && g.bias) ? g.bias[n] : 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = m0 + wm * (32 * TM) + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
@@ -1342,6 +1364,7 @@ int gemm_impl(int layout, int precision, int64_t M, int64_t N, int64_t K, const 
     VAE_REQUIRE(vae_aligned16(workspace), "vae_gemm: workspace must be 16-byte aligned");
     g.C = workspace;
   }
+  g.vecC = (N % 4 == 0) && vae_aligned16(g.C) && (split > 1 || slabs_out || ldc % 4 == 0);
   dim3 grid(tiles_m * g.tiles_n, split);
   if (dma_ok) {
     dim3 grid1(tiles_m * g.tiles_n * split);
