@@ -104,10 +104,10 @@ def test_gemm_two_f16_terms(ops, layout, shape):
 @pytest.mark.parametrize("shape", [(5, 4100, 128), (130, 8192, 256), (512, 40000, 256), (300, 6000, 512), (2100, 4100, 256),
                                    (2048, 8192, 128)])
 def test_gemm_decoder_head_shape(ops, shape):
-    """NT products with a small K and a wide N (the decoder heads): from 2048 rows on the two-f16-term mode runs on the
-    A-stationary kernel (K % 128 == 0, N >= 4096), the rest on the tiled one -- bf16 mode equals the product of
-    bf16-rounded operands, the two-f16-term mode is fp32-grade; bias, ragged M / N, accumulate, a strided output.
-    (VAE_GEMM_ASTAT=2 sends every shape that fits through the A-stationary kernel, both modes: same assertions.)"""
+    """NT products with a small K and a wide N (the decoder heads), whose time is dominated by the output tile write
+    (16-byte stores through the per-wave LDS patch; ragged N takes the scalar path for the last column block): bf16
+    mode equals the product of bf16-rounded operands, the two-f16-term mode is fp32-grade; bias, ragged M / N,
+    accumulate, a strided output."""
     M, N, K = shape
     a64, b64, bias64 = _rand((M, K), 21), _rand((N, K), 22, 0.1), _rand((N,), 23)
     A, Bm, bias = a64.float().cuda(), b64.float().cuda(), bias64.float().cuda()

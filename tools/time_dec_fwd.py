@@ -1,4 +1,4 @@
-"""Decoder-head forward product (M, 40000, 256), bf16 and two-f16-term modes; VAE_GEMM_ASTAT=0 selects the tiled kernel."""
+"""Decoder-head forward product (M, 40000, 256), bf16 and two-f16-term modes."""
 import sys, torch
 sys.path.insert(0, ".")
 from vae_amd import ops

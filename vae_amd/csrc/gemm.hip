@@ -939,196 +939,6 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(GemmArgs g) {
   GSTAMP();
 }
 
-// ---------------------------------------------------------------------------------------
-// A-stationary kernel for C[M, N] = A[M, K] B[N, K]^T (+ bias) with a SMALL K and a very wide N -- the decoder-head
-// forward product (M = cells, K = hidden width, N = 2 x genes) at LARGE M (see the dispatch in gemm_impl for where it
-// pays).  The tiled kernel above spends most of a workgroup's life writing its output tile while the co-resident
-// workgroup's operand loads queue behind those stores; here the two never alternate in bursts:
-//   * a workgroup (8 waves, one per CU) owns a 128-row panel of A: split once into its NP planes, resident in LDS
-//     ([128][K + 8] per plane) for the whole kernel;
-//   * each wave streams its own 32-column sub-tiles of B: a lane loads the 8 consecutive k of "its" column straight
-//     from global memory in the matrix-core operand layout and splits them in registers -- B never touches LDS, and
-//     there is no barrier after the prologue;
-//   * per sub-tile a wave runs K/16 x 4 (x 3 products) MFMAs into 4 accumulators and stores 64 values per lane, while
-//     its next operand chunk is already in flight: stores and loads interleave at the granularity of a sub-tile.
-// NP = 1: bf16 operands (VAE_BF16); NP = 2: two scaled f16 terms (VAE_FP32_F16X2).  K % 128 == 0, 16-byte rows.
-// ---------------------------------------------------------------------------------------
-template <int NP>
-__global__ __launch_bounds__(512, 1) void gemm_astat_kernel(GemmArgs g, int panels, int wpp) {
-  extern __shared__ __attribute__((aligned(16))) __bf16 a_lds[];   // NP planes of [128][K + 8]
-  const int K = g.K, LDA = K + 8, plane = 128 * LDA;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
-  // workgroups that stream the same columns of B (same w, different row panels) share an XCD and its L2
-  int panel, w;
-  if ((wpp & 7) == 0) {
-    const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
-    panel = local % panels;
-    w = xcd + 8 * (local / panels);
-  } else {
-    panel = blockIdx.x % panels;
-    w = blockIdx.x / panels;
-  }
-  const int m0 = panel * 128;
-
-  float scA = 1.f, scB = 1.f;
-  if (NP == 2) {
-    if (g.na > 0 || g.nb > 0) {
-      __shared__ float red_s[16];
-      auto partial_max = [&](const float* __restrict__ p, int n) {
-        float m = 0.f;
-        const float4* p4 = reinterpret_cast<const float4*>(p);
-        const int n4 = n >> 2;
-        for (int i = tid; i < n4; i += 512) {
-          const float4 v = p4[i];
-          m = fmaxf(m, fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)));
-        }
-        for (int j = (n4 << 2) + tid; j < n; j += 512) m = fmaxf(m, p[j]);
-        return m;
-      };
-      float ma = partial_max(g.sa, g.na), mb = partial_max(g.sb, g.nb);
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) {
-        ma = fmaxf(ma, __shfl_xor(ma, o, 64));
-        mb = fmaxf(mb, __shfl_xor(mb, o, 64));
-      }
-      if (lane == 0) { red_s[wave] = ma; red_s[8 + wave] = mb; }
-      __syncthreads();
-      ma = mb = 0.f;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) { ma = fmaxf(ma, red_s[i]); mb = fmaxf(mb, red_s[8 + i]); }
-      scA = vae_scale_from_absmax(ma);
-      scB = vae_scale_from_absmax(mb);
-    } else {
-      if (g.sa) scA = *g.sa;
-      if (g.sb) scB = *g.sb;
-    }
-  }
-
-  // ---- the A panel: 128 x K floats -> NP planes in LDS (rows past M repeat the last row; never stored) ----
-  {
-    const int kq = K >> 2;
-    for (int c = tid; c < 128 * kq; c += 512) {
-      const int row = c / kq, k = 4 * (c - row * kq);
-      const float4 v = *reinterpret_cast<const float4*>(g.A + (int64_t)min(m0 + row, g.M - 1) * g.lda + k);
-      const float f[4] = {v.x, v.y, v.z, v.w};
-      if (NP == 2) {
-        f16x4 h4, l4;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float as = f[j] * scA;
-          const _Float16 hh = (_Float16)as;
-          h4[j] = hh;
-          l4[j] = (_Float16)(as - (float)hh);
-        }
-        *reinterpret_cast<bf16x4*>(a_lds + row * LDA + k) = __builtin_bit_cast(bf16x4, h4);
-        *reinterpret_cast<bf16x4*>(a_lds + plane + row * LDA + k) = __builtin_bit_cast(bf16x4, l4);
-      } else {
-        bf16x4 b4;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) b4[j] = (__bf16)f[j];
-        *reinterpret_cast<bf16x4*>(a_lds + row * LDA + k) = b4;
-      }
-    }
-  }
-  __syncthreads();
-
-  // ---- each wave: its own stream of 32-column sub-tiles, operand chunks of 64 k (8 x 16 bytes per lane) ----
-  const int S = (g.N + 31) >> 5;
-  const int nw = wpp * 8;
-  const int nch = K >> 6;                       // chunks per sub-tile (even: K % 128 == 0)
-  const float inv_sc = 1.f / (scA * scB);
-  auto load_chunk = [&](float4 (&buf)[8], int j, int ch) {
-    const float* p = g.B + (int64_t)min(j * 32 + l31, g.N - 1) * g.ldb + 64 * ch + 8 * h;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      buf[2 * q] = *reinterpret_cast<const float4*>(p + 16 * q);
-      buf[2 * q + 1] = *reinterpret_cast<const float4*>(p + 16 * q + 4);
-    }
-  };
-  f32x16 acc[4];
-  auto compute_chunk = [&](const float4 (&buf)[8], int ch) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int kk = 64 * ch + 16 * q + 8 * h;       // this lane's 8 consecutive k of the 16-deep step
-      const float f[8] = {buf[2 * q].x, buf[2 * q].y, buf[2 * q].z, buf[2 * q].w,
-                          buf[2 * q + 1].x, buf[2 * q + 1].y, buf[2 * q + 1].z, buf[2 * q + 1].w};
-      if (NP == 2) {
-        f16x8 bh, bl;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float bs = f[e] * scB;
-          const _Float16 hh = (_Float16)bs;
-          bh[e] = hh;
-          bl[e] = (_Float16)(bs - (float)hh);
-        }
-#pragma unroll
-        for (int ti = 0; ti < 4; ++ti) {
-          const __bf16* pa = a_lds + (32 * ti + l31) * LDA + kk;
-          const f16x8 ah = __builtin_bit_cast(f16x8, *reinterpret_cast<const bf16x8*>(pa));
-          const f16x8 al = __builtin_bit_cast(f16x8, *reinterpret_cast<const bf16x8*>(pa + plane));
-          f32x16 c = acc[ti];                          // smallest terms first, as the tiled kernel does
-          c = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, c, 0, 0, 0);
-          acc[ti] = c;
-        }
-      } else {
-        bf16x8 b;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) b[e] = (__bf16)f[e];
-#pragma unroll
-        for (int ti = 0; ti < 4; ++ti) {
-          const bf16x8 a = *reinterpret_cast<const bf16x8*>(a_lds + (32 * ti + l31) * LDA + kk);
-          acc[ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[ti], 0, 0, 0);
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);   // keep the fragment reads of later steps from being hoisted (registers)
-    }
-  };
-  // panel base in scalar registers, 32-bit element offsets inside the panel (the host checks 128 * ldc + N < 2^30)
-  float* const Cp = g.C + (int64_t)m0 * g.ldc;
-  const unsigned ldc_u = (unsigned)g.ldc;
-  const int rows_left = g.M - m0;
-  auto store_tile = [&](int j) {
-    const int n = j * 32 + l31;
-    if (n >= g.N) return;
-    const float bv = g.bias ? g.bias[n] : 0.f;
-#pragma unroll
-    for (int ti = 0; ti < 4; ++ti)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = 32 * ti + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (row < rows_left) {
-          float* p = Cp + ((unsigned)row * ldc_u + (unsigned)n);
-          float v = (NP == 2 ? acc[ti][r] * inv_sc : acc[ti][r]) + bv;
-          if (g.accumulate) v += *p;
-          *p = v;
-        }
-      }
-  };
-
-  float4 buf0[8], buf1[8];
-  int j = w * 8 + wave;
-  if (j >= S) return;
-  load_chunk(buf0, j, 0);
-  while (j < S) {
-#pragma unroll
-    for (int ti = 0; ti < 4; ++ti)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[ti][r] = 0.f;
-    const int jn = j + nw;
-    for (int ch = 0; ch < nch; ch += 2) {
-      load_chunk(buf1, j, ch + 1);                 // in flight during the MFMAs of chunk ch
-      compute_chunk(buf0, ch);
-      if (ch + 2 < nch) load_chunk(buf0, j, ch + 2);
-      else if (jn < S) load_chunk(buf0, jn, 0);    // first chunk of the next sub-tile, ahead of this one's stores
-      compute_chunk(buf1, ch + 1);
-    }
-    store_tile(j);
-    j = jn;
-  }
-}
-
 // Sums the split-K slabs in slab order, adds the bias, writes (or accumulates into) C.
 // VEC: N % 4 == 0, ldc % 4 == 0, 16-byte aligned pointers -> 16 B per lane, 4 slabs in flight.
 template <bool VEC>
@@ -1294,38 +1104,6 @@ int gemm_impl(int layout, int precision, int64_t M, int64_t N, int64_t K, const 
   g.accumulate = accumulate;
   g.vecA = (lda % 4 == 0) && vae_aligned16(A);
   g.vecB = (ldb % 4 == 0) && vae_aligned16(B);
-  // decoder-head forward shape (small K, very wide N, plain output): the A-stationary kernel
-  {
-    // measured (tools/time_dec_fwd.py, N = 40000, K = 256): two-f16-term mode 412 vs 510 us at M = 4096 but 70 vs 64 us
-    // at M = 512 (its row-strided operand loads cost more than the tiled kernel's staging there); bf16 mode 357 vs 360
-    // and 59 vs 44 us -> used for the two-f16-term mode from M = 2048 on.  VAE_GEMM_ASTAT=0: never, =2: whenever it fits
-    static const int astat_on = getenv("VAE_GEMM_ASTAT") ? atoi(getenv("VAE_GEMM_ASTAT")) : 1;
-    const int np = precision == 1 ? 1 : (f16x2 ? 2 : 0);
-    const int64_t lds_bytes = (int64_t)np * 128 * (K + 8) * 2;
-    const bool pays = astat_on == 2 || (np == 2 && M >= 2048);
-    if (astat_on && pays && np && layout == NT && !slabs_out && !x_mean && K % 128 == 0 && lds_bytes <= 140 * 1024 && N >= 4096 &&
-        M >= 1 && g.vecA && g.vecB && 128 * ldc + N < (1ll << 30)) {
-      const int panels = (int)((M + 127) / 128);
-      const int S = (int)((N + 31) / 32);
-      int wpp = panels >= 256 ? 1 : 256 / panels;
-      if (wpp > (S + 7) / 8) wpp = (S + 7) / 8;
-      if (wpp >= 8) wpp &= ~7;
-      hipStream_t st = (hipStream_t)stream;
-      hipError_t e = hipSuccess;
-      if (np == 2) {
-        e = hipFuncSetAttribute((const void*)gemm_astat_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        if (e == hipSuccess)
-          hipLaunchKernelGGL(gemm_astat_kernel<2>, dim3(panels * wpp), dim3(512), (size_t)lds_bytes, st, g, panels, wpp);
-      } else {
-        e = hipFuncSetAttribute((const void*)gemm_astat_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        if (e == hipSuccess)
-          hipLaunchKernelGGL(gemm_astat_kernel<1>, dim3(panels * wpp), dim3(512), (size_t)lds_bytes, st, g, panels, wpp);
-      }
-      if (e != hipSuccess) return vae_set_error(VAE_ERR_LAUNCH, "vae_gemm: cannot raise the LDS limit: %s", hipGetErrorString(e));
-      VAE_CHECK_LAUNCH("vae_gemm(a-stationary)");
-      return VAE_OK;
-    }
-  }
   const Plan plan = make_plan(g.M, g.N, g.K);
   static const int no_dma = getenv("VAE_GEMM_NO_DMA") ? atoi(getenv("VAE_GEMM_NO_DMA")) : 0;  // tuning knob
   const bool norm = x_mean != nullptr;
