@@ -631,7 +631,7 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
 
 template <int LAYOUT, int BM, int BN, int WAVES_M, int NP>
-__global__ __launch_bounds__(256, 2) void gemm_x3_kernel(GemmArgs g) {
+__global__ __launch_bounds__(256, (NP <= 2 ? 3 : 2)) void gemm_x3_kernel(GemmArgs g) {
   constexpr bool A_KC = (LAYOUT != TN);
   constexpr bool B_KC = (LAYOUT == NT);
   constexpr int WAVES_N = 4 / WAVES_M;
