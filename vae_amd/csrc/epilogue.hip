@@ -145,11 +145,13 @@ __device__ __forceinline__ int tab_index(float x) {  // 0 for zeros and for coun
 
 struct Fwd { float ll, a; };
 
+// Transcendentals per element: exp(-pi), log(1 + e^-pi), log(theta + mu + eps), 1 / (theta + mu + eps), exp(ptl) and ONE
+// shared log / reciprocal pair of s = (x > 0 ? mu + eps : 1 + e^ptl): a positive count needs log(mu + eps) and
+// 1 / (mu + eps), a zero needs softplus(ptl) = log(1 + e^ptl) and its derivative e^ptl / (1 + e^ptl) -- never both.
 template <bool ZINB>
-__device__ __forceinline__ Fwd elem_fwd(float x, float mu, float pi, float th, float lgd_tab, const float* __restrict__ Tg,
-                                        int G) {
+__device__ __forceinline__ Fwd elem_fwd(float x, float mu, float pi, float th, float lte, float lgd_tab,
+                                        const float* __restrict__ Tg, int G) {
   Fwd o;
-  const float lte = flog(th + EPS);
   const float tm = th + mu + EPS;
   const float ltm = flog(tm), itm = frcp(tm);
   const float dlt = lte - ltm;
@@ -157,20 +159,24 @@ __device__ __forceinline__ Fwd elem_fwd(float x, float mu, float pi, float th, f
   float lgd = lgd_tab;
   if (pos && !(x < (float)KTAB && x == truncf(x)))  // rare: large or fractional count
     lgd = lgamma_any(x + th) - Tg[ROW_LG * G] - lgamma_any(x + 1.f);
-  const float ime = frcp(mu + EPS);
-  const float nzterm = x * (-flog(ime) - ltm) + lgd;            // log(mu+eps) = -log(1/(mu+eps))
-  const float a_nz = (x * ime - (x + th) * itm) * mu;
   if (ZINB) {
     const float sp = fsoftplus(-pi);
     const float ptl = fmaf(th, dlt, -pi);
     const float z = fexp(fminf(ptl, 20.f));
-    const float big = ptl > 20.f;
-    const float spz = big ? ptl : flog(1.f + z);               // softplus(ptl), threshold 20
-    const float sgz = big ? 1.f : z * frcp(1.f + z);           // its derivative
+    const bool big = ptl > 20.f;
+    const float s = pos ? mu + EPS : 1.f + z;
+    const float ls = flog(s), is = frcp(s);
+    const float nzterm = x * (ls - ltm) + lgd;                  // pos: ls = log(mu + eps)
+    const float a_nz = (x * is - (x + th) * itm) * mu;          // pos: is = 1 / (mu + eps)
+    const float spz = big ? ptl : ls;                           // zero: softplus(ptl), threshold 20
+    const float sgz = big ? 1.f : z * is;                       // zero: its derivative
     const bool zero = x < EPS;
     o.ll = pos ? (-sp + ptl + nzterm) : (zero ? spz - sp : 0.f);
     o.a = pos ? a_nz : (zero ? -sgz * th * itm * mu : 0.f);
   } else {
+    const float s = mu + EPS;
+    const float nzterm = x * (flog(s) - ltm) + lgd;
+    const float a_nz = (x * frcp(s) - (x + th) * itm) * mu;
     o.ll = th * dlt + (pos ? nzterm : 0.f);
     o.a = pos ? a_nz : -th * itm * mu;
   }
@@ -291,9 +297,10 @@ __global__ __launch_bounds__(THREADS, 4) void nbzinb_fwd_kernel(
 
   // phase 2: software-pipelined likelihood pass.  Iteration j evaluates float4 j while the HBM
   // operands of j+1 and the L2 table entries of j+1 (theta, count-indexed lgamma term) travel.
-  auto tab = [&](const float4& xv, int i, float4& th, float (&lg)[4]) {
+  auto tab = [&](const float4& xv, int i, float4& th, float4& lt, float (&lg)[4]) {
     const int ii = i < n4 ? i : 0;
     th = ld4<VEC>(T + ROW_TH * G, ii, G, 1.f);
+    lt = ld4<VEC>(T + ROW_LTE * G, ii, G, 0.f);
     const float xc[4] = {xv.x, xv.y, xv.z, xv.w};
 #pragma unroll
     for (int c = 0; c < 4; ++c) lg[c] = T[(ROW_LGD + tab_index(xc[c])) * G + min(4 * ii + c, G - 1)];
@@ -301,26 +308,26 @@ __global__ __launch_bounds__(THREADS, 4) void nbzinb_fwd_kernel(
   // vmcnt retires in issue order, so per iteration the order is: (1) table loads of j+1 (their
   // x landed an iteration ago), (2) HBM loads of j+2, (3) evaluate j -- waiting for (1) next
   // iteration then never waits for the younger HBM loads of (2).
-  float4 tha, thb;
+  float4 tha, thb, lta, ltb;
   float lga[4], lgb[4];
-  tab(xa, tid, tha, lga);
+  tab(xa, tid, tha, lta, lga);
   float acc_ll = 0.f, acc_a = 0.f;
 #pragma unroll 1
   for (int j = 0; j < EPT; ++j) {
     const int i = tid + j * THREADS;
-    tab(xb, i + THREADS, thb, lgb);
+    tab(xb, i + THREADS, thb, ltb, lgb);
     float4 xc, pc;
     hbm(j + 2 < EPT ? i + 2 * THREADS : n4, xc, pc);
     const float4 ev = srow[i];
     const int g = 4 * i;
-    Fwd f0 = elem_fwd<ZINB>(xa.x, scale * ev.x, pa.x, tha.x, lga[0], T + min(g, G - 1), G);
-    Fwd f1 = elem_fwd<ZINB>(xa.y, scale * ev.y, pa.y, tha.y, lga[1], T + min(g + 1, G - 1), G);
-    Fwd f2 = elem_fwd<ZINB>(xa.z, scale * ev.z, pa.z, tha.z, lga[2], T + min(g + 2, G - 1), G);
-    Fwd f3 = elem_fwd<ZINB>(xa.w, scale * ev.w, pa.w, tha.w, lga[3], T + min(g + 3, G - 1), G);
+    Fwd f0 = elem_fwd<ZINB>(xa.x, scale * ev.x, pa.x, tha.x, lta.x, lga[0], T + min(g, G - 1), G);
+    Fwd f1 = elem_fwd<ZINB>(xa.y, scale * ev.y, pa.y, tha.y, lta.y, lga[1], T + min(g + 1, G - 1), G);
+    Fwd f2 = elem_fwd<ZINB>(xa.z, scale * ev.z, pa.z, tha.z, lta.z, lga[2], T + min(g + 2, G - 1), G);
+    Fwd f3 = elem_fwd<ZINB>(xa.w, scale * ev.w, pa.w, tha.w, lta.w, lga[3], T + min(g + 3, G - 1), G);
     const bool v0 = g < G, v1 = g + 1 < G, v2 = g + 2 < G, v3 = g + 3 < G;
     acc_ll += (v0 ? f0.ll : 0.f) + (v1 ? f1.ll : 0.f) + (v2 ? f2.ll : 0.f) + (v3 ? f3.ll : 0.f);
     acc_a += (v0 ? f0.a : 0.f) + (v1 ? f1.a : 0.f) + (v2 ? f2.a : 0.f) + (v3 ? f3.a : 0.f);
-    xa = xb; pa = pb; tha = thb;
+    xa = xb; pa = pb; tha = thb; lta = ltb;
     xb = xc; pb = pc;
 #pragma unroll
     for (int c = 0; c < 4; ++c) lga[c] = lgb[c];
