@@ -38,6 +38,22 @@ __device__ __forceinline__ void vae_wave_absmax_store(float* entry, float v) {
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
   if ((threadIdx.x & 63) == 0) *entry = v;
 }
+// Column g of out_k = sum over `chunks` slabs of slab[c][k][g] (slab layout [chunk][3][G]), in chunk order -- the
+// deterministic reduction of the epilogue backward's per-chunk column sums (four loads in flight).
+__device__ __forceinline__ void vae_colreduce_column(const float* __restrict__ slab, int chunks, int G, int k, int g,
+                                                     float* __restrict__ o, int overwrite) {
+  const float* p = slab + (int64_t)k * G + g;
+  const int64_t st = (int64_t)3 * G;
+  float s = 0.f;
+  int c = 0;
+  for (; c + 4 <= chunks; c += 4) {
+    const float a = p[c * st], b = p[(c + 1) * st], d = p[(c + 2) * st], e = p[(c + 3) * st];
+    s = (((s + a) + b) + d) + e;
+  }
+  for (; c < chunks; ++c) s += p[c * st];
+  o[g] = overwrite ? s : o[g] + s;
+}
+
 // The power of two that puts an operand with maximum magnitude m into [2^13, 2^14): the scale of the two-f16-term
 // products (gemm.hip).  1 for m = 0, inf or NaN.
 __device__ __forceinline__ float vae_scale_from_absmax(float m) {

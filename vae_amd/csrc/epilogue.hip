@@ -513,16 +513,7 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict_
   if (g >= G || k >= nk) return;
   float* o = k == 0 ? o0 : (k == 1 ? o1 : o2);
   if (!o) return;
-  const float* p = slab + (int64_t)k * G + g;
-  const int64_t st = (int64_t)3 * G;
-  float s = 0.f;
-  int c = 0;
-  for (; c + 4 <= chunks; c += 4) {  // four loads in flight, fixed summation order
-    const float a = p[c * st], b = p[(c + 1) * st], d = p[(c + 2) * st], e = p[(c + 3) * st];
-    s = (((s + a) + b) + d) + e;
-  }
-  for (; c < chunks; ++c) s += p[c * st];
-  o[g] = overwrite ? s : o[g] + s;
+  vae_colreduce_column(slab, chunks, G, k, g, o, overwrite);
 }
 
 template <bool ZINB, bool VEC, int EPT, int THREADS, typename XT>
@@ -675,7 +666,7 @@ static int nbzinb_bwd_impl(int zinb, const float* logit_scale, int64_t ld_s, con
                            float g_scalar, int64_t B, int64_t G, float* dlogit_scale, int64_t ld_ds,
                            float* dlogit_dropout, int64_t ld_dp, float* dlibrary, float* dpx_r, float* dbias_scale,
                            float* dbias_dropout, float* workspace, int64_t workspace_bytes, void* stream, int overwrite,
-                           float* absmax = nullptr) {
+                           float* absmax = nullptr, VaeDeferredColreduce* defer = nullptr) {
   VAE_REQUIRE(!overwrite || workspace, "vae_nbzinb_bwd_overwrite: needs the workspace (deterministic mode)");
   VAE_REQUIRE(logit_scale && x && library && gene_table && rowmax && rowsum && S && dlogit_scale && dpx_r,
               "vae_nbzinb_bwd: null pointer");
@@ -707,7 +698,11 @@ static int nbzinb_bwd_impl(int zinb, const float* logit_scale, int64_t ld_s, con
 #undef LAUNCH_BWD2
 #undef LAUNCH_BWD
   VAE_CHECK_LAUNCH("vae_nbzinb_bwd");
-  if (slab) {
+  if (slab && defer && overwrite && dbias_scale && (!zinb || dbias_dropout)) {   // the caller folds the reduction into a later launch
+    defer->slab = workspace; defer->chunks = chunks; defer->G = (int)G; defer->nk = zinb ? 3 : 2;
+    defer->out[0] = dpx_r; defer->out[1] = dbias_scale; defer->out[2] = zinb ? dbias_dropout : nullptr;
+  } else if (slab) {
+    if (defer) defer->slab = nullptr;
     hipLaunchKernelGGL(colreduce_kernel, dim3((unsigned)((G + 255) / 256), zinb ? 3 : 2), dim3(256), 0, st, workspace,
                        chunks, (int)G, zinb ? 3 : 2, dpx_r, dbias_scale, dbias_dropout, overwrite);
     VAE_CHECK_LAUNCH("vae_nbzinb_bwd(colreduce)");
@@ -720,14 +715,14 @@ int vae_nbzinb_bwd_ex(int x_dtype, int zinb, const float* logit_scale, int64_t l
                       const float* rowsum, const float* S, const float* g_ll, float g_scalar, int64_t B, int64_t G,
                       float* dlogit_scale, int64_t ld_ds, float* dlogit_dropout, int64_t ld_dp, float* dlibrary, float* dpx_r,
                       float* dbias_scale, float* dbias_dropout, float* workspace, int64_t workspace_bytes, float* absmax,
-                      void* stream) {
+                      VaeDeferredColreduce* defer, void* stream) {
   if (x_dtype == VAE_X_U8)
     return nbzinb_bwd_impl<uint8_t>(zinb, logit_scale, ld_s, logit_dropout, ld_p, (const uint8_t*)x, ld_x, library, gene_table,
                                     rowmax, rowsum, S, g_ll, g_scalar, B, G, dlogit_scale, ld_ds, dlogit_dropout, ld_dp,
-                                    dlibrary, dpx_r, dbias_scale, dbias_dropout, workspace, workspace_bytes, stream, 1, absmax);
+                                    dlibrary, dpx_r, dbias_scale, dbias_dropout, workspace, workspace_bytes, stream, 1, absmax, defer);
   return nbzinb_bwd_impl<float>(zinb, logit_scale, ld_s, logit_dropout, ld_p, (const float*)x, ld_x, library, gene_table, rowmax,
                                 rowsum, S, g_ll, g_scalar, B, G, dlogit_scale, ld_ds, dlogit_dropout, ld_dp, dlibrary, dpx_r,
-                                dbias_scale, dbias_dropout, workspace, workspace_bytes, stream, 1, absmax);
+                                dbias_scale, dbias_dropout, workspace, workspace_bytes, stream, 1, absmax, defer);
 }
 
 extern "C" int vae_nbzinb_bwd(int zinb, const float* logit_scale, int64_t ld_s, const float* logit_dropout, int64_t ld_p,

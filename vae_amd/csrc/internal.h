@@ -33,10 +33,18 @@ int vae_normalize_rows_ex(const void* x, int x_dtype, int64_t ldx, int64_t B, in
 int vae_gene_dropout_ex(const void* x, int x_dtype, int64_t ldx, int64_t B, int64_t G, float p, float alpha, uint64_t seed,
                         uint32_t step, float* running, int32_t* counts, uint32_t* threshold, float* stats, float* mean,
                         float* xn, int64_t ld_xn, float* absmax, void* stream);
+// The column reduction that vae_nbzinb_bwd_ex leaves to a later launch (defer != null: it fills this in instead of
+// launching colreduce_kernel; the slabs in `workspace` must then stay untouched until that launch has run).
+struct VaeDeferredColreduce {
+  const float* slab;
+  int chunks, G, nk;       // nk = 2 (NB) or 3 (ZINB) column vectors
+  float* out[3];           // d px_r, d bias_scale, d bias_dropout (overwritten)
+};
+
 // vae_nbzinb_bwd_overwrite / vae_nbzinb_bwd_u8(overwrite = 1) that also stores the per-workgroup maxima of |dlogits|
 int vae_nbzinb_bwd_ex(int x_dtype, int zinb, const float* logit_scale, int64_t ld_s, const float* logit_dropout, int64_t ld_p,
                       const void* x, int64_t ld_x, const float* library, const float* gene_table, const float* rowmax,
                       const float* rowsum, const float* S, const float* g_ll, float g_scalar, int64_t B, int64_t G,
                       float* dlogit_scale, int64_t ld_ds, float* dlogit_dropout, int64_t ld_dp, float* dlibrary, float* dpx_r,
                       float* dbias_scale, float* dbias_dropout, float* workspace, int64_t workspace_bytes, float* absmax,
-                      void* stream);
+                      VaeDeferredColreduce* defer, void* stream);

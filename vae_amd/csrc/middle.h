@@ -1,6 +1,7 @@
 // Internal interface of middle.hip (fused encoder-tail / decoder-head kernels), used by step.hip.
 #pragma once
 #include "../../include/vae_amd.h"
+#include "internal.h"
 
 bool vae_mid_supported(const vae_step_config& c);
 
@@ -17,4 +18,5 @@ int vae_mid_backward(const vae_step_config& c, const vae_step_tensors* p, const 
                      const float* pre_enc0, const float* ln_mz, const float* ln_rz, const float* ln_ml,
                      const float* ln_rl, const float* z, const float* h_enc0, float* dbet_d, float* dgam_d,
                      float* dpre_d, float* dq_z, float* dq_l, float* dbet_e, float* dgam_e, float* dpre_e,
-                     float* absmax_dpre /* nullable: B * VAE_MID_WAVES per-wave maxima of |dpre_e| */, void* stream);
+                     float* absmax_dpre /* nullable: B * VAE_MID_WAVES per-wave maxima of |dpre_e| */,
+                     const VaeDeferredColreduce* cr /* nullable: column slabs to reduce in the last launch */, void* stream);

@@ -556,6 +556,8 @@ struct WgradTask {
 struct WgradBatch {
   WgradTask task[MAX_TASKS];
   int ntask, B;
+  int cr_tile0;              // workgroups from here on reduce the epilogue backward's column slabs (cr.slab != null)
+  VaeDeferredColreduce cr;
 };
 
 constexpr int TW = 1024;                  // threads of a small_wgrad workgroup
@@ -565,6 +567,12 @@ __global__ __launch_bounds__(TW) void small_wgrad_kernel(WgradBatch wb) {
   __shared__ float Vs[RC][64];            // V[b0+row][q0+col]
   __shared__ float Us[RC][PT];            // U[b0+row][p0+i] (ones for a column sum)
   float (*comb)[PT][64] = reinterpret_cast<float (*)[PT][64]>(&Vs[0][0]);  // [NR][PT][64], reuses Vs after the last round
+  if ((int)blockIdx.x >= wb.cr_tile0) {   // d px_r / d head biases: one column per thread, slabs summed in chunk order
+    const int strips = (wb.cr.G + TW - 1) / TW;
+    const int t = blockIdx.x - wb.cr_tile0, kk = t / strips, g = (t - kk * strips) * TW + threadIdx.x;
+    if (g < wb.cr.G && wb.cr.out[kk]) vae_colreduce_column(wb.cr.slab, wb.cr.chunks, wb.cr.G, kk, g, wb.cr.out[kk], 1);
+    return;
+  }
   int k = 0;
 #pragma unroll
   for (int i = 1; i < MAX_TASKS; ++i) k += (i < wb.ntask && (int)blockIdx.x >= wb.task[i].tile0) ? 1 : 0;
@@ -675,7 +683,7 @@ int vae_mid_backward(const vae_step_config& c, const vae_step_tensors* p, const 
                      const float* pre_enc0, const float* ln_mz, const float* ln_rz, const float* ln_ml,
                      const float* ln_rl, const float* z, const float* h_enc0, float* dbet_d, float* dgam_d,
                      float* dpre_d, float* dq_z, float* dq_l, float* dbet_e, float* dgam_e, float* dpre_e,
-                     float* absmax_dpre, void* stream) {
+                     float* absmax_dpre, const VaeDeferredColreduce* cr, void* stream) {
   MidBwd a;
   a.absmax_dpre = absmax_dpre;
   a.slabs = slabs; a.nslab = nslab; a.slab_stride = c.B * c.Hd;
@@ -721,6 +729,12 @@ int vae_mid_backward(const vae_step_config& c, const vae_step_tensors* p, const 
   add(nullptr, 0, 1, dpre_e, HE, HE, g->enc_b0, 0, 1);
   wb.ntask = n;
   wb.B = B;
+  wb.cr_tile0 = tiles;
+  wb.cr = VaeDeferredColreduce{};
+  if (cr && cr->slab) {
+    wb.cr = *cr;
+    tiles += cr->nk * ((cr->G + TW - 1) / TW);
+  }
   hipLaunchKernelGGL(small_wgrad_kernel, dim3((unsigned)tiles), dim3(TW), 0, (hipStream_t)stream, wb);
   VAE_CHECK_LAUNCH("vae_elbo_step_backward(small wgrad)");
   return VAE_OK;

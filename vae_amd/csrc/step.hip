@@ -27,7 +27,8 @@ struct Layout {
   int64_t dbet_d, dgam_d, dbet_e, dgam_e;  // per-cell LayerNorm-gradient rows of the fused middle
   int64_t xn_z, mean_z, gene_thr, gene_counts;  // GeneDropout: the z-encoder's own normalised counts (-1: off)
   int64_t amax[8]; int amax_n[8];  // partial maxima of the operands of the two-f16-term GEMMs (AM_*): offset, entries
-  int64_t scratch;        // split-K slabs / column-sum slabs (shared, used by one launch at a time)
+  int64_t bwd_slabs;      // column-sum slabs of the epilogue backward (kept until the last launch of the backward)
+  int64_t scratch;        // split-K slabs (shared, used by one launch at a time)
   int64_t scratch_floats;
   int64_t total;
 };
@@ -92,6 +93,7 @@ bool make_layout(const vae_step_config& c, Layout* lo) {
   s = maxi(s, vae_gemm_slabs_workspace_bytes(B, H + Hl, G));  // slabs consumed by the fused middle
   s = maxi(s, vae_gemm_slabs_workspace_bytes(B, Hd, NH));
   s = maxi(s, vae_nbzinb_bwd_workspace_bytes(B, G));
+  lo->bwd_slabs = take(vae_nbzinb_bwd_workspace_bytes(B, G) / 4 + 4);
   lo->scratch_floats = up4(s / 4 + 4);
   lo->scratch = take(lo->scratch_floats);
   lo->total = off;
@@ -315,9 +317,13 @@ extern "C" int vae_elbo_step_backward(const vae_step_config* cfg, const vae_step
   float* lp = c.zinb ? logits + G : nullptr;
 
   // epilogue backward: logits := dlogits (in place); d px_r and the head-bias gradients are overwritten
+  // its column sums (d px_r, head-bias gradients) stay as per-chunk slabs; on the fused-middle path the last launch of
+  // the backward reduces them (one launch less), else a reduce launch follows at once
+  VaeDeferredColreduce cr{};
   TRY(vae_nbzinb_bwd_ex(c.x_dtype, c.zinb, logits, NH, lp, NH, xv, ldx, ws + lo.library, ws + lo.table, ws + lo.rowmax,
                         ws + lo.rowsum, ws + lo.S, nullptr, g_ll, B, G, logits, NH, lp, NH, ws + lo.dlibrary, g->px_r, g->heads_b,
-                        c.zinb ? g->heads_b + G : nullptr, ws + lo.scratch, lo.scratch_floats * 4, k.am(AM_DLOGITS), stream));
+                        c.zinb ? g->heads_b + G : nullptr, ws + lo.bwd_slabs, vae_nbzinb_bwd_workspace_bytes(B, G),
+                        k.am(AM_DLOGITS), vae_mid_supported(c) ? &cr : nullptr, stream));
   const float* px = ws + lo.dec_h[c.n_layers - 1];
   TRY(k.big(VAE_TN, NH, Hd, B, logits, NH, AM_DLOGITS, px, Hd, AM_PX, g->heads_w, Hd, nullptr, nullptr));  // dW = dlogits^T px
   if (event_heads_ready) {
@@ -332,7 +338,7 @@ extern "C" int vae_elbo_step_backward(const vae_step_config* cfg, const vae_step
                          ws + lo.qz_v, ws + lo.ql_v, ws + lo.dlibrary, ws + lo.pre_enc0, ws + lo.ln_mz[0], ws + lo.ln_rz[0],
                          ws + lo.ln_ml, ws + lo.ln_rl, ws + lo.z, ws + lo.h_enc0, ws + lo.dbet_d, ws + lo.dgam_d,
                          ws + lo.dpx, ws + lo.dheads_z, ws + lo.dheads_l, ws + lo.dbet_e, ws + lo.dgam_e,
-                         ws + lo.dpre_enc0, k.am(AM_DPRE), stream));
+                         ws + lo.dpre_enc0, k.am(AM_DPRE), &cr, stream));
   } else {
     // the unfused kernels ACCUMULATE the LayerNorm / bias gradients with atomics: clear them first
     auto zero = [&](float* q, int64_t n) {
