@@ -51,6 +51,20 @@ def test_argument_validation_without_gpu():
     assert rc == 1
     with pytest.raises(RuntimeError, match="status 1"):
         _lib.check(rc, "nbzinb_fwd")
+    # the input-side entry points (rows f2 / f4): null pointers, batch limit, output type, in-place mixing
+    rc = lib.vae_gather_counts(None, 10, 8, None, 4, None, 8, None, 1, 8, None)
+    assert rc == 1 and b"null" in lib.vae_last_error()
+    fake = C.c_void_p(4096)      # never dereferenced: validation fails first
+    rc = lib.vae_gather_counts(fake, 10, 8, fake, 70000, None, 8, fake, 1, 8, None)
+    assert rc == 1 and b"65535" in lib.vae_last_error()
+    rc = lib.vae_gather_counts(fake, 10, 8, fake, 4, None, 16, fake, 1, 16, None)
+    assert rc == 1 and b"gene index" in lib.vae_last_error()
+    rc = lib.vae_gather_counts(fake, 10, 8, fake, 4, None, 8, fake, 5, 8, None)
+    assert rc == 1 and b"out_dtype" in lib.vae_last_error()
+    rc = lib.vae_mixup_counts(fake, 0, 8, 4, 8, fake, fake, fake, 8, None)
+    assert rc == 1 and b"in-place" in lib.vae_last_error()
+    rc = lib.vae_mixup_counts(fake, 3, 8, 4, 8, fake, fake, C.c_void_p(8192), 8, None)
+    assert rc == 1 and b"x_dtype" in lib.vae_last_error()
 
 
 def test_workspace_queries():
