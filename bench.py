@@ -106,7 +106,6 @@ def kernel_breakdown(arena, cfg, x, precision):
     logits = torch.randn(B, NH, device=dev)
     lib = torch.full((B,), 9.0, device=dev)
     table = ops.gene_table(arena.p("px_r"))
-    ll, rmax, rsum, S = ops.nbzinb_fwd(zinb, logits[:, :G], logits[:, G:] if zinb else None, x, lib, table)
     dl = torch.empty_like(logits)
     dlib, dpxr = torch.empty(B, device=dev), torch.zeros(G, device=dev)
     dbs, dbp = torch.zeros(G, device=dev), torch.zeros(G, device=dev)
@@ -128,14 +127,38 @@ def kernel_breakdown(arena, cfg, x, precision):
     ks["gemm_enc_wgrad"] = (time_kernel(lambda: mm(ops.TN, dpre, xn, gw_enc)), "mfma", fl(H + Hl, G, B))
     logits.normal_()
     per = 12 if zinb else 8
-    ks["nbzinb_fwd"] = (time_kernel(lambda: ops.nbzinb_fwd(zinb, logits[:, :G], logits[:, G:] if zinb else None, x, lib, table)),
+    # the step's likelihood forward: the streaming pass with the softmax statistics handed in (the decoder-head GEMM's
+    # epilogue produces them); the statistics-only pass that serves shapes outside that GEMM path is timed beside it
+    fo = torch.stack(ops.nbzinb_fwd(zinb, logits[:, :G], logits[:, G:] if zinb else None, x, lib, table, streaming=True))
+    ks["nbzinb_fwd"] = (time_kernel(lambda: ops.nbzinb_fwd(zinb, logits[:, :G], logits[:, G:] if zinb else None, x, lib, table,
+                                                           streaming=True, out=fo, have_stats=True, partials_only=True)),
                         "hbm", float(per) * B * G)
+    ks["nbzinb_fwd_with_own_statistics"] = (
+        time_kernel(lambda: ops.nbzinb_fwd(zinb, logits[:, :G], logits[:, G:] if zinb else None, x, lib, table, streaming=True,
+                                           out=fo)), "hbm", float(per + 4) * B * G)
+    rmax, rsum, S = fo[1], fo[2], fo[3]
     per_b = 20 if zinb else 12
     ks["nbzinb_bwd"] = (time_kernel(lambda: ops.nbzinb_bwd(zinb, logits[:, :G], logits[:, G:] if zinb else None, x, lib, table,
                                                            rmax, rsum, S, None, -1e-5, dl[:, :G], dl[:, G:] if zinb else None,
                                                            dlib, dpxr, dbs, dbp if zinb else None)),
                         "hbm", float(per_b) * B * G)
     return ks
+
+
+def pmc_traffic(config, precision, B, kernel):
+    """HBM bytes per launch of ``kernel`` from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json: FETCH_SIZE x 2
+    per the gfx950 correction + WRITE_SIZE, separate --pmc runs of this same script's kernels; counters cannot be read
+    from inside the timed process).  None when no pass matches this configuration."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            table = json.load(f)
+    except (OSError, ValueError):
+        return None
+    rec = table.get(f"{config}/{precision}/B{B}", {}).get(kernel)
+    if not rec:
+        return None
+    return {"bytes": rec["fetch_bytes"] + rec["write_bytes"], "fetch_bytes": rec["fetch_bytes"], "write_bytes": rec["write_bytes"],
+            "unit": "B per launch", "source": rec.get("source")}
 
 
 def cpu_baseline(cfg, threads):
@@ -166,9 +189,21 @@ def cpu_baseline(cfg, threads):
         times.append(time.perf_counter() - t0)
     times.sort()
     med = times[len(times) // 2]
-    return dict(value=B / med, unit="cells/s", cores=threads, kind="port",
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            model = next((ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")), model)
+    except OSError:
+        pass
+    try:
+        import psutil
+        physical = psutil.cpu_count(logical=False)
+    except Exception:  # noqa: BLE001
+        physical = None
+    return dict(value=B / med, unit="cells/s", cores=threads, kind="port", host_cpu=model, host_physical_cores=physical,
+                host_logical_cpus=os.cpu_count(),
                 sample=f"{len(times)} fwd+bwd steps of batch {B} of the same config (oracle/vae_oracle.py, fp32, "
-                       f"median {med * 1e3:.1f} ms/step)")
+                       f"median {med * 1e3:.1f} ms/step, torch.set_num_threads({threads}): the job's CPU share on the box)")
 
 
 def main():
@@ -191,6 +226,17 @@ def main():
     ap.add_argument("--no-breakdown", action="store_true")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # launched bare: start one rank per GPU ourselves, as fresh child processes of torch.distributed.run, BEFORE
+        # anything in this process touches the GPU (importing torch does not); rank 0 of the children prints the JSON line
+        import socket
+        import subprocess
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.run(cmd).returncode)
     if os.environ.get("VAE_BENCH_WATCHDOG"):  # dump every thread's stack if the run is still alive after N seconds
         import faulthandler
         faulthandler.dump_traceback_later(int(os.environ["VAE_BENCH_WATCHDOG"]), exit=True)
@@ -198,8 +244,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py: --gpus N > 1 must be launched through torch.distributed.run (one rank per GPU)")
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     import torch.distributed as dist
     if args.backend == "gloo":
         local_rank %= max(1, torch.cuda.device_count())  # rehearsal: ranks may share a GPU
@@ -320,7 +365,8 @@ def main():
         else:
             ach, peak, unit = work / (t_ms * 1e-3) / 1e12, MFMA_PEAK[cfg["precision"]], "TFLOP/s"
         result["roofline"] = {"kernel": name, "bound": bound, "achieved": ach, "peak": peak, "unit": unit,
-                              "frac": ach / peak, "traffic": None, "avg_launch_ms": t_ms,
+                              "frac": ach / peak, "traffic": pmc_traffic(args.config, cfg["precision"], B, name), "avg_launch_ms": t_ms,
+                              "algorithmic_per_launch": work,
                               "peak_basis": MFMA_BASIS[cfg["precision"]] if bound == "mfma" else "HBM3E 8 TB/s"}
         result["kernels"] = {
             k: {"ms": v[0], "bound": v[1],

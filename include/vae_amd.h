@@ -41,6 +41,8 @@ extern "C" {
                           * precision: the five gene-sized products use it, the operand maxima come from the
                           * kernels that produce the operands; every other product as VAE_FP32            */
 
+enum { VAE_X_F32 = 0, VAE_X_U8 = 1 };   /* dtype of a count matrix */
+
 /* ---- library ---------------------------------------------------------------------------- */
 int vae_version(void);             /* 100 * major + minor */
 const char* vae_arch(void);        /* "gfx950" */
@@ -141,11 +143,24 @@ int vae_px_rate(const float* logit_scale, int64_t ld_s, const float* library, co
 int64_t vae_gene_table_rows(void);
 /* per-gene constants of the epilogue, (vae_gene_table_rows(), G); rebuild whenever px_r changes   */
 int vae_gene_table(const float* px_r, int64_t G, float* table, void* stream);
-int64_t vae_nbzinb_max_genes(void);
+int64_t vae_nbzinb_max_genes(void);   /* limit of vae_nbzinb_fwd / _u8 (a row parked in LDS): 32768; _ws and the step: none */
 /* ll[b] = sum_g log p(x[b,g]); rowmax / rowsum / S are what the backward needs (each [B])         */
 int vae_nbzinb_fwd(int zinb, const float* logit_scale, int64_t ld_s, const float* logit_dropout, int64_t ld_p,
                    const float* x, int64_t ld_x, const float* library, const float* gene_table, int64_t B, int64_t G,
                    float* ll, float* rowmax, float* rowsum, float* S, void* stream);
+/* The same results by a STREAMING pass (what vae_elbo_step_forward runs): one launch computes the softmax statistics of
+ * every row, then (strip of 1024 genes) x (chunk of cells) workgroups evaluate the likelihood with loads and arithmetic
+ * overlapped; per-strip partial sums of ll / S go through `workspace` (>= vae_nbzinb_fwd_workspace_bytes) and are added
+ * in strip order (deterministic).  x: float (VAE_X_F32) or uint8 (VAE_X_U8) counts.  have_stats != 0: rowmax / rowsum
+ * are INPUTS (max_g and sum_g exp(l - max) of every row, e.g. from the producer of the logits) and the statistics
+ * launch is skipped -- the step gets them from the decoder-head GEMM's epilogue.  ll == S == NULL: the final sum over
+ * strips is left to the caller: workspace[(s * 2 + k) * B + b], s < ceil(G / 1024), holds strip s's share of ll[b] (k = 0)
+ * and S[b] (k = 1) -- the step adds them up inside its ELBO reduction.                                                */
+int64_t vae_nbzinb_fwd_workspace_bytes(int64_t B, int64_t G);
+int vae_nbzinb_fwd_ws(int zinb, const float* logit_scale, int64_t ld_s, const float* logit_dropout, int64_t ld_p,
+                      const void* x, int x_dtype, int64_t ld_x, const float* library, const float* gene_table, int64_t B,
+                      int64_t G, float* ll, float* rowmax, float* rowsum, float* S, int have_stats, float* workspace,
+                      int64_t workspace_bytes, void* stream);
 /* uint8 counts (needs G % 4 == 0, ld % 4 == 0, 4-byte aligned rows)                               */
 int vae_nbzinb_fwd_u8(int zinb, const float* logit_scale, int64_t ld_s, const float* logit_dropout, int64_t ld_p,
                    const uint8_t* x, int64_t ld_x, const float* library, const float* gene_table, int64_t B, int64_t G,
@@ -216,7 +231,6 @@ int vae_loglik_elem_bwd(int zinb, const float* gout, int64_t ld_g, const float* 
                         int64_t ld_mu, const float* theta, int64_t ld_theta, const float* pi, int64_t ld_pi, int64_t B,
                         int64_t G, float* dmu, float* dtheta, float* dpi, void* stream);
 
-enum { VAE_X_F32 = 0, VAE_X_U8 = 1 };   /* dtype of a count matrix */
 
 /* ---- dropout ------------------------------------------------------------------------------------
  * nn.Dropout of FCLayers (modules.py:115): x[b, c] *= keep / (1 - p).  torch's generator cannot be
@@ -311,6 +325,13 @@ int vae_elbo_step_px_rate(const vae_step_config* cfg, const float* workspace, in
 int vae_elbo_step_backward(const vae_step_config* cfg, const vae_step_tensors* params, const vae_step_tensors* grads,
                            const void* x, int64_t ldx, const float* eps_z, const float* eps_l, int use_dz_extra,
                            float* workspace, int64_t workspace_bytes, void* event_heads_ready, void* stream);
+/* The same with a second release point for a data-parallel caller (the reference's DDP reduces gradient buckets while
+ * the backward still runs, train.py:57): event_small_ready (nullable hipEvent_t) is recorded once EVERY gradient except
+ * the first-layer encoder weights (enc_w0, written by the last GEMM of the backward) is final.                       */
+int vae_elbo_step_backward_events(const vae_step_config* cfg, const vae_step_tensors* params, const vae_step_tensors* grads,
+                                  const void* x, int64_t ldx, const float* eps_z, const float* eps_l, int use_dz_extra,
+                                  float* workspace, int64_t workspace_bytes, void* event_heads_ready,
+                                  void* event_small_ready, void* stream);
 
 /* ---- fused optimiser step ------------------------------------------------------
  * One call = torch.nn.utils.clip_grad_norm_(max_grad_norm) (Trainer(gradient_clip_val=0.5),

@@ -114,3 +114,33 @@ def test_unbuilt_variants_raise():
         _dataset(store, meta, None, cell_restrictions={"positive_prs": True}, group_balancing=None)
     with pytest.raises(IndexError):
         _dataset(store, meta, None, gene_idx=[0, 5000], group_balancing=None)
+
+
+def test_metadata_loader_executes_nothing_from_the_file(tmp_path):
+    """the metadata file (data.py:41) was read with pickle.load, which runs whatever the file names.  The
+    loader now resolves numpy arrays and plain containers only, and also reads an .npz (allow_pickle=False)."""
+    import pickle
+    from vae_amd.data import _load_metadata
+    _, meta = synthetic_study(n_cells=50, n_genes=20)
+    f = tmp_path / "metadata.pkl"
+    f.write_bytes(pickle.dumps(meta))
+    got = _load_metadata(str(f), None)
+    assert set(got) == {"obs", "var"}
+    for table in ("obs", "var"):
+        for k, v in meta[table].items():
+            assert np.array_equal(np.asarray(got[table][k]), np.asarray(v), equal_nan=np.asarray(v).dtype.kind == "f"), k
+
+    class Boom:
+        def __reduce__(self):
+            import os
+            return (os.system, ("echo pwned > /dev/null",))
+
+    bad = tmp_path / "bad.pkl"
+    bad.write_bytes(pickle.dumps({"obs": {"x": Boom()}, "var": {}}))
+    with pytest.raises(pickle.UnpicklingError, match="only numpy arrays"):
+        _load_metadata(str(bad), None)
+    z = tmp_path / "metadata.npz"
+    np.savez(z, **{f"{t}/{k}": np.asarray(v) for t in ("obs", "var") for k, v in meta[t].items()})
+    got = _load_metadata(str(z), None)
+    assert np.array_equal(got["obs"]["SubID"], meta["obs"]["SubID"]) and np.array_equal(got["var"]["gene_name"], meta["var"]["gene_name"])
+    assert _load_metadata(None, meta) is meta

@@ -397,10 +397,11 @@ def test_dropout_stream_matches_host_restatement(ops, p):
         ops.dropout_apply(y, 1.0, seed, step, site)
 
 
+@pytest.mark.parametrize("streaming", [False, True], ids=["per_cell", "streaming"])
 @pytest.mark.parametrize("zinb", [True, False])
 @pytest.mark.parametrize("G", [1000, 1003, 4100])
 @pytest.mark.parametrize("counts", ["f32", "u8"])
-def test_fused_epilogue_against_the_oracle_likelihood(ops, zinb, G, counts):
+def test_fused_epilogue_against_the_oracle_likelihood(ops, zinb, G, counts, streaming):
     """vae_nbzinb_fwd / _bwd alone vs the oracle's softmax -> exp(library) -> log_(zi)nb_positive -> sum
     (modules.py:362,404, distributions.py:22-90, task.py:156-165) in fp64 autograd, on counts that hit every branch:
     zeros, table counts (< 16), Stirling counts (16..255, thousands) and -- float counts only -- fractional ones;
@@ -430,8 +431,11 @@ def test_fused_epilogue_against_the_oracle_likelihood(ops, zinb, G, counts):
     xd = x.to(torch.uint8).cuda() if counts == "u8" else x.cuda()
     lsd, lpd = ls.cuda(), lp.cuda()
     table = ops.gene_table(px_r.cuda())
-    ll, rmax, rsum, S = ops.nbzinb_fwd(zinb, lsd, lpd if zinb else None, xd, lib.cuda(), table)
+    ll, rmax, rsum, S = ops.nbzinb_fwd(zinb, lsd, lpd if zinb else None, xd, lib.cuda(), table, streaming=streaming)
     assert np.max(np.abs(ll.cpu().double().numpy() - ll64.detach().numpy()) / np.abs(ll64.detach().numpy())) < 1e-5
+    # softmax statistics: log-sum-exp of every row against fp64
+    lse = (rmax.double() + rsum.double().log()).cpu().numpy()
+    assert np.max(np.abs(lse - torch.logsumexp(ls.double(), dim=-1).numpy())) < 2e-6
     dls, dlp = torch.empty_like(lsd), torch.empty_like(lpd)
     dlib = torch.empty(B, device="cuda")
     dpxr, dbs, dbp = (torch.zeros(G, device="cuda") for _ in range(3))
@@ -465,3 +469,39 @@ def test_poisson_log_prob_matches_torch():
     assert rel_err(rd.grad.cpu().numpy(), r64.grad.numpy()) < 1e-5
     # the recon loss of the task: -log_prob summed over genes
     assert rel_err((-out).sum(-1).detach().cpu().numpy(), (-ref).sum(-1).detach().numpy()) < 1e-5
+
+
+@pytest.mark.parametrize("zinb", [True, False])
+def test_streaming_epilogue_forward_at_full_width(ops, zinb):
+    """The streaming forward (vae_nbzinb_fwd_ws: the kernels the fused step runs) at 20 000 and 30 000 genes and a batch
+    that fills several cell chunks, against the one-workgroup-per-cell kernel (itself held to the fp64 oracle above and in
+    the step tests): per-cell ll to 2e-6 relative, S_b to 1e-5 of its scale, statistics to 1e-6."""
+    from oracle import vae_oracle as O
+    g = torch.Generator(device="cuda").manual_seed(3)
+    for B, G in ((300, 20000), (70, 30000), (5, 50000)):
+        x = torch.poisson(torch.rand(B, G, generator=g, device="cuda") * 1.5, generator=g)
+        x[torch.rand(B, G, generator=g, device="cuda") < 0.4] = 0
+        x[:, 3] = 40.0
+        ls = torch.randn(B, G, generator=g, device="cuda") * 2
+        lp = torch.randn(B, G, generator=g, device="cuda") * 3
+        lib = torch.randn(B, generator=g, device="cuda") * 0.5 + 8
+        px_r = torch.randn(G, generator=g, device="cuda") * 0.7
+        table = ops.gene_table(px_r)
+        b = ops.nbzinb_fwd(zinb, ls, lp if zinb else None, x, lib, table, streaming=True)
+        c = ops.nbzinb_fwd(zinb, ls, lp if zinb else None, x.to(torch.uint8), lib, table, streaming=True)
+        if G <= 32768:        # the per-cell kernel parks a row in LDS: 32 768 genes at most
+            a = ops.nbzinb_fwd(zinb, ls, lp if zinb else None, x, lib, table)
+            assert float(((a[0] - b[0]).abs() / a[0].abs()).max()) < 2e-6, (B, G)
+            assert float(((a[1] + a[2].log()) - (b[1] + b[2].log())).abs().max()) < 1e-6
+            assert float((a[3] - b[3]).abs().max() / a[3].abs().max()) < 1e-5
+        else:                 # beyond it: straight against the fp64 oracle
+            with pytest.raises(RuntimeError):
+                ops.nbzinb_fwd(zinb, ls, lp if zinb else None, x, lib, table)
+            mu = torch.exp(lib.double().cpu())[:, None] * torch.softmax(ls.double().cpu(), dim=-1)
+            th = torch.exp(px_r.double().cpu())
+            ll64 = (O.log_zinb_positive(x.double().cpu(), mu, th, lp.double().cpu()) if zinb
+                    else O.log_nb_positive(x.double().cpu(), mu, th)).sum(-1)
+            assert float(((b[0].cpu().double() - ll64).abs() / ll64.abs()).max()) < 1e-5
+        for u, v in zip(b, c):
+            assert torch.equal(u, v)                      # uint8 counts: the same bits
+        assert torch.equal(b[0], ops.nbzinb_fwd(zinb, ls, lp if zinb else None, x, lib, table, streaming=True)[0])   # run to run

@@ -49,8 +49,14 @@ def _worker(rank, world, port, payload, likelihood, q):
         sentinel = arena.flat_grad[arena.used_end:].clone().fill_(7.0)
         arena.flat_grad[arena.used_end:] = sentinel
         red = GradAllReducer(arena, payload=payload)
-        red.bucket_ready("dec_heads")
-        red.bucket_ready("rest")
+        from vae_amd.parallel import BUCKET_ORDER
+        spans = sorted(sp for t in BUCKET_ORDER for sp in red.buckets[t] if sp[1] > sp[0])
+        covered = sum(hi - lo for lo, hi in spans)      # the buckets tile every gradient the loss reaches, once
+        assert all(a[1] <= b[0] for a, b in zip(spans, spans[1:])) and spans[0][0] == 0 and spans[-1][1] == arena.used_end
+        n_grad = sum(arena.g(k).numel() for k, g in g_local.items() if g is not None)
+        assert n_grad <= covered <= n_grad + 3 * len(arena.offsets)    # + alignment padding only
+        for tag in BUCKET_ORDER:
+            red.bucket_ready(tag)
         red.finish()
         tol = 1e-6 if payload == "fp32" else 2e-2
         worst = 0.0
@@ -80,3 +86,37 @@ def test_gradient_allreduce_matches_full_batch(payload, likelihood):
     for p in procs:
         p.join(timeout=60)
     assert all(r[1] == "ok" for r in res), res
+
+
+def _seed_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from vae_amd.train import rank_seed
+        gen = torch.Generator().manual_seed(rank_seed(43))
+        idx = torch.randint(0, 100000, (256,), generator=gen)        # the batch draw of train.main
+        perm = torch.randperm(1000, generator=torch.Generator().manual_seed(rank_seed(43)))[:64]   # RandomSampler's
+        q.put((rank, rank_seed(43), idx.tolist(), perm.tolist()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_ranks_draw_different_cells():
+    """every rank seeded 43 drew the SAME batch, so N GPUs averaged N copies of one gradient.  The reference's
+    DDP gives each rank its own sampler shard (train.py:57); here the batch generators are seeded 43 + rank."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000) + 23
+    procs = [ctx.Process(target=_seed_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert [r[1] for r in res] == [43, 44]
+    assert res[0][2] != res[1][2] and len(set(res[0][2]) & set(res[1][2])) < 16
+    assert res[0][3] != res[1][3]
+    from vae_amd.train import rank_seed
+    assert rank_seed(43) == 43                                    # single process: the reference's seed

@@ -1,0 +1,127 @@
+"""GPU side of the data-parallel path (vae_amd/parallel.py):
+  * one process: the two HIP events the native backward records release each gradient bucket only once it is final
+    (a side stream snapshots every bucket behind its event; the snapshots must equal the final gradients);
+  * two ranks over RCCL ("nccl"), one GPU each: skipped on a box with one GPU, so the first box with two exercises it;
+    every rank must end with the oracle's gradient of the mean loss over the union batch (DDP semantics, train.py:57)."""
+import os
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class _SnapshotReducer:
+    """Stands in for GradAllReducer: 'reducing' a bucket = copying it, on a side stream, behind the event."""
+    world, on_gpu = 2, True
+
+    def __init__(self, arena):
+        from vae_amd.parallel import GradAllReducer
+        self.arena = arena
+        self.buckets = GradAllReducer(arena).buckets
+        self.stream = torch.cuda.Stream()
+        self.snap, self.had_event = {}, {}
+
+    def bucket_ready(self, tag, after_event=None):
+        self.had_event[tag] = after_event is not None
+        ev = after_event
+        if ev is None:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+        with torch.cuda.stream(self.stream):
+            self.stream.wait_event(ev)
+            self.snap[tag] = [self.arena.flat_grad[lo:hi].clone() for lo, hi in self.buckets[tag]]
+
+
+@pytest.mark.parametrize("n_layers", [1, 2])
+def test_native_events_release_buckets_only_when_final(n_layers):
+    from oracle import vae_oracle as O
+    from vae_amd.arena import ParamArena
+    from vae_amd.step import ElboStep
+    B, G, H, Hd, Hl, L = 512, 20000, 256, 256, 128, 30
+    p = O.init_params(G, H, Hd, Hl, L, n_layers, seed=3)
+    x = O.synthetic_counts(B, G, seed=3, zero_inflate=0.3).cuda()
+    g = torch.Generator().manual_seed(4)
+    ez, el = torch.randn(B, L, generator=g).cuda(), torch.randn(B, 1, generator=g).cuda()
+    arena = ParamArena(p, n_layers, "zinb", "cuda")
+    step = ElboStep(arena, l_mean=7.0, l_var=1.0)
+    red = _SnapshotReducer(arena)
+    for it in range(3):
+        arena.flat_grad.fill_(float("nan"))      # a bucket released too early would be snapshotted with NaNs in it
+        torch.cuda.synchronize()
+        step.run(x, ez, el, reducer=red)
+        torch.cuda.synchronize()
+        assert red.had_event == {"dec_heads": True, "small": True, "enc_w0": False}
+        real = torch.zeros(arena.total, dtype=torch.bool, device="cuda")     # gradient elements (not alignment padding)
+        for k, (off, shape) in arena.offsets.items():
+            if k not in arena.no_grad:
+                real[off:off + arena.g(k).numel()] = True
+        seen = 0
+        for tag, spans in red.buckets.items():
+            for (lo, hi), snap in zip(spans, red.snap[tag]):
+                m = real[lo:hi]
+                assert torch.isfinite(snap[m]).all(), (it, tag)
+                assert torch.equal(snap[m], arena.flat_grad[lo:hi][m]), (it, tag)
+                seen += int(m.sum())
+        assert seen == int(real.sum())                                      # the three buckets cover every gradient
+
+
+def _nccl_worker(rank, world, port, payload, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    try:
+        from oracle import vae_oracle as O
+        from vae_amd.arena import ParamArena
+        from vae_amd.parallel import GradAllReducer, broadcast_parameters
+        from vae_amd.step import ElboStep
+        B, G, H, Hd, Hl, L = 256, 4000, 128, 128, 64, 10
+        p = O.init_params(G, H, Hd, Hl, L, 1, seed=11)
+        x = O.synthetic_counts(B, G, seed=11, zero_inflate=0.3)
+        g = torch.Generator().manual_seed(12)
+        ez, el = torch.randn(B, L, generator=g), torch.randn(B, 1, generator=g)
+        lm, lv = O.library_prior(x)
+        start = p if rank == 0 else {k: v + 1.0 for k, v in p.items()}     # the broadcast must repair rank 1
+        arena = ParamArena(start, 1, "zinb", f"cuda:{rank}")
+        broadcast_parameters(arena)
+        step = ElboStep(arena, l_mean=lm, l_var=lv)
+        red = GradAllReducer(arena, payload=payload)
+        half = slice(rank * B // world, (rank + 1) * B // world)
+        for _ in range(3):                                                   # repeated steps reuse events and wire buffers
+            step.run(x[half].cuda(), ez[half].cuda(), el[half].cuda(), reducer=red)
+            red.finish()
+        torch.cuda.synchronize()
+        _, g_full = O.training_step_with_grads({k: v.double() for k, v in p.items()}, x.double(), ez.double(), el.double(),
+                                               n_layers=1, likelihood="zinb", l_mean=lm, l_var=lv)
+        tol = 1e-4 if payload == "fp32" else 2e-2
+        worst = 0.0
+        for k, gf in g_full.items():
+            if gf is None or k.startswith("cell_decoder"):
+                continue
+            worst = max(worst, float((arena.g(k).cpu().double() - gf).abs().max() / gf.abs().max().clamp_min(1e-30)))
+        q.put((rank, "ok" if worst < tol else "fail", worst))
+    except Exception as e:  # noqa: BLE001
+        q.put((rank, "fail", repr(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("payload", ["fp32", "bf16"])
+def test_two_ranks_rccl_match_the_full_batch_gradient(payload):
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (RCCL, one rank per GPU)")
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000) + (41 if payload == "bf16" else 40)
+    procs = [ctx.Process(target=_nccl_worker, args=(r, 2, port, payload, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(r[1] == "ok" for r in res), res

@@ -54,6 +54,9 @@ SIGNATURES = {
     "vae_gene_table": (_i32, [_ptr, _i64, _ptr, _ptr]),
     "vae_nbzinb_max_genes": (_i64, []),
     "vae_nbzinb_fwd": (_i32, [_i32, _ptr, _i64, _ptr, _i64, _ptr, _i64, _ptr, _ptr, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _ptr]),
+    "vae_nbzinb_fwd_workspace_bytes": (_i64, [_i64, _i64]),
+    "vae_nbzinb_fwd_ws": (_i32, [_i32, _ptr, _i64, _ptr, _i64, _ptr, _i32, _i64, _ptr, _ptr, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _i32,
+                                 _ptr, _i64, _ptr]),
     "vae_nbzinb_fwd_u8": (_i32, [_i32, _ptr, _i64, _ptr, _i64, _ptr, _i64, _ptr, _ptr, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _ptr]),
     "vae_nbzinb_bwd_u8": (_i32, [_i32, _ptr, _i64, _ptr, _i64, _ptr, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _f32, _i64, _i64,
                                  _ptr, _i64, _ptr, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _i64, _i32, _ptr]),
@@ -69,6 +72,7 @@ SIGNATURES = {
     "vae_elbo_step_ws_offset": (_i64, [_ptr, _i32]),
     "vae_elbo_step_forward": (_i32, [_ptr, _ptr, _ptr, _i64, _ptr, _ptr, _ptr, _i64, _ptr]),
     "vae_elbo_step_backward": (_i32, [_ptr, _ptr, _ptr, _ptr, _i64, _ptr, _ptr, _i32, _ptr, _i64, _ptr, _ptr]),
+    "vae_elbo_step_backward_events": (_i32, [_ptr, _ptr, _ptr, _ptr, _i64, _ptr, _ptr, _i32, _ptr, _i64, _ptr, _ptr, _ptr]),
     "vae_adamw_workspace_bytes": (_i64, []),
     "vae_adamw_step": (_i32, [_ptr, _ptr, _ptr, _ptr, _i64, _ptr, _i32, C.c_double, C.c_double, C.c_double, C.c_double,
                               _i64, C.c_double, C.c_double, _ptr, _i64, _ptr, _ptr]),

@@ -117,6 +117,16 @@ __device__ __forceinline__ float vae_absmax_scan(const float* __restrict__ w, in
 }
 
 
+// exp with the rounding error of v*log2(e) fed back (keeps softmax weights at ~1 ulp for |v| <= 88); -inf -> 0
+__device__ __forceinline__ float vae_exp_acc(float v) {
+  v = fmaxf(v, -100.f);  // exp underflows to 0 well before; keeps -inf (masked lanes) out of the fma
+  const float t = v * 1.44269504088896341f;
+  float r = fmaf(v, 1.44269504088896341f, -t);
+  r = fmaf(v, 1.925963033500011e-8f, r);
+  const float e = __builtin_amdgcn_exp2f(t);
+  return fmaf(e, r * 0.69314718055994531f, e);
+}
+
 // torch.nn.functional.softplus with beta=1, threshold=20 (distributions.py:42,47; modules.py:269)
 __device__ __forceinline__ float softplus20(float v) { return v > 20.f ? v : log1pf(expf(v)); }
 // its derivative as torch's softplus_backward evaluates it: z/(z+1), z = exp(v)

@@ -44,15 +44,7 @@ constexpr int TABLE_ROWS = 5 + 2 * KTAB;
 __device__ __forceinline__ float flog(float v) { return __builtin_amdgcn_logf(v) * 0.69314718055994531f; }
 __device__ __forceinline__ float fexp(float v) { return __builtin_amdgcn_exp2f(v * 1.44269504088896341f); }
 __device__ __forceinline__ float frcp(float v) { return __builtin_amdgcn_rcpf(v); }
-// exp with the rounding error of v*log2(e) fed back (keeps softmax weights at ~1 ulp for |v| <= 88)
-__device__ __forceinline__ float fexp_acc(float v) {
-  v = fmaxf(v, -100.f);  // exp underflows to 0 well before; keeps -inf (masked lanes) out of the fma
-  const float t = v * 1.44269504088896341f;
-  float r = fmaf(v, 1.44269504088896341f, -t);
-  r = fmaf(v, 1.925963033500011e-8f, r);
-  const float e = __builtin_amdgcn_exp2f(t);
-  return fmaf(e, r * 0.69314718055994531f, e);
-}
+__device__ __forceinline__ float fexp_acc(float v) { return vae_exp_acc(v); }   // compensated exp (common.h)
 __device__ __forceinline__ float fsoftplus(float v) { return v > 20.f ? v : flog(1.f + fexp(v)); }
 __device__ __forceinline__ float fsigmoid20(float v) {  // softplus'(v) as torch evaluates it
   const float z = fexp(fminf(v, 20.f));
@@ -100,8 +92,10 @@ __device__ __forceinline__ void gene_table_entry(const float* __restrict__ px_r,
   if (g >= G) return;
   const float th = expf(px_r[g]);
   T[ROW_TH * G + g] = th;
+  // 1 / (theta + eps) by the SAME hardware instruction the kernels use (frcp), so that expressions built from it on
+  // both sides of a difference agree bit for bit; log(theta + eps) is no longer subtracted from anything (elem_core)
   T[ROW_LTE * G + g] = logf(th + EPS);
-  T[ROW_ITE * G + g] = 1.f / (th + EPS);
+  T[ROW_ITE * G + g] = frcp(th + EPS);
   T[ROW_LG * G + g] = lgammaf(th);
   T[ROW_PSI * G + g] = digamma_exact(th);
   float lg = 0.f, dg = 0.f;  // k = 0
@@ -145,16 +139,35 @@ __device__ __forceinline__ int tab_index(float x) {  // 0 for zeros and for coun
 
 struct Fwd { float ll, a; };
 
-// Transcendentals per element: exp(-pi), log(1 + e^-pi), log(theta + mu + eps), 1 / (theta + mu + eps), exp(ptl) and ONE
-// shared log / reciprocal pair of s = (x > 0 ? mu + eps : 1 + e^ptl): a positive count needs log(mu + eps) and
-// 1 / (mu + eps), a zero needs softplus(ptl) = log(1 + e^ptl) and its derivative e^ptl / (1 + e^ptl) -- never both.
+// log(theta + eps) - log(theta + mu + eps) = -log1p(r), r = mu / (theta + eps), evaluated WITHOUT the cancellation of the
+// reference's two logarithms: u = fl(1 + r), log1p(r) = log(u) + (r - (u - 1)) / u (first-order repair of the rounding of
+// u; exact to O(ulp^2)).  The reference's fp32 form loses theta * ulp(log theta) ~ 1e-6 absolute in ptl, which is all of
+// d ll / d pi = sigmoid(-pi) - sigmoid(ptl) for a quiet gene; this form keeps full relative accuracy of the difference,
+// and a gene whose mu is below fp32's resolution of theta gives EXACTLY ptl = -pi, d pi = 0, as in torch.  Also returns
+// log(theta + mu + eps) and 1 / (theta + mu + eps) = ite / u.  One log, one reciprocal, as before.
+struct Core { float dlt, ltm, itm, rru; };   // rru = r / u = 1 - (theta + eps) / (theta + mu + eps)
+__device__ __forceinline__ Core elem_core(float mu, float lte, float ite) {
+  Core c;
+  const float r = mu * ite;
+  const float u = 1.f + r;
+  const float ru = frcp(u);
+  const float l1p = fmaf(__builtin_amdgcn_logf(u), 0.69314718055994531f, (r - (u - 1.f)) * ru);
+  c.dlt = -l1p;
+  c.ltm = lte + l1p;
+  c.itm = ite * ru;
+  c.rru = r * ru;
+  return c;
+}
+
+// Transcendentals per element: exp(-pi), log(1 + e^-pi), log(1 + r), 1 / (1 + r), exp(ptl) and ONE shared log / reciprocal
+// pair of s = (x > 0 ? mu + eps : 1 + e^ptl): a positive count needs log(mu + eps) and 1 / (mu + eps), a zero needs
+// softplus(ptl) = log(1 + e^ptl) and its derivative e^ptl / (1 + e^ptl) -- never both.
 template <bool ZINB>
-__device__ __forceinline__ Fwd elem_fwd(float x, float mu, float pi, float th, float lte, float lgd_tab,
+__device__ __forceinline__ Fwd elem_fwd(float x, float mu, float pi, float th, float lte, float ite, float lgd_tab,
                                         const float* __restrict__ Tg, int G) {
   Fwd o;
-  const float tm = th + mu + EPS;
-  const float ltm = flog(tm), itm = frcp(tm);
-  const float dlt = lte - ltm;
+  const Core k = elem_core(mu, lte, ite);
+  const float ltm = k.ltm, itm = k.itm, dlt = k.dlt;
   const bool pos = x > EPS;
   float lgd = lgd_tab;
   if (pos && !(x < (float)KTAB && x == truncf(x)))  // rare: large or fractional count
@@ -189,10 +202,10 @@ template <bool ZINB>
 __device__ __forceinline__ Bwd elem_bwd(float x, float mu, float pi, float th, float lte, float ite, float dgd_tab,
                                         const float* __restrict__ Tg, int G) {
   Bwd o;
-  const float tm = th + mu + EPS;
-  const float ltm = flog(tm), itm = frcp(tm);
-  const float dlt = lte - ltm;
-  const float dptl_dth = dlt + th * (ite - itm);
+  const Core k = elem_core(mu, lte, ite);
+  const float itm = k.itm, dlt = k.dlt;
+  // d ptl / d theta = (lte - ltm) + theta (1/(theta+eps) - 1/(theta+mu+eps)); the bracket is ite * r / u: no cancellation
+  const float dptl_dth = fmaf(th * ite, k.rru, dlt);
   const bool pos = x > EPS;
   float dgd = dgd_tab;
   if (pos && !(x < (float)KTAB && x == truncf(x))) dgd = digamma_any(x + th) - Tg[ROW_PSI * G];
@@ -320,10 +333,11 @@ __global__ __launch_bounds__(THREADS, 4) void nbzinb_fwd_kernel(
     hbm(j + 2 < EPT ? i + 2 * THREADS : n4, xc, pc);
     const float4 ev = srow[i];
     const int g = 4 * i;
-    Fwd f0 = elem_fwd<ZINB>(xa.x, scale * ev.x, pa.x, tha.x, lta.x, lga[0], T + min(g, G - 1), G);
-    Fwd f1 = elem_fwd<ZINB>(xa.y, scale * ev.y, pa.y, tha.y, lta.y, lga[1], T + min(g + 1, G - 1), G);
-    Fwd f2 = elem_fwd<ZINB>(xa.z, scale * ev.z, pa.z, tha.z, lta.z, lga[2], T + min(g + 2, G - 1), G);
-    Fwd f3 = elem_fwd<ZINB>(xa.w, scale * ev.w, pa.w, tha.w, lta.w, lga[3], T + min(g + 3, G - 1), G);
+    // 1 / (theta + eps): the instruction the gene table uses (ROW_ITE), recomputed here instead of a third table load
+    Fwd f0 = elem_fwd<ZINB>(xa.x, scale * ev.x, pa.x, tha.x, lta.x, frcp(tha.x + EPS), lga[0], T + min(g, G - 1), G);
+    Fwd f1 = elem_fwd<ZINB>(xa.y, scale * ev.y, pa.y, tha.y, lta.y, frcp(tha.y + EPS), lga[1], T + min(g + 1, G - 1), G);
+    Fwd f2 = elem_fwd<ZINB>(xa.z, scale * ev.z, pa.z, tha.z, lta.z, frcp(tha.z + EPS), lga[2], T + min(g + 2, G - 1), G);
+    Fwd f3 = elem_fwd<ZINB>(xa.w, scale * ev.w, pa.w, tha.w, lta.w, frcp(tha.w + EPS), lga[3], T + min(g + 3, G - 1), G);
     const bool v0 = g < G, v1 = g + 1 < G, v2 = g + 2 < G, v3 = g + 3 < G;
     acc_ll += (v0 ? f0.ll : 0.f) + (v1 ? f1.ll : 0.f) + (v2 ? f2.ll : 0.f) + (v3 ? f3.ll : 0.f);
     acc_a += (v0 ? f0.a : 0.f) + (v1 ? f1.a : 0.f) + (v2 ? f2.a : 0.f) + (v3 ? f3.a : 0.f);
@@ -342,6 +356,160 @@ __global__ __launch_bounds__(THREADS, 4) void nbzinb_fwd_kernel(
   }
 }
 
+// ---- forward, streaming form: (strip of 1024 genes) x (chunk of cells) per workgroup ------------------------------
+// The one-workgroup-per-cell kernel above loads a whole row, then reduces, then evaluates: at B = 512 every workgroup of
+// the single generation is in the same phase at the same time, so HBM time and VALU time ADD (57 us for 123 MB).  Here
+// the row statistics (max, sum of exponentials) are known before the pass starts -- from softmax_stats_kernel below or
+// from the decoder-head GEMM's epilogue -- and the likelihood becomes one streaming pass tiled like the backward:
+// ~1000 workgroups whose loads and arithmetic overlap, per-gene constants in registers, the same 3-stage software
+// pipeline over the cells of a chunk.  Per-cell sums (ll and S_b) leave as per-strip partials, added up in strip order
+// by the ELBO reduction (deterministic).
+constexpr int BWD_STRIP = 1024;   // 256 threads x float4
+constexpr int BWD_MAX_ROWS = 64;  // cells per workgroup (per-cell constants staged in LDS)
+constexpr int FWD_STRIP = BWD_STRIP;   // one grid function serves both directions
+
+// One workgroup per cell: running (max, sum of exp(v - max)) per thread over the row, merged across the workgroup.
+template <bool VEC>
+__global__ __launch_bounds__(256) void softmax_stats_kernel(const float* __restrict__ ls, int64_t ld_s, int G,
+                                                            float* __restrict__ rowmax, float* __restrict__ rowsum) {
+  __shared__ float red[4];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const float* r_s = ls + (int64_t)b * ld_s;
+  const int n4 = (G + 3) >> 2;
+  const float NEG = -INFINITY;
+  float m = NEG, s = 0.f;
+  for (int i0 = tid; i0 < n4; i0 += 4 * 256) {
+    float4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u * 256;
+      v[u] = i < n4 ? ld4<VEC>(r_s, i, G, NEG) : make_float4(NEG, NEG, NEG, NEG);
+    }
+    float mx = m;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) mx = fmaxf(fmaxf(mx, fmaxf(v[u].x, v[u].y)), fmaxf(v[u].z, v[u].w));
+    if (mx > m) { s *= fexp_acc(m - mx); m = mx; }   // first touch: s = 0
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      s += (fexp_acc(v[u].x - m) + fexp_acc(v[u].y - m)) + (fexp_acc(v[u].z - m) + fexp_acc(v[u].w - m));
+  }
+  const float M = block_max<4>(m, red);
+  s = block_sum<4>(s * fexp_acc(m - M), red);
+  if (tid == 0) { rowmax[b] = M; rowsum[b] = s; }
+}
+
+// rowmax / rowsum from the per-slot statistics the decoder-head GEMM's epilogue wrote: one WAVE per row, its lanes
+// across the slots (every load in flight at once), shuffles for the two reductions; fixed order -> deterministic
+__global__ __launch_bounds__(256) void softmax_stats_merge_kernel(const float* __restrict__ sm, const float* __restrict__ ss,
+                                                                  int slots, int B, float* __restrict__ rowmax,
+                                                                  float* __restrict__ rowsum) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= B) return;
+  float m = -INFINITY;
+  for (int t = lane; t < slots; t += 64) m = fmaxf(m, sm[(int64_t)t * B + b]);
+  const float M = wave_max(m);
+  float s = 0.f;
+  for (int t = lane; t < slots; t += 64) s += ss[(int64_t)t * B + b] * fexp_acc(sm[(int64_t)t * B + b] - M);
+  s = wave_sum(s);
+  if (lane == 0) { rowmax[b] = M; rowsum[b] = s; }
+}
+
+struct RowInF { float4 l, p, x; };
+
+template <bool ZINB, bool VEC, typename XT>
+__global__ __launch_bounds__(256) void nbzinb_fwd_tiled_kernel(
+    const float* __restrict__ ls, int64_t ld_s, const float* __restrict__ lp, int64_t ld_p, const XT* __restrict__ x,
+    int64_t ld_x, const float* __restrict__ library, const float* __restrict__ T, const float* __restrict__ rowmax,
+    const float* __restrict__ rowsum, int B, int G, int rows_per_block, float* __restrict__ part) {
+  __shared__ float2 rc[BWD_MAX_ROWS];         // per cell: {max + log(sum exp), exp(library)}
+  __shared__ float2 red[BWD_MAX_ROWS][4];     // per cell and wave: {sum ll, sum a}
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b0 = blockIdx.y * rows_per_block;
+  const int b1 = min(B, b0 + rows_per_block);
+  for (int r = tid; r < b1 - b0; r += 256) rc[r] = make_float2(rowmax[b0 + r] + logf(rowsum[b0 + r]), expf(library[b0 + r]));
+  __syncthreads();
+  // lanes past the last gene keep running (the wave reductions need every lane): clamped addresses, zero weight
+  const int g_raw = blockIdx.x * FWD_STRIP + tid * 4;
+  const int nv = g_raw < G ? min(4, G - g_raw) : 0;
+  const int g0 = nv > 0 ? g_raw : 0;
+  float th[4], lt[4], it[4];
+  const float* Tg[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int g = min(g0 + j, G - 1);
+    Tg[j] = T + g;
+    th[j] = T[ROW_TH * G + g];
+    lt[j] = T[ROW_LTE * G + g];
+    it[j] = T[ROW_ITE * G + g];
+  }
+  auto load = [&](int b) {
+    RowInF r;
+    r.l = ld4<VEC>(ls + (int64_t)b * ld_s, g0 >> 2, G, 0.f);
+    r.x = ld4<VEC>(x + (int64_t)b * ld_x, g0 >> 2, G, 0.f);
+    r.p = ZINB ? ld4<VEC>(lp + (int64_t)b * ld_p, g0 >> 2, G, 0.f) : make_float4(0.f, 0.f, 0.f, 0.f);
+    return r;
+  };
+  // stage A (cell b+2): HBM loads; stage B (cell b+1): count-indexed table loads (L2); stage C (cell b): evaluate.
+  // vmcnt retires in issue order: the table loads of b+1 are issued BEFORE the HBM loads of b+2.
+  RowInF c0 = load(b0);
+  RowInF c1 = b0 + 1 < b1 ? load(b0 + 1) : c0;
+  float d0[4], d1[4] = {0.f, 0.f, 0.f, 0.f};
+  {
+    const float xv[4] = {c0.x.x, c0.x.y, c0.x.z, c0.x.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) d0[j] = Tg[j][(ROW_LGD + tab_index(xv[j])) * G];
+  }
+  for (int b = b0; b < b1; ++b) {
+    if (b + 1 < b1) {
+      const float xv[4] = {c1.x.x, c1.x.y, c1.x.z, c1.x.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) d1[j] = Tg[j][(ROW_LGD + tab_index(xv[j])) * G];
+    }
+    RowInF c2 = c1;
+    if (b + 2 < b1) c2 = load(b + 2);
+    const float2 k = rc[b - b0];
+    const float l4[4] = {c0.l.x, c0.l.y, c0.l.z, c0.l.w};
+    const float p4[4] = {c0.p.x, c0.p.y, c0.p.z, c0.p.w};
+    const float x4[4] = {c0.x.x, c0.x.y, c0.x.z, c0.x.w};
+    float sll = 0.f, sa = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float p = fexp_acc(l4[j] - k.x);      // softmax weight, as the backward evaluates it
+      const Fwd f = elem_fwd<ZINB>(x4[j], k.y * p, p4[j], th[j], lt[j], it[j], d0[j], Tg[j], G);
+      sll += j < nv ? f.ll : 0.f;
+      sa += j < nv ? f.a : 0.f;
+    }
+    sll = wave_sum(sll);
+    sa = wave_sum(sa);
+    if (lane == 0) red[b - b0][wave] = make_float2(sll, sa);
+    c0 = c1;
+    c1 = c2;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) d0[j] = d1[j];
+  }
+  __syncthreads();
+  for (int r = tid; r < b1 - b0; r += 256) {   // this strip's share of ll[b] and S_b, waves in a fixed order
+    const float2 a = red[r][0], b2 = red[r][1], c = red[r][2], d = red[r][3];
+    part[((int64_t)blockIdx.x * 2 + 0) * B + b0 + r] = ((a.x + b2.x) + c.x) + d.x;
+    part[((int64_t)blockIdx.x * 2 + 1) * B + b0 + r] = ((a.y + b2.y) + c.y) + d.y;
+  }
+}
+
+// ll[b] = sum over strips of the partials, in strip order; likewise S[b]
+__global__ __launch_bounds__(256) void fwd_partials_finish_kernel(const float* __restrict__ part, int strips, int B,
+                                                                  float* __restrict__ ll, float* __restrict__ S) {
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  if (b >= B) return;
+  float a = 0.f, c = 0.f;
+  for (int s = 0; s < strips; ++s) {
+    a += part[((int64_t)s * 2 + 0) * B + b];
+    c += part[((int64_t)s * 2 + 1) * B + b];
+  }
+  ll[b] = a;
+  S[b] = c;
+}
+
 // ---- px_rate export (validation / inference: LitVAE.validation_step, task.py:240,263) ------
 // px_rate[b,g] = exp(library[b]) * exp(l[b,g] - max_b) / sum_b: the mu the likelihood pass above used
 // (same expression, same rounding), from the row statistics it saved.  Grid (strips of 1024 genes, cells).
@@ -354,8 +522,8 @@ __global__ __launch_bounds__(256) void px_rate_kernel(const float* __restrict__ 
   const int b = blockIdx.y;
   const int i = blockIdx.x * 256 + threadIdx.x;  // float4 index in the row
   if (4 * i >= G) return;
-  const float m = rowmax[b];
-  const float scale = expf(library[b]) / rowsum[b];
+  const float m = rowmax[b] + logf(rowsum[b]);
+  const float scale = expf(library[b]);
   const float4 l = ld4<VEC>(ls + (int64_t)b * ld_s, i, G, 0.f);
   float4 r;
   r.x = scale * fexp_acc(l.x - m); r.y = scale * fexp_acc(l.y - m);
@@ -373,8 +541,6 @@ __global__ __launch_bounds__(256) void px_rate_kernel(const float* __restrict__ 
 }
 
 // ---- backward: (gene strip of 1024) x (chunk of cells) per workgroup ----------------------
-constexpr int BWD_STRIP = 1024;  // 256 threads x float4
-constexpr int BWD_MAX_ROWS = 64;  // cells per workgroup (per-cell constants staged in LDS)
 
 struct RowIn { float4 l, p, x; };
 
@@ -544,8 +710,7 @@ void dispatch_fwd(const float* ls, int64_t ld_s, const float* lp, int64_t ld_p, 
   else if (G <= 16384) FWD_CASE(8, 512);
   else if (G <= 20480) FWD_CASE(10, 512);
   else if (G <= 24576) FWD_CASE(6, 1024);
-  else if (G <= 32768) FWD_CASE(8, 1024);
-  else FWD_CASE(10, 1024);
+  else FWD_CASE(8, 1024);   // 128 KB of LDS + the reduction scratch: the most one workgroup can hold
 #undef FWD_CASE
 }
 
@@ -573,7 +738,9 @@ int vae_step_prologue(const float* w0, int64_t n0, const float* w1, int64_t n1, 
   return VAE_OK;
 }
 
-extern "C" int64_t vae_nbzinb_max_genes(void) { return 10 * 1024 * 4; }
+// the one-workgroup-per-cell kernel parks a whole row in LDS (vae_nbzinb_fwd / _u8); the streaming form
+// (vae_nbzinb_fwd_ws, vae_elbo_step_*) has no such limit
+extern "C" int64_t vae_nbzinb_max_genes(void) { return 8 * 1024 * 4; }
 
 template <typename XT>
 static int nbzinb_fwd_impl(int zinb, const float* logit_scale, int64_t ld_s, const float* logit_dropout, int64_t ld_p,
@@ -758,4 +925,71 @@ extern "C" int vae_nbzinb_bwd_u8(int zinb, const float* logit_scale, int64_t ld_
   return nbzinb_bwd_impl<uint8_t>(zinb, logit_scale, ld_s, logit_dropout, ld_p, x, ld_x, library, gene_table, rowmax, rowsum, S,
                                   g_ll, g_scalar, B, G, dlogit_scale, ld_ds, dlogit_dropout, ld_dp, dlibrary, dpx_r,
                                   dbias_scale, dbias_dropout, workspace, workspace_bytes, stream, overwrite);
+}
+
+// ---- forward, streaming form (host side) ----------------------------------------------------------------------------
+extern "C" int64_t vae_nbzinb_fwd_workspace_bytes(int64_t B, int64_t G) {
+  int strips, chunks, rpb;
+  bwd_grid(B, G, &strips, &chunks, &rpb);
+  return (int64_t)strips * 2 * B * (int64_t)sizeof(float);
+}
+
+// have_stats != 0: rowmax / rowsum already hold the softmax statistics of every row (decoder-head GEMM epilogue).
+// ll / S may be null: the per-strip partials then stay in `workspace` ([strips][2][B]) for vae_elbo_reduce_parts.
+int vae_nbzinb_fwd_tiled_ex(int x_dtype, int zinb, const float* logit_scale, int64_t ld_s, const float* logit_dropout,
+                            int64_t ld_p, const void* x, int64_t ld_x, const float* library, const float* gene_table, int64_t B,
+                            int64_t G, float* ll, float* rowmax, float* rowsum, float* S, int have_stats, float* workspace,
+                            int64_t workspace_bytes, int* strips_out, void* stream) {
+  VAE_REQUIRE(logit_scale && x && library && gene_table && rowmax && rowsum && workspace, "vae_nbzinb_fwd_ws: null pointer");
+  VAE_REQUIRE((ll == nullptr) == (S == nullptr), "vae_nbzinb_fwd_ws: ll and S go together");
+  VAE_REQUIRE(!zinb || logit_dropout, "vae_nbzinb_fwd_ws: ZINB needs logit_dropout");
+  VAE_REQUIRE(B > 0 && G > 0 && B < (1 << 30) && G < (1 << 30), "vae_nbzinb_fwd_ws: bad shape");
+  VAE_REQUIRE(ld_s >= G && ld_x >= G && (!zinb || ld_p >= G), "vae_nbzinb_fwd_ws: leading dimension too small");
+  VAE_REQUIRE(x_dtype == VAE_X_F32 || x_dtype == VAE_X_U8, "vae_nbzinb_fwd_ws: bad x_dtype");
+  VAE_REQUIRE(workspace_bytes >= vae_nbzinb_fwd_workspace_bytes(B, G), "vae_nbzinb_fwd_ws: workspace too small");
+  const bool u8 = x_dtype == VAE_X_U8;
+  const bool x_ok = u8 ? ((reinterpret_cast<uintptr_t>(x) & 3u) == 0) : vae_aligned16(x);
+  const bool vec = (G % 4 == 0) && (ld_s % 4 == 0) && (ld_x % 4 == 0) && (!zinb || ld_p % 4 == 0) &&
+                   vae_aligned16(logit_scale) && x_ok && (!zinb || vae_aligned16(logit_dropout)) && vae_aligned16(gene_table);
+  VAE_REQUIRE(!u8 || vec, "vae_nbzinb_fwd_u8: needs G %% 4 == 0, leading dimensions %% 4 == 0 and aligned rows");
+  hipStream_t st = (hipStream_t)stream;
+  if (!have_stats) {
+    if (vec) hipLaunchKernelGGL(softmax_stats_kernel<true>, dim3((unsigned)B), dim3(256), 0, st, logit_scale, ld_s, (int)G, rowmax, rowsum);
+    else     hipLaunchKernelGGL(softmax_stats_kernel<false>, dim3((unsigned)B), dim3(256), 0, st, logit_scale, ld_s, (int)G, rowmax, rowsum);
+    VAE_CHECK_LAUNCH("vae_nbzinb_fwd_ws(stats)");
+  }
+  int strips, chunks, rows_per_block;
+  bwd_grid(B, G, &strips, &chunks, &rows_per_block);
+  const dim3 grid(strips, chunks);
+#define LAUNCH_FT(Z, V, XT_)                                                                                              \
+  hipLaunchKernelGGL((nbzinb_fwd_tiled_kernel<Z, V, XT_>), grid, dim3(256), 0, st, logit_scale, ld_s, logit_dropout, ld_p,   \
+                     (const XT_*)x, ld_x, library, gene_table, rowmax, rowsum, (int)B, (int)G, rows_per_block, workspace)
+  if (u8) { if (zinb) LAUNCH_FT(true, true, uint8_t); else LAUNCH_FT(false, true, uint8_t); }
+  else if (zinb) { if (vec) LAUNCH_FT(true, true, float); else LAUNCH_FT(true, false, float); }
+  else           { if (vec) LAUNCH_FT(false, true, float); else LAUNCH_FT(false, false, float); }
+#undef LAUNCH_FT
+  VAE_CHECK_LAUNCH("vae_nbzinb_fwd_ws");
+  if (strips_out) *strips_out = strips;
+  if (ll) {
+    hipLaunchKernelGGL(fwd_partials_finish_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, st, workspace, strips, (int)B, ll, S);
+    VAE_CHECK_LAUNCH("vae_nbzinb_fwd_ws(finish)");
+  }
+  return VAE_OK;
+}
+
+extern "C" int vae_nbzinb_fwd_ws(int zinb, const float* logit_scale, int64_t ld_s, const float* logit_dropout, int64_t ld_p,
+                                 const void* x, int x_dtype, int64_t ld_x, const float* library, const float* gene_table,
+                                 int64_t B, int64_t G, float* ll, float* rowmax, float* rowsum, float* S, int have_stats,
+                                 float* workspace, int64_t workspace_bytes, void* stream) {
+  return vae_nbzinb_fwd_tiled_ex(x_dtype, zinb, logit_scale, ld_s, logit_dropout, ld_p, x, ld_x, library, gene_table, B, G, ll,
+                                 rowmax, rowsum, S, have_stats, workspace, workspace_bytes, nullptr, stream);
+}
+
+int vae_softmax_stats_merge(const float* stat_m, const float* stat_s, int slots, int64_t B, float* rowmax, float* rowsum,
+                            void* stream) {
+  VAE_REQUIRE(stat_m && stat_s && slots > 0 && B > 0 && rowmax && rowsum, "vae_softmax_stats_merge: bad arguments");
+  hipLaunchKernelGGL(softmax_stats_merge_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, (hipStream_t)stream, stat_m,
+                     stat_s, slots, (int)B, rowmax, rowsum);
+  VAE_CHECK_LAUNCH("vae_softmax_stats_merge");
+  return VAE_OK;
 }

@@ -52,6 +52,12 @@ struct GemmArgs {
   const float* sb;     // operands are multiplied by before the split (null = 1); the product is scaled back
   int na, nb;          // > 0: sa / sb are arrays of na / nb partial maxima of |A| / |B| written by the producers of the
                        // operands; the kernel reduces them and derives the factors (0: sa / sb are the factors)
+  // gemm_x3_kernel, 16-byte-store epilogue: softmax statistics of the output rows over columns [0, stat_cols), one
+  // (max, sum of exp(v - max)) pair per row and per wave-wide column span ("slot" = tile_n * WAVES_N + wave_n), written
+  // to stat_m / stat_s [slot][M] -- the decoder-head GEMM hands the likelihood pass its softmax denominators this way
+  float* stat_m;
+  float* stat_s;
+  int stat_cols;
 };
 
 // ---- global -> register tile loaders (R*8/256 float4 per thread per operand, R = 64 or 128) ----
@@ -904,6 +910,14 @@ __global__ __launch_bounds__(256, (NP <= 2 ? 3 : 2)) void gemm_x3_kernel(GemmArg
   const bool vec_out = PATCHED && g.vecC && !(g.split == 1 && g.accumulate);
   float* patch = reinterpret_cast<float*>(smem) + wave * (32 * 40);
   if (vec_out) __syncthreads();   // every wave is done with the operand planes
+  // running softmax statistics of this wave's rows over its column span: lane (8 r' + c) holds rows r' + 8 i, i < 4
+  constexpr bool STAT_OK = LAYOUT == NT && TM <= 2;         // tile shapes whose epilogue carries the statistics registers
+  const bool stats = STAT_OK && g.stat_m != nullptr;        // the host enables it only when every block takes the path below
+  float rmax[STAT_OK ? TM : 1][4], rsum[STAT_OK ? TM : 1][4];
+#pragma unroll
+  for (int mi = 0; mi < (STAT_OK ? TM : 1); ++mi)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { rmax[mi][i] = -INFINITY; rsum[mi][i] = 0.f; }
 #pragma unroll
   for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
@@ -921,6 +935,26 @@ __global__ __launch_bounds__(256, (NP <= 2 ? 3 : 2)) void gemm_x3_kernel(GemmArg
           const int m = m0 + wm * (32 * TM) + mi * 32 + row;
           const float4 v = *reinterpret_cast<const float4*>(patch + row * 40 + 4 * (lane & 7));
           if (m < g.M) *reinterpret_cast<float4*>(out + (int64_t)m * ldc + nb + 4 * (lane & 7)) = v;
+          if (STAT_OK && stats && nb < g.stat_cols) {
+            // lane-local running (max, sum of exp) over the columns THIS lane stores: no cross-lane traffic in the loop.
+            // Plain exp2 (no compensation): the terms that matter sit within a few units of the maximum, where the
+            // argument rounding is < 1e-7 relative; the softmax WEIGHTS downstream keep the compensated form.
+            constexpr int MI = STAT_OK ? 1 : 0;   // (index 0 when the registers are not carried)
+            constexpr float L2E = 1.44269504088896341f;
+            const int c0 = nb + 4 * (lane & 7);
+            const float a0 = c0 < g.stat_cols ? v.x : -INFINITY, a1 = c0 + 1 < g.stat_cols ? v.y : -INFINITY;
+            const float a2 = c0 + 2 < g.stat_cols ? v.z : -INFINITY, a3 = c0 + 3 < g.stat_cols ? v.w : -INFINITY;
+            const float om = rmax[mi * MI][i];
+            const float nm = fmaxf(fmaxf(fmaxf(a0, a1), fmaxf(a2, a3)), om);
+            const float nb2 = -nm * L2E;   // nm is finite unless every column so far was masked (then the terms are exp2(nan)?)
+            if (nm > -INFINITY) {
+              const float e = (__builtin_amdgcn_exp2f(fmaf(a0, L2E, nb2)) + __builtin_amdgcn_exp2f(fmaf(a1, L2E, nb2))) +
+                              (__builtin_amdgcn_exp2f(fmaf(a2, L2E, nb2)) + __builtin_amdgcn_exp2f(fmaf(a3, L2E, nb2)));
+              const float rescale = om == nm ? 1.f : __builtin_amdgcn_exp2f(fmaxf(fmaf(om, L2E, nb2), -126.f));
+              rsum[mi * MI][i] = fmaf(rsum[mi * MI][i], rescale, e);
+              rmax[mi * MI][i] = nm;
+            }
+          }
         }
         continue;
       }
@@ -936,6 +970,28 @@ __global__ __launch_bounds__(256, (NP <= 2 ? 3 : 2)) void gemm_x3_kernel(GemmArg
         }
       }
     }
+  if (STAT_OK && stats && n0 + wn * (32 * TNN) < g.stat_cols) {   // (uniform per wave: every lane takes part in the shuffles)
+    const int slot = tn * WAVES_N + wn;
+#pragma unroll
+    for (int mi = 0; mi < (STAT_OK ? TM : 1); ++mi)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        // merge the 8 lanes that share this row: max, rescale, sum
+        float M = rmax[mi][i];
+        M = fmaxf(M, __shfl_xor(M, 1, 64));
+        M = fmaxf(M, __shfl_xor(M, 2, 64));
+        M = fmaxf(M, __shfl_xor(M, 4, 64));
+        float sv = rmax[mi][i] > -INFINITY ? rsum[mi][i] * vae_exp_acc(rmax[mi][i] - M) : 0.f;
+        sv += __shfl_xor(sv, 1, 64);
+        sv += __shfl_xor(sv, 2, 64);
+        sv += __shfl_xor(sv, 4, 64);
+        const int m = m0 + wm * (32 * TM) + mi * 32 + (lane >> 3) + 8 * i;
+        if ((lane & 7) == 0 && m < g.M) {
+          g.stat_m[(int64_t)slot * g.M + m] = M;
+          g.stat_s[(int64_t)slot * g.M + m] = sv;
+        }
+      }
+  }
   GSTAMP();
 }
 
@@ -1078,14 +1134,16 @@ namespace {
 int gemm_impl(int layout, int precision, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B,
               int64_t ldb, float* C, int64_t ldc, const float* bias, const float* x_mean, int accumulate,
               float* workspace, int64_t workspace_bytes, void* stream, int* slabs_out, const float* scale_a = nullptr,
-              const float* scale_b = nullptr, int n_max_a = 0, int n_max_b = 0) {
+              const float* scale_b = nullptr, int n_max_a = 0, int n_max_b = 0, VaeGemmRowStats* stats = nullptr) {
   VAE_REQUIRE(layout >= 0 && layout <= 2, "vae_gemm: layout must be 0 (NT), 1 (NN) or 2 (TN), got %d", layout);
   VAE_REQUIRE(precision >= 0 && precision <= 3, "vae_gemm: precision must be 0 (fp32), 1 (bf16), 2 (bf16x3) or 3 (f16x2), got %d",
               precision);
   // 3 = two scaled f16 terms, three products: only the split pipeline implements it; shapes outside it take the
   // exact fp32 MFMA kernel (the scales are then not needed)
-  const bool f16x2 = precision == 3;
-  if (f16x2) precision = 0;
+  // Without scales (the public vae_gemm(precision = 3), or a step whose shapes fell out of the pipeline) the operands
+  // could under- or overflow f16 unscaled: such calls run the three-bf16-term split, which needs no scale.
+  const bool f16x2 = precision == 3 && scale_a && scale_b;
+  if (precision == 3) precision = 0;
   VAE_REQUIRE(M > 0 && N > 0 && K > 0 && M < (1 << 30) && N < (1 << 30) && K < (1 << 30),
               "vae_gemm: bad shape M=%lld N=%lld K=%lld", (long long)M, (long long)N, (long long)K);
   VAE_REQUIRE(A && B && (C || slabs_out), "vae_gemm: null operand");
@@ -1099,6 +1157,8 @@ int gemm_impl(int layout, int precision, int64_t M, int64_t N, int64_t K, const 
   VAE_REQUIRE((n_max_a <= 0 || vae_aligned16(scale_a)) && (n_max_b <= 0 || vae_aligned16(scale_b)),
               "vae_gemm: partial maxima must be 16-byte aligned");
   g.sa = scale_a; g.sb = scale_b; g.na = n_max_a; g.nb = n_max_b;
+  g.stat_m = g.stat_s = nullptr; g.stat_cols = 0;
+  if (stats) stats->slots = 0;
   g.lda = lda; g.ldb = ldb; g.ldc = ldc;
   g.M = (int)M; g.N = (int)N; g.K = (int)K;
   g.accumulate = accumulate;
@@ -1144,6 +1204,17 @@ int gemm_impl(int layout, int precision, int64_t M, int64_t N, int64_t K, const 
   }
   g.vecC = (N % 4 == 0) && vae_aligned16(g.C) && (split > 1 || slabs_out || ldc % 4 == 0);
   dim3 grid(tiles_m * g.tiles_n, split);
+  // softmax statistics ride in the 16-byte-store epilogue of the split kernel: every 32-column block must take it
+  if (stats && stats->m && stats->s && stats->cols > 0 && dma_ok && layout == NT && split == 1 && !slabs_out && !accumulate &&
+      g.vecC && N % 32 == 0 && stats->cols <= N && bm == 128) {   // bm == 128: the tile shapes that carry the registers
+    const int waves_n = bn == 160 ? 1 : (bm == 160 ? 4 : 2);      // WAVES_N of the three tile shapes launched below
+    const int span = bn / waves_n;
+    const int slots = (stats->cols + span - 1) / span;
+    if ((int64_t)slots * M <= stats->capacity) {
+      g.stat_m = stats->m; g.stat_s = stats->s; g.stat_cols = stats->cols;
+      stats->slots = slots;
+    }
+  }
   if (dma_ok) {
     dim3 grid1(tiles_m * g.tiles_n * split);
 #define VAE_DMA_LAUNCH(LAY)                                                                              \
@@ -1274,11 +1345,19 @@ int vae_absmax_partials(const float* X, int64_t rows, int64_t cols, int64_t ld, 
 // vae_gemm / vae_gemm_slabs on two scaled f16 terms, the scales derived in the kernel from the partial maxima of |A|, |B|
 int vae_gemm_f16x2(int layout, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* max_a, int n_max_a,
                    const float* B, int64_t ldb, const float* max_b, int n_max_b, float* C, int64_t ldc, const float* bias,
-                   int accumulate, float* workspace, int64_t workspace_bytes, void* stream, int* slabs_out) {
+                   int accumulate, float* workspace, int64_t workspace_bytes, void* stream, int* slabs_out,
+                   VaeGemmRowStats* stats) {
   VAE_REQUIRE(max_a && max_b && n_max_a > 0 && n_max_b > 0, "vae_gemm_f16x2: operand maxima missing");
   return gemm_impl(layout, 3, M, N, K, A, lda, B, ldb, slabs_out ? nullptr : C, slabs_out ? N : ldc, slabs_out ? nullptr : bias,
                    nullptr, slabs_out ? 0 : accumulate, workspace, workspace_bytes, stream, slabs_out, max_a, max_b, n_max_a,
-                   n_max_b);
+                   n_max_b, stats);
+}
+// vae_gemm that may also leave the softmax statistics of its output rows (see VaeGemmRowStats)
+int vae_gemm_rowstats(int layout, int precision, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B,
+                      int64_t ldb, float* C, int64_t ldc, const float* bias, float* workspace, int64_t workspace_bytes,
+                      VaeGemmRowStats* stats, void* stream) {
+  return gemm_impl(layout, precision, M, N, K, A, lda, B, ldb, C, ldc, bias, nullptr, 0, workspace, workspace_bytes, stream,
+                   nullptr, nullptr, nullptr, 0, 0, stats);
 }
 
 extern "C" int64_t vae_absmax_workspace_bytes(void) { return 1024 * (int64_t)sizeof(float); }

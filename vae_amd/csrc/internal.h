@@ -17,9 +17,27 @@ int vae_step_prologue(const float* w0, int64_t n0, const float* w1, int64_t n1, 
 // vae_gemm (slabs_out == null) / vae_gemm_slabs (slabs_out != null: partial slabs left in the workspace) on two scaled
 // f16 terms per element and three matrix-core products; the power-of-two scales are derived inside the kernel from the
 // n_max_a / n_max_b partial maxima of |A| / |B| that the producers of the operands stored
+// Request for the softmax statistics of the output rows over columns [0, cols) of an NT product (decoder-head logits):
+// when the shape runs the split kernel's 16-byte-store epilogue, the GEMM writes, per row and per wave-wide column span
+// ("slot"), max and sum of exp(v - max) to m / s [slot][M] and sets slots > 0; otherwise slots = 0 and nothing is written
+// (the caller then computes the statistics with its own pass).  capacity: floats available in each of m and s.
+struct VaeGemmRowStats {
+  float* m;
+  float* s;
+  int cols;
+  int64_t capacity;
+  int slots;     // out
+};
 int vae_gemm_f16x2(int layout, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* max_a, int n_max_a,
                    const float* B, int64_t ldb, const float* max_b, int n_max_b, float* C, int64_t ldc, const float* bias,
-                   int accumulate, float* workspace, int64_t workspace_bytes, void* stream, int* slabs_out);
+                   int accumulate, float* workspace, int64_t workspace_bytes, void* stream, int* slabs_out,
+                   VaeGemmRowStats* stats = nullptr);
+int vae_gemm_rowstats(int layout, int precision, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B,
+                      int64_t ldb, float* C, int64_t ldc, const float* bias, float* workspace, int64_t workspace_bytes,
+                      VaeGemmRowStats* stats, void* stream);
+// rowmax[b] / rowsum[b] from the `slots` per-slot statistics a GEMM left (epilogue.hip)
+int vae_softmax_stats_merge(const float* stat_m, const float* stat_s, int slots, int64_t B, float* rowmax, float* rowsum,
+                            void* stream);
 
 // Entries of the partial-maxima arrays the producers below fill (all of them, every call)
 #define VAE_NORM_WAVES 4           /* vae_normalize_rows_ex / vae_gene_dropout_ex: B * 4 entries      */
@@ -48,3 +66,14 @@ int vae_nbzinb_bwd_ex(int x_dtype, int zinb, const float* logit_scale, int64_t l
                       float* dlogit_scale, int64_t ld_ds, float* dlogit_dropout, int64_t ld_dp, float* dlibrary, float* dpx_r,
                       float* dbias_scale, float* dbias_dropout, float* workspace, int64_t workspace_bytes, float* absmax,
                       VaeDeferredColreduce* defer, void* stream);
+
+// vae_nbzinb_fwd_ws (streaming forward) for the step: have_stats != 0 skips the statistics launch (rowmax / rowsum came
+// from the decoder-head GEMM); ll == S == null leaves the per-strip partials ([*strips_out][2][B]) in the workspace for
+// vae_elbo_reduce_parts, which adds them up in strip order while it forms the ELBO scalars (one launch less).
+int vae_nbzinb_fwd_tiled_ex(int x_dtype, int zinb, const float* logit_scale, int64_t ld_s, const float* logit_dropout,
+                            int64_t ld_p, const void* x, int64_t ld_x, const float* library, const float* gene_table, int64_t B,
+                            int64_t G, float* ll, float* rowmax, float* rowsum, float* S, int have_stats, float* workspace,
+                            int64_t workspace_bytes, int* strips_out, void* stream);
+// vae_elbo_reduce whose ll[b] (and S[b]) are first formed from `strips` per-strip partials part[(s*2 + k)*B + b]
+int vae_elbo_reduce_parts(const float* part, int strips, float* ll, float* S, const float* kl_z, const float* kl_l, int64_t B,
+                          float kl_weight, float gene_loss_coeff, float* out5, float* recon, void* stream);

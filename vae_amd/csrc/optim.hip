@@ -72,6 +72,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
     acc = block_sum<4>(acc, red);
     const float total = sqrtf(acc);
     coef = fminf(max_norm / (total + 1e-6f), 1.f);  // torch.nn.utils.clip_grad_norm_
+    if (total != total) coef = total;               // ... whose clamp(max=1) lets a NaN norm through (fminf would drop it)
     if (norm_out && blockIdx.x == 0 && threadIdx.x == 0) norm_out[0] = total;
   }
   const float gs = gscale * coef;

@@ -341,23 +341,42 @@ __global__ void add_inplace_kernel(const float* __restrict__ src, float* __restr
 //   out[3] = gene_loss = out[0] + kl_weight*(mean(kl_l + kl_z)), out[4] = coeff*gene_loss
 // single workgroup, fixed summation order (deterministic).
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void elbo_reduce_kernel(const float* __restrict__ ll, const float* __restrict__ kl_z,
-                                                          const float* __restrict__ kl_l, int B, float kl_weight,
-                                                          float coeff, float* __restrict__ out,
-                                                          float* __restrict__ recon) {
-  __shared__ float red[4];
+// part != null: ll[i] / S[i] are first formed (and stored) from the per-strip partials of the streaming likelihood pass:
+// thread pairs (row, k) with four strips in flight, strip order fixed (deterministic)
+__global__ __launch_bounds__(1024) void elbo_reduce_kernel(float* __restrict__ ll, const float* __restrict__ kl_z,
+                                                           const float* __restrict__ kl_l, int B, float kl_weight,
+                                                           float coeff, float* __restrict__ out,
+                                                           float* __restrict__ recon, const float* __restrict__ part,
+                                                           int strips, float* __restrict__ S) {
+  __shared__ float red[16];
+  if (part) {
+    for (int j = threadIdx.x; j < 2 * B; j += 1024) {
+      const int i = j >> 1, k = j & 1;
+      const float* p = part + (int64_t)k * B + i;
+      const int64_t st = (int64_t)2 * B;
+      float v = 0.f;
+      int s = 0;
+      for (; s + 4 <= strips; s += 4) {
+        const float a = p[s * st], b2 = p[(s + 1) * st], c2 = p[(s + 2) * st], d2 = p[(s + 3) * st];
+        v = (((v + a) + b2) + c2) + d2;
+      }
+      for (; s < strips; ++s) v += p[s * st];
+      (k ? S : ll)[i] = v;
+    }
+    __syncthreads();   // ll written by this (the only) workgroup is read below
+  }
   float a = 0.f, b = 0.f, c = 0.f, d = 0.f;
-  for (int i = threadIdx.x; i < B; i += 256) {
+  for (int i = threadIdx.x; i < B; i += 1024) {
     if (recon) recon[i] = -ll[i];
     a -= ll[i];
     b += kl_z[i];
     c += kl_l[i];
     d += kl_l[i] + kl_z[i];
   }
-  a = block_sum<4>(a, red);
-  b = block_sum<4>(b, red);
-  c = block_sum<4>(c, red);
-  d = block_sum<4>(d, red);
+  a = block_sum<16>(a, red);
+  b = block_sum<16>(b, red);
+  c = block_sum<16>(c, red);
+  d = block_sum<16>(d, red);
   if (threadIdx.x == 0) {
     const float n = (float)B;
     const float gl = a / n + kl_weight * (d / n);
@@ -600,9 +619,18 @@ extern "C" int vae_colsum(const float* in, int64_t ld, int64_t M, int64_t N, flo
 extern "C" int vae_elbo_reduce(const float* ll, const float* kl_z, const float* kl_l, int64_t B, float kl_weight,
                                float gene_loss_coeff, float* out5, float* recon, void* stream) {
   VAE_REQUIRE(ll && kl_z && kl_l && out5 && B > 0, "vae_elbo_reduce: bad arguments");
-  hipLaunchKernelGGL(elbo_reduce_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, ll, kl_z, kl_l, (int)B, kl_weight,
-                     gene_loss_coeff, out5, recon);
+  hipLaunchKernelGGL(elbo_reduce_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, const_cast<float*>(ll), kl_z, kl_l, (int)B,
+                     kl_weight, gene_loss_coeff, out5, recon, (const float*)nullptr, 0, (float*)nullptr);
   VAE_CHECK_LAUNCH("vae_elbo_reduce");
+  return VAE_OK;
+}
+
+int vae_elbo_reduce_parts(const float* part, int strips, float* ll, float* S, const float* kl_z, const float* kl_l, int64_t B,
+                          float kl_weight, float gene_loss_coeff, float* out5, float* recon, void* stream) {
+  VAE_REQUIRE(part && strips > 0 && ll && S && kl_z && kl_l && out5 && B > 0, "vae_elbo_reduce_parts: bad arguments");
+  hipLaunchKernelGGL(elbo_reduce_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, ll, kl_z, kl_l, (int)B, kl_weight,
+                     gene_loss_coeff, out5, recon, part, strips, S);
+  VAE_CHECK_LAUNCH("vae_elbo_reduce_parts");
   return VAE_OK;
 }
 

@@ -8,6 +8,7 @@
 #include "internal.h"
 #include "philox.h"
 
+#include <stdlib.h>
 #include <string.h>
 
 namespace {
@@ -27,6 +28,8 @@ struct Layout {
   int64_t dbet_d, dgam_d, dbet_e, dgam_e;  // per-cell LayerNorm-gradient rows of the fused middle
   int64_t xn_z, mean_z, gene_thr, gene_counts;  // GeneDropout: the z-encoder's own normalised counts (-1: off)
   int64_t amax[8]; int amax_n[8];  // partial maxima of the operands of the two-f16-term GEMMs (AM_*): offset, entries
+  int64_t stat_m, stat_s, stat_cap;   // per-slot softmax statistics the decoder-head GEMM leaves (internal.h)
+  int64_t fwd_part;       // per-strip partials of ll[b] / S_b of the streaming likelihood pass
   int64_t bwd_slabs;      // column-sum slabs of the epilogue backward (kept until the last launch of the backward)
   int64_t scratch;        // split-K slabs (shared, used by one launch at a time)
   int64_t scratch_floats;
@@ -93,6 +96,9 @@ bool make_layout(const vae_step_config& c, Layout* lo) {
   s = maxi(s, vae_gemm_slabs_workspace_bytes(B, H + Hl, G));  // slabs consumed by the fused middle
   s = maxi(s, vae_gemm_slabs_workspace_bytes(B, Hd, NH));
   s = maxi(s, vae_nbzinb_bwd_workspace_bytes(B, G));
+  lo->fwd_part = take(vae_nbzinb_fwd_workspace_bytes(B, G) / 4 + 4);
+  lo->stat_cap = B * ((G + 31) / 32);            // narrowest slot of the GEMM's row statistics: 32 columns
+  lo->stat_m = take(lo->stat_cap); lo->stat_s = take(lo->stat_cap);
   lo->bwd_slabs = take(vae_nbzinb_bwd_workspace_bytes(B, G) / 4 + 4);
   lo->scratch_floats = up4(s / 4 + 4);
   lo->scratch = take(lo->scratch_floats);
@@ -117,15 +123,17 @@ struct Ctx {
   // one of the five gene-sized products: two-f16-term split when the step runs in VAE_FP32_F16X2, else as `gemm`;
   // slabs_out != null leaves split-K slabs in the scratch (no bias) for the fused middle
   int big(int layout, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, int slot_a, const float* Bm, int64_t ldb,
-          int slot_b, float* C, int64_t ldc, const float* bias, int* slabs_out) const {
+          int slot_b, float* C, int64_t ldc, const float* bias, int* slabs_out, VaeGemmRowStats* stats = nullptr) const {
     if (fx())
       return vae_gemm_f16x2(layout, M, N, K, A, lda, am(slot_a), lo.amax_n[slot_a], Bm, ldb, am(slot_b), lo.amax_n[slot_b], C, ldc,
                             bias, 0, ws + lo.scratch,
-                            lo.scratch_floats * 4, st, slabs_out);
+                            lo.scratch_floats * 4, st, slabs_out, stats);
+    // a VAE_FP32_F16X2 step whose shapes are outside the two-f16-term pipeline (fx() false) has no operand maxima:
+    // its gene-sized products run as VAE_FP32 like every other product of the step
+    const int prec = c.precision == VAE_FP32_F16X2 ? VAE_FP32 : c.precision;
     if (slabs_out)
-      return vae_gemm_slabs(layout, c.precision, M, N, K, A, lda, Bm, ldb, ws + lo.scratch, lo.scratch_floats * 4, slabs_out, st);
-    return vae_gemm(layout, c.precision, M, N, K, A, lda, Bm, ldb, C, ldc, bias, nullptr, 0, ws + lo.scratch,
-                    lo.scratch_floats * 4, st);
+      return vae_gemm_slabs(layout, prec, M, N, K, A, lda, Bm, ldb, ws + lo.scratch, lo.scratch_floats * 4, slabs_out, st);
+    return vae_gemm_rowstats(layout, prec, M, N, K, A, lda, Bm, ldb, C, ldc, bias, ws + lo.scratch, lo.scratch_floats * 4, stats, st);
   }
   // nn.Dropout after a hidden LayerNorm (forward: the activation; backward: the gradient arriving there)
   int drop(float* x, int64_t ld, int64_t W, uint32_t site) const {
@@ -133,7 +141,8 @@ struct Ctx {
   }
   int gemm(int layout, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* Bm, int64_t ldb,
            float* C, int64_t ldc, const float* bias, const float* mean, int acc) const {
-    return vae_gemm(layout, fx() ? VAE_FP32 : c.precision, M, N, K, A, lda, Bm, ldb, C, ldc, bias, mean, acc, ws + lo.scratch,
+    return vae_gemm(layout, c.precision == VAE_FP32_F16X2 ? VAE_FP32 : c.precision, M, N, K, A, lda, Bm, ldb, C, ldc, bias, mean, acc,
+                    ws + lo.scratch,
                     lo.scratch_floats * 4, st);
   }
 };
@@ -144,8 +153,8 @@ int check_common(const vae_step_config* cfg, const void* a, const void* b, const
   if (!make_layout(*cfg, lo)) return vae_set_error(VAE_ERR_ARG, "%s: bad configuration", who);
   if (ldx < cfg->G) return vae_set_error(VAE_ERR_ARG, "%s: ldx < G", who);
   if (cfg->x_dtype != VAE_X_F32 && cfg->x_dtype != VAE_X_U8) return vae_set_error(VAE_ERR_ARG, "%s: bad x_dtype", who);
-  if (cfg->G > vae_nbzinb_max_genes())
-    return vae_set_error(VAE_ERR_ARG, "%s: G=%lld exceeds %lld", who, (long long)cfg->G, (long long)vae_nbzinb_max_genes());
+  if (cfg->B >= (1 << 30) || cfg->G >= (1 << 29))
+    return vae_set_error(VAE_ERR_ARG, "%s: B=%lld / G=%lld too large", who, (long long)cfg->B, (long long)cfg->G);
   if (!(cfg->l_var > 0.f)) return vae_set_error(VAE_ERR_ARG, "%s: l_var must be positive", who);
   if (cfg->precision != VAE_FP32 && cfg->precision != VAE_BF16 && cfg->precision != VAE_FP32_F16X2)
     return vae_set_error(VAE_ERR_ARG, "%s: precision must be VAE_FP32, VAE_BF16 or VAE_FP32_F16X2", who);
@@ -274,16 +283,22 @@ extern "C" int vae_elbo_step_forward(const vae_step_config* cfg, const vae_step_
   }
   // decoder heads -> fused softmax / library scale / NB-ZINB / row sum -> ELBO scalars
   if (k.fx() && !vae_mid_supported(c)) TRY(vae_absmax_partials(px, B, Hd, Hd, k.am(AM_PX), stream));
-  TRY(k.big(VAE_NT, B, NH, Hd, px, Hd, AM_PX, p->heads_w, Hd, AM_WHEADS, ws + lo.logits, NH, p->heads_b, nullptr));
+  // ... whose epilogue also leaves the softmax statistics of the scale logits (per row and column span) when the shape
+  // runs the split kernel; a tiny launch merges them.  Otherwise the likelihood pass computes them itself.
+  VaeGemmRowStats rs{ws + lo.stat_m, ws + lo.stat_s, (int)G, lo.stat_cap, 0};
+  static const bool no_gemm_stats = getenv("VAE_NO_GEMM_STATS") != nullptr;   // A/B knob
+  TRY(k.big(VAE_NT, B, NH, Hd, px, Hd, AM_PX, p->heads_w, Hd, AM_WHEADS, ws + lo.logits, NH, p->heads_b, nullptr,
+            no_gemm_stats ? nullptr : &rs));
+  if (rs.slots > 0) TRY(vae_softmax_stats_merge(ws + lo.stat_m, ws + lo.stat_s, rs.slots, B, ws + lo.rowmax, ws + lo.rowsum, stream));
   if (!k.fx()) TRY(vae_gene_table(p->px_r, G, ws + lo.table, stream));
-  if (c.x_dtype == VAE_X_U8)
-    TRY(vae_nbzinb_fwd_u8(c.zinb, ws + lo.logits, NH, c.zinb ? ws + lo.logits + G : nullptr, NH, (const uint8_t*)xv, ldx,
-                          ws + lo.library, ws + lo.table, B, G, ws + lo.ll, ws + lo.rowmax, ws + lo.rowsum, ws + lo.S, stream));
-  else
-    TRY(vae_nbzinb_fwd(c.zinb, ws + lo.logits, NH, c.zinb ? ws + lo.logits + G : nullptr, NH, (const float*)xv, ldx,
-                       ws + lo.library, ws + lo.table, B, G, ws + lo.ll, ws + lo.rowmax, ws + lo.rowsum, ws + lo.S, stream));
-  TRY(vae_elbo_reduce(ws + lo.ll, ws + lo.kl_z, ws + lo.kl_l, B, c.kl_weight, c.gene_loss_coeff, ws + lo.scalars,
-                      ws + lo.recon, stream));
+  // streaming likelihood pass: row statistics, then (gene strip x cell chunk) tiles; its per-strip partial sums are added
+  // up by the ELBO reduction
+  int strips = 0;
+  TRY(vae_nbzinb_fwd_tiled_ex(c.x_dtype, c.zinb, ws + lo.logits, NH, c.zinb ? ws + lo.logits + G : nullptr, NH, xv, ldx,
+                              ws + lo.library, ws + lo.table, B, G, nullptr, ws + lo.rowmax, ws + lo.rowsum, nullptr, rs.slots > 0,
+                              ws + lo.fwd_part, vae_nbzinb_fwd_workspace_bytes(B, G), &strips, stream));
+  TRY(vae_elbo_reduce_parts(ws + lo.fwd_part, strips, ws + lo.ll, ws + lo.S, ws + lo.kl_z, ws + lo.kl_l, B, c.kl_weight,
+                            c.gene_loss_coeff, ws + lo.scalars, ws + lo.recon, stream));
   return VAE_OK;
 }
 
@@ -304,6 +319,14 @@ extern "C" int vae_elbo_step_backward(const vae_step_config* cfg, const vae_step
                                       const void* xv, int64_t ldx, const float* eps_z, const float* eps_l,
                                       int use_dz_extra, float* ws, int64_t ws_bytes, void* event_heads_ready,
                                       void* stream) {
+  return vae_elbo_step_backward_events(cfg, p, g, xv, ldx, eps_z, eps_l, use_dz_extra, ws, ws_bytes, event_heads_ready, nullptr,
+                                       stream);
+}
+
+extern "C" int vae_elbo_step_backward_events(const vae_step_config* cfg, const vae_step_tensors* p, const vae_step_tensors* g,
+                                             const void* xv, int64_t ldx, const float* eps_z, const float* eps_l,
+                                             int use_dz_extra, float* ws, int64_t ws_bytes, void* event_heads_ready,
+                                             void* event_small_ready, void* stream) {
   Layout lo;
   TRY(check_common(cfg, p, g, xv, ldx, eps_z, eps_l, ws, ws_bytes, &lo, "vae_elbo_step_backward"));
   const vae_step_config& c = *cfg;
@@ -325,7 +348,12 @@ extern "C" int vae_elbo_step_backward(const vae_step_config* cfg, const vae_step
                         c.zinb ? g->heads_b + G : nullptr, ws + lo.bwd_slabs, vae_nbzinb_bwd_workspace_bytes(B, G),
                         k.am(AM_DLOGITS), vae_mid_supported(c) ? &cr : nullptr, stream));
   const float* px = ws + lo.dec_h[c.n_layers - 1];
-  TRY(k.big(VAE_TN, NH, Hd, B, logits, NH, AM_DLOGITS, px, Hd, AM_PX, g->heads_w, Hd, nullptr, nullptr));  // dW = dlogits^T px
+  // dW = dlogits^T px.  In VAE_FP32_F16X2 this ONE product keeps the exact three-bf16-term split: the magnitude of a gene's
+  // column of dlogits follows the gene's softmax mass, which spans > 2^20 across genes, and ONE power-of-two scale for the
+  // whole operand (the two-f16-term scheme) would leave the weight-gradient ROWS of quiet genes with few correct bits --
+  // invisible in a tensor-wide norm, but AdamW normalises per element (tests/test_configs_gpu.py, row accuracy).  The
+  // dgrad below sums over genes, where the quiet ones do not matter, and every other operand of the step is uniform.
+  TRY(k.gemm(VAE_TN, NH, Hd, B, logits, NH, px, Hd, g->heads_w, Hd, nullptr, nullptr, 0));
   if (event_heads_ready) {
     if (hipEventRecord((hipEvent_t)event_heads_ready, (hipStream_t)stream) != hipSuccess)
       return vae_set_error(VAE_ERR_LAUNCH, "vae_elbo_step_backward: hipEventRecord failed");
@@ -408,6 +436,11 @@ extern "C" int vae_elbo_step_backward(const vae_step_config* cfg, const vae_step
     if (k.fx()) {
       TRY(vae_absmax_partials(ws + lo.dpre_enc0, B, HE, HE, k.am(AM_DPRE), stream));
     }
+  }
+  // every gradient except the first-layer encoder weights is final from here on (second all-reduce bucket)
+  if (event_small_ready) {
+    if (hipEventRecord((hipEvent_t)event_small_ready, (hipStream_t)stream) != hipSuccess)
+      return vae_set_error(VAE_ERR_LAUNCH, "vae_elbo_step_backward: hipEventRecord failed");
   }
   if (c.input_dropout_rate > 0.f) {  // GeneDropout: each encoder's weight gradient over its own input
     TRY(k.big(VAE_TN, H, G, B, ws + lo.dpre_enc0, HE, AM_DPRE, ws + lo.xn_z, lo.ld_xn, AM_XNZ, g->enc_w0, G, nullptr, nullptr));

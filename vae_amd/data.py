@@ -115,11 +115,45 @@ class CountStore:
         return ops.gather_counts(self.dev, cell_rows, gene_idx, dtype=dtype)
 
 
+class _ArraysOnlyUnpickler(pickle.Unpickler):
+    """Unpickler for the study's metadata file (data.py:41: a ``{"obs": {column: array}, "var": {...}}`` dict).
+    Unpickling a file normally runs whatever callables it names; this one resolves ONLY what a dict of numpy arrays
+    and plain Python containers needs, so a crafted file cannot execute code -- anything else raises."""
+
+    _ALLOWED = {
+        ("numpy.core.multiarray", "_reconstruct"), ("numpy._core.multiarray", "_reconstruct"),
+        ("numpy.core.multiarray", "scalar"), ("numpy._core.multiarray", "scalar"),
+        ("numpy", "ndarray"), ("numpy", "dtype"),
+        ("collections", "OrderedDict"),
+        ("builtins", "dict"), ("builtins", "list"), ("builtins", "tuple"), ("builtins", "set"), ("builtins", "frozenset"),
+        ("builtins", "str"), ("builtins", "bytes"), ("builtins", "int"), ("builtins", "float"), ("builtins", "bool"),
+        ("builtins", "complex"), ("builtins", "slice"), ("builtins", "range"),
+    }
+
+    def find_class(self, module, name):
+        if (module, name) in self._ALLOWED:
+            return super().find_class(module, name)
+        raise pickle.UnpicklingError(
+            f"vae_amd.data: the metadata file names {module}.{name}; only numpy arrays and plain containers are loaded "
+            "(pass the dict itself as `metadata=`, or save it with numpy.savez)")
+
+
 def _load_metadata(metadata_path, metadata):
+    """The ``{"obs": .., "var": ..}`` dict itself, a ``.npz`` written by ``numpy.savez(path, **{"obs/<col>": a, "var/<col>": a})``
+    (loaded with ``allow_pickle=False``), or the reference's pickle (data.py:41) through an arrays-only unpickler."""
     if metadata is not None:
         return metadata
-    with open(metadata_path, "rb") as f:      # the caller's own file, as the reference reads it (data.py:41)
-        return pickle.load(f)
+    if str(metadata_path).endswith(".npz"):
+        out: Dict[str, Dict[str, Any]] = {"obs": {}, "var": {}}
+        with np.load(metadata_path, allow_pickle=False) as z:
+            for k in z.files:
+                table, _, col = k.partition("/")
+                if table not in out or not col:
+                    raise ValueError(f"vae_amd.data: unexpected key {k!r} in {metadata_path} (want obs/<column>, var/<column>)")
+                out[table][col] = z[k]
+        return out
+    with open(metadata_path, "rb") as f:
+        return _ArraysOnlyUnpickler(f).load()
 
 
 def _convert_apoe(obs):
@@ -470,9 +504,12 @@ class DataModule:
                                              training=False, **common)
         self.n_genes = self.train_dataset.n_genes
 
-    def train_dataloader(self):
-        return _Loader(self.train_dataset, BatchSampler(RandomSampler(self.train_dataset), batch_size=self.train_dataset.batch_size,
-                                                        drop_last=True))
+    def train_dataloader(self, generator: Optional[torch.Generator] = None):
+        """``generator``: the sampler's own source of randomness (default: torch's global generator, as the
+        reference).  Data-parallel ranks pass one seeded per rank, so that every rank draws its own cells --
+        what Lightning's DDP does with a per-rank sampler shard (train.py:57)."""
+        return _Loader(self.train_dataset, BatchSampler(RandomSampler(self.train_dataset, generator=generator),
+                                                        batch_size=self.train_dataset.batch_size, drop_last=True))
 
     def val_dataloader(self):
         return _Loader(self.val_dataset, BatchSampler(SequentialSampler(self.val_dataset), batch_size=self.val_dataset.batch_size,

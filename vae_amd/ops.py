@@ -310,11 +310,15 @@ def gene_table(px_r: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.
 
 
 def nbzinb_fwd(zinb: bool, logit_scale: torch.Tensor, logit_dropout: Optional[torch.Tensor], x: torch.Tensor,
-               library: torch.Tensor, table: torch.Tensor):
+               library: torch.Tensor, table: torch.Tensor, streaming: bool = False, out: Optional[torch.Tensor] = None,
+               have_stats: bool = False, partials_only: bool = False):
     """Fused softmax + library scale + NB/ZINB log-likelihood + row sum.
 
     -> (ll (B,), rowmax (B,), rowsum (B,), S (B,)); recon = -ll.  The last three are what
-    ``nbzinb_bwd`` needs."""
+    ``nbzinb_bwd`` needs.  ``streaming``: the (gene strip x cell chunk) form the fused step runs
+    (``vae_nbzinb_fwd_ws``) instead of the one-workgroup-per-cell kernel.  ``out``: a (4, B) buffer for the four
+    results; with ``have_stats`` its rows 1 and 2 already hold rowmax / rowsum and the statistics launch is skipped;
+    ``partials_only`` leaves the sum over gene strips to the caller (ll / S are then not written)."""
     lib = _lib.load()
     _chk2d(logit_scale, "logit_scale")
     u8 = _chk_counts(x)
@@ -328,7 +332,20 @@ def nbzinb_fwd(zinb: bool, logit_scale: torch.Tensor, logit_dropout: Optional[to
     _chk1d(library, B, "library")
     if table.shape != (lib.vae_gene_table_rows(), G) or not table.is_contiguous():
         raise ValueError("vae_amd.ops.nbzinb_fwd: table must be the gene table made by ops.gene_table")
-    o = torch.empty(4, B, dtype=torch.float32, device=x.device)
+    o = out if out is not None else torch.empty(4, B, dtype=torch.float32, device=x.device)
+    if o.shape != (4, B) or o.dtype != torch.float32 or not o.is_cuda or not o.is_contiguous():
+        raise ValueError("vae_amd.ops.nbzinb_fwd: out must be a contiguous float32 GPU tensor of shape (4, B)")
+    if have_stats and (out is None or not streaming):
+        raise ValueError("vae_amd.ops.nbzinb_fwd: have_stats needs streaming=True and out= holding rowmax / rowsum")
+    if streaming:
+        nbytes = lib.vae_nbzinb_fwd_workspace_bytes(B, G)
+        ws = workspace(nbytes, x.device)
+        _lib.check(lib.vae_nbzinb_fwd_ws(int(zinb), _p(logit_scale), _ld(logit_scale), _p(logit_dropout if zinb else None),
+                                         _ld(logit_dropout) if zinb else 0, _p(x), _lib.X_U8 if u8 else _lib.X_F32, _ld(x),
+                                         _p(library), _p(table), B, G, None if partials_only else _p(o[0]), _p(o[1]), _p(o[2]),
+                                         None if partials_only else _p(o[3]), int(have_stats), _p(ws), nbytes, _stream()),
+                   "nbzinb_fwd_ws")
+        return o[0], o[1], o[2], o[3]
     _lib.check((lib.vae_nbzinb_fwd_u8 if u8 else lib.vae_nbzinb_fwd)(int(zinb), _p(logit_scale), _ld(logit_scale), _p(logit_dropout if zinb else None),
                                   _ld(logit_dropout) if zinb else 0, _p(x), _ld(x), _p(library), _p(table), B, G,
                                   _p(o[0]), _p(o[1]), _p(o[2]), _p(o[3]), _stream()), "nbzinb_fwd")

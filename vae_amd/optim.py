@@ -57,10 +57,21 @@ class FusedAdamW:
                 ranges[-1] = (ranges[-1][0], off + n, wd)
             else:
                 ranges.append((off, off + n, wd))
-        # padding between groups (<= 3 floats) is zero in every arena: bridge equal-decay neighbours
+        # alignment padding between groups (<= 3 floats, zero in every arena) is bridged between equal-decay neighbours --
+        # but only when the gap really is padding: a skipped / gradient-less parameter of <= 3 elements sitting there
+        # must stay untouched, as torch leaves grad=None parameters alone
+        def is_padding(lo: int, hi: int) -> bool:
+            for off, shape in arena.offsets.values():
+                n = 1
+                for d in shape:
+                    n *= d
+                if off < hi and off + n > lo:
+                    return False
+            return True
+
         merged: List[Tuple[int, int, float]] = []
         for r in ranges:
-            if merged and r[0] - merged[-1][1] <= 3 and merged[-1][2] == r[2]:
+            if merged and r[0] - merged[-1][1] <= 3 and merged[-1][2] == r[2] and is_padding(merged[-1][1], r[0]):
                 merged[-1] = (merged[-1][0], r[1], r[2])
             else:
                 merged.append(r)

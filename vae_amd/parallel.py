@@ -1,5 +1,5 @@
 """Data-parallel gradient averaging for the fused step: one process per GPU, RCCL over xGMI
-(``torch.distributed`` backend "nccl"; "gloo" on CPU for tests).
+(``torch.distributed`` backend "nccl"; "gloo" on CPU for tests and for rehearsals on one GPU).
 
 Semantics = the reference's DDP (train.py:57): every rank computes the mean loss over ITS
 cells, gradients are summed over ranks and divided by the world size.  Parameters the loss
@@ -7,19 +7,36 @@ never reaches (px_r_decoder.*, px_dropout_decoder.* under NB) are statically exc
 arena keeps them past ``used_end`` -- which replaces ``find_unused_parameters=True``.
 
 The gradient arena is already one flat buffer, so buckets are plain slices: no flatten /
-unflatten copies.  Buckets are reduced on a side stream as soon as the kernels that write
-them have been enqueued (the fused step calls ``bucket_ready``), so the big decoder-head
-bucket travels while the encoder backward still computes.  xGMI is point-to-point, so few,
-large messages are preferred (default: 2-3 buckets of tens of MB).
+unflatten copies.  Three buckets, in the order the backward finishes them:
+
+  ``dec_heads``  decoder-head weights (2G x Hd: 41 MB at 20k genes)  -- final after the first wgrad GEMM
+  ``small``      every other tensor except the first-layer encoder weights (hidden layers, heads,
+                 biases, LayerNorm, px_r, cell heads: < 1 MB)          -- final before the last GEMM
+  ``enc_w0``     [z_encoder ; l_encoder] first-layer weights ((H+Hl) x G: 31 MB) -- the last kernel
+
+Each bucket is reduced on a side stream as soon as a HIP event recorded by the native backward
+(``vae_elbo_step_backward_events``) says its gradients are final, so the 41 MB bucket travels while the
+rest of the backward computes and only the last bucket is exposed.  xGMI is point-to-point, so few,
+large messages are preferred over many small ones.
+
+Backends
+  * nccl (RCCL): ``all_reduce(AVG)`` of the bucket slice in place, enqueued on the side stream.
+  * gloo with GPU gradients (rehearsal on fewer GPUs than ranks): the bucket is copied to a pinned
+    host buffer on the side stream, reduced on the host in ``finish()`` and copied back -- gloo never
+    sees a device tensor (its own CUDA path takes streams from torch's pool for every collective;
+    see DESIGN.md §6 for what that did on one shared GPU).
+  * gloo with CPU gradients (unit tests): in place.
 """
 from __future__ import annotations
 
-from typing import List, Optional, Tuple
+from typing import Dict, List, Optional, Tuple
 
 import torch
 import torch.distributed as dist
 
-from .arena import ParamArena
+from .arena import ParamArena, _enc
+
+BUCKET_ORDER = ("dec_heads", "small", "enc_w0")
 
 
 class GradAllReducer:
@@ -31,18 +48,36 @@ class GradAllReducer:
         self.payload = payload
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.on_gpu = arena.flat_grad.is_cuda
+        backend = dist.get_backend(group) if dist.is_initialized() else None
+        self.host_staged = self.on_gpu and self.world > 1 and backend != "nccl"
         # RCCL averages in the collective itself (ReduceOp.AVG); gloo has no AVG: sum, then scale
-        self.avg_in_collective = (self.world > 1 and self.on_gpu and payload == "fp32"
-                                  and dist.get_backend(group) == "nccl")
+        self.avg_in_collective = self.world > 1 and self.on_gpu and backend == "nccl"
         self.comm_stream = torch.cuda.Stream(device=arena.device, priority=-1) if self.on_gpu else None
-        self._pending: List[Tuple[torch.Tensor, Optional[torch.Tensor], object]] = []
-        # bucket boundaries (element offsets into flat_grad): decoder-head weights | everything else.
-        # Under NB the dropout-head weights have no gradient and fall between the two ranges.
+        self._pending: List[tuple] = []
+        # bucket boundaries (element offsets into flat_grad).  Under NB the dropout-head weights have no
+        # gradient and fall between "dec_heads" and "small".
         ws, wp = "decoder.px_scale_decoder.0.weight", "decoder.px_dropout_decoder.weight"
         lo = arena.offsets[ws][0]
         hi = lo + arena.p(ws).numel() + (arena.p(wp).numel() if arena.likelihood == "zinb" else 0)
         after = arena.offsets[wp][0] + arena.p(wp).numel()
-        self.buckets = {"dec_heads": [(lo, hi)], "rest": [(0, lo), (after, arena.used_end)]}
+        e0 = arena.offsets[_enc("z_encoder", 0, "w")][0]
+        if e0 != 0 or lo < e0:
+            raise RuntimeError("GradAllReducer: unexpected arena layout (encoder weights must come first)")
+        self.buckets: Dict[str, List[Tuple[int, int]]] = {
+            "dec_heads": [(lo, hi)], "small": [(after, arena.used_end)], "enc_w0": [(0, lo)]}
+        # wire / staging buffers are allocated once (no allocation in the step loop)
+        self._wire: Dict[Tuple[int, int], torch.Tensor] = {}
+        self._host: Dict[Tuple[int, int], torch.Tensor] = {}
+        wire_dtype = torch.bfloat16 if payload == "bf16" else torch.float32
+        for spans in self.buckets.values():
+            for span in spans:
+                n = span[1] - span[0]
+                if n <= 0 or self.world == 1:
+                    continue
+                if payload == "bf16":
+                    self._wire[span] = torch.empty(n, dtype=torch.bfloat16, device=arena.device)
+                if self.host_staged:
+                    self._host[span] = torch.empty(n, dtype=wire_dtype).pin_memory()
 
     # -- called by the step right after the kernels writing a bucket were enqueued -----------
     def bucket_ready(self, tag: str, after_event=None) -> None:
@@ -50,30 +85,39 @@ class GradAllReducer:
         step) at the point of the compute stream where the bucket became final; default = now."""
         if self.world == 1:
             return
-        for lo, hi in self.buckets[tag]:
+        for span in self.buckets[tag]:
+            lo, hi = span
             if hi <= lo:
                 continue
             buf = self.arena.flat_grad[lo:hi]
-            if self.on_gpu:
-                ev = after_event
-                if ev is None:
-                    ev = torch.cuda.Event()
-                    ev.record(torch.cuda.current_stream())
-                with torch.cuda.stream(self.comm_stream):
-                    self.comm_stream.wait_event(ev)
-                    self._launch(buf)
-            else:
-                self._launch(buf)
+            if not self.on_gpu:
+                self._launch_cpu(buf)
+                continue
+            ev = after_event
+            if ev is None:
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream())
+            with torch.cuda.stream(self.comm_stream):
+                self.comm_stream.wait_event(ev)
+                wire = buf
+                if self.payload == "bf16":
+                    wire = self._wire[span]
+                    wire.copy_(buf)
+                if self.host_staged:
+                    host = self._host[span]
+                    host.copy_(wire, non_blocking=True)
+                    landed = torch.cuda.Event()
+                    landed.record(self.comm_stream)
+                    self._pending.append((buf, wire, host, landed))
+                else:
+                    op = dist.ReduceOp.AVG if self.payload == "fp32" else dist.ReduceOp.SUM
+                    work = dist.all_reduce(wire, op=op, group=self.group, async_op=True)
+                    self._pending.append((buf, wire, None, work))
 
-    def _launch(self, buf: torch.Tensor) -> None:
-        if self.payload == "bf16":
-            wire = buf.to(torch.bfloat16)
-            work = dist.all_reduce(wire, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-            self._pending.append((buf, wire, work))
-        else:
-            op = dist.ReduceOp.AVG if self.avg_in_collective else dist.ReduceOp.SUM
-            work = dist.all_reduce(buf, op=op, group=self.group, async_op=True)
-            self._pending.append((buf, None, work))
+    def _launch_cpu(self, buf: torch.Tensor) -> None:
+        wire = buf.to(torch.bfloat16) if self.payload == "bf16" else buf
+        work = dist.all_reduce(wire, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self._pending.append((buf, wire, None, work))
 
     def finish(self) -> None:
         """Wait for every bucket, apply the 1/world averaging; the compute stream then owns the grads."""
@@ -82,11 +126,19 @@ class GradAllReducer:
         scale = 1.0 / self.world
         ctx = torch.cuda.stream(self.comm_stream) if self.on_gpu else _Null()
         with ctx:
-            for buf, wire, work in self._pending:
-                work.wait()
-                if wire is not None:
+            for buf, wire, host, handle in self._pending:
+                if host is not None:               # gloo rehearsal on the GPU: host round trip
+                    handle.synchronize()           # the device -> host copy has landed
+                    dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
+                    wire.copy_(host, non_blocking=True)
+                    if wire is not buf:
+                        buf.copy_(wire)
+                    buf.mul_(scale)
+                    continue
+                handle.wait()
+                if wire is not buf:
                     buf.copy_(wire)
-                if not (self.avg_in_collective and wire is None):
+                if not (self.avg_in_collective and wire is buf):
                     buf.mul_(scale)
         self._pending.clear()
         if self.on_gpu:
@@ -104,4 +156,9 @@ class _Null:
 def broadcast_parameters(arena: ParamArena, src: int = 0, group=None) -> None:
     """Make every rank start from rank ``src``'s parameters (one flat broadcast)."""
     if dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.broadcast(arena.flat, src=src, group=group)
+        if arena.flat.is_cuda and dist.get_backend(group) != "nccl":   # rehearsal: keep gloo away from device tensors
+            host = arena.flat.cpu()
+            dist.broadcast(host, src=src, group=group)
+            arena.flat.copy_(host)
+        else:
+            dist.broadcast(arena.flat, src=src, group=group)

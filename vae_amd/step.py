@@ -126,7 +126,7 @@ class ElboStep:
         self.params = _tensors(a.p, a.pcat, self.n_layers, self.zinb)
         self.grads = _tensors(a.g, a.gcat, self.n_layers, self.zinb)
         self._plans: Dict[int, tuple] = {}
-        self._ev_heads = None
+        self._ev_heads = self._ev_small = None
         self._zero = None
         self._last_fwd = None
 
@@ -239,19 +239,25 @@ class ElboStep:
             return out
         self._last_fwd = None   # the backward overwrites the logits in place
 
-        ev = None
-        if reducer is not None and reducer.world > 1 and not os.environ.get("VAE_NO_NATIVE_EVENT"):
+        # Data parallel: the native backward records two HIP events on the compute stream -- decoder-head weight
+        # gradients final / everything but the first-layer encoder weights final -- and the reducer's side stream
+        # waits for them, so the buckets travel while the rest of the backward computes (parallel.py).
+        ev_heads = ev_small = None
+        if reducer is not None and reducer.world > 1 and reducer.on_gpu and not os.environ.get("VAE_NO_NATIVE_EVENT"):
             if self._ev_heads is None:
-                self._ev_heads = torch.cuda.Event()
-                self._ev_heads.record()  # materialises the hipEvent_t handle
-            ev = C.c_void_p(self._ev_heads.cuda_event)
-        rc = self.lib.vae_elbo_step_backward(C.byref(cfg), C.byref(self.params), C.byref(self.grads), x.data_ptr(), ldx,
-                                             eps_z.data_ptr(), eps_l.data_ptr(), use_extra, ws.data_ptr(), nbytes, ev,
-                                             stream)
+                self._ev_heads, self._ev_small = torch.cuda.Event(), torch.cuda.Event()
+                self._ev_heads.record()   # materialises the hipEvent_t handles (torch creates them lazily)
+                self._ev_small.record()
+            ev_heads, ev_small = self._ev_heads, self._ev_small
+        rc = self.lib.vae_elbo_step_backward_events(
+            C.byref(cfg), C.byref(self.params), C.byref(self.grads), x.data_ptr(), ldx, eps_z.data_ptr(), eps_l.data_ptr(),
+            use_extra, ws.data_ptr(), nbytes, C.c_void_p(ev_heads.cuda_event) if ev_heads is not None else None,
+            C.c_void_p(ev_small.cuda_event) if ev_small is not None else None, stream)
         _lib.check(rc, "elbo_step_backward")
         if reducer is not None:
-            reducer.bucket_ready("dec_heads", after_event=self._ev_heads if ev is not None else None)
-            reducer.bucket_ready("rest")
+            reducer.bucket_ready("dec_heads", after_event=ev_heads)
+            reducer.bucket_ready("small", after_event=ev_small)
+            reducer.bucket_ready("enc_w0")
         return out
 
     # ------------------------------------------------------------------------------------

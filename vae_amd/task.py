@@ -96,6 +96,7 @@ class LitVAE(nn.Module):
         self.logged: Dict[str, float] = {}
         self._arena: Optional[ParamArena] = None
         self._fused: Optional[ElboStep] = None
+        self._fused_val: Optional[ElboStep] = None
         self._l1 = None
         self._create_results_dict()
         if use_gdro:
@@ -256,16 +257,19 @@ class LitVAE(nn.Module):
             self.attach_arena()
         if self.library_mean is None or self.library_var is None:
             raise ValueError("fused step needs the library prior constants (library_mean / library_var)")
-        if self._fused is None or self._fused.kl_weight != self.kl_weight:
-            self._fused = ElboStep(self._arena, l_mean=float(self.library_mean), l_var=float(self.library_var),
-                                   kl_weight=self.kl_weight, gene_loss_coeff=self.gene_loss_coeff,
-                                   precision=self.precision)
+        # validation has its OWN step object (no dropout; own workspace): rebuilding the training one here would make
+        # the next training step rebuild it again and reallocate its workspace
+        if self._fused_val is None:
+            self._fused_val = ElboStep(self._arena, l_mean=float(self.library_mean), l_var=float(self.library_var),
+                                       kl_weight=self.kl_weight, gene_loss_coeff=self.gene_loss_coeff,
+                                       precision=self.precision)
         gene_vals = batch[0]
         B, L = gene_vals.shape[0], self.network.n_latent
         if eps_z is None:
             eps_z = torch.empty(B, L, device=gene_vals.device).normal_()
             eps_l = torch.empty(B, 1, device=gene_vals.device).normal_()
-        out = self._fused.infer(gene_vals, eps_z, eps_l, want_px_rate=self.save_gene_vals)
+        self._fused_val.kl_weight = self.kl_weight      # KL warm-up: a field of the step's config, not a new step
+        out = self._fused_val.infer(gene_vals, eps_z, eps_l, want_px_rate=self.save_gene_vals)
         self.log("recon_loss_val", out["recon_mean"])
         self.log("kl_z_val", out["scalars"][1])
         self._record_validation(batch, out["qz_m"], out.get("px_rate"))
@@ -298,7 +302,7 @@ class LitVAE(nn.Module):
             p.data = arena.p(k)
             p.grad = None if k in arena.no_grad else arena.g(k)
         self._arena = arena
-        self._fused = None
+        self._fused = self._fused_val = None
         self._l1 = None
         return arena
 
@@ -324,8 +328,7 @@ class LitVAE(nn.Module):
         p_in = float(gdrop.p) if self.training and gdrop.p >= 1e-6 else 0.0
         if getattr(self.network.l_encoder.drop, "p", 0.0) >= 1e-6:
             raise NotImplementedError("fused step: the library encoder is built without input dropout (networks.py:215-222)")
-        if self._fused is None or self._fused.kl_weight != self.kl_weight or self._fused.dropout_rate != p_drop or \
-                self._fused.input_dropout_rate != p_in:
+        if self._fused is None or self._fused.dropout_rate != p_drop or self._fused.input_dropout_rate != p_in:
             running = None
             if p_in > 0:   # share GeneDropout.running_non_zero_means with the module: one state for both paths
                 G = self.network.px_r.shape[0]
@@ -355,6 +358,7 @@ class LitVAE(nn.Module):
                 self._l1 = L1Penalty(self._arena)
             if reducer is not None and reducer.world > 1:
                 raise NotImplementedError("fused step: l1_lambda with a gradient reducer (add the penalty after finish())")
+        self._fused.kl_weight = self.kl_weight          # KL warm-up (task.py:213-220): a field of the step's config
         out = self._fused.run(gene_vals, eps_z, eps_l, cell_head_fn=fn, loss_scale=loss_scale, reducer=reducer)
         if self.l1_lambda > 0:
             l1 = self._l1.apply(self.l1_lambda * loss_scale)

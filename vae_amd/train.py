@@ -23,6 +23,13 @@ from .parallel import GradAllReducer, broadcast_parameters
 from .task import LitVAE
 
 
+def rank_seed(base: int = 43) -> int:
+    """Seed of a rank's batch sampler: ``base`` (pl.seed_everything(43), train.py:20) on one process, ``base + rank``
+    under torch.distributed -- every rank must draw its OWN cells (Lightning's DDP shards the sampler per rank,
+    train.py:57); with one seed for all, N GPUs would average N copies of the same gradient."""
+    return base + (dist.get_rank() if dist.is_initialized() else 0)
+
+
 def library_size_stats(counts: torch.Tensor, n: int = 200_000):
     """mean / variance of log1p(row sums) over at most n cells (data.py:233-244)."""
     lib = torch.log1p(counts[:n].sum(dim=1).double())
@@ -77,9 +84,11 @@ def main(train_idx: List[int], test_idx: List[int], cell_class: str, additional_
         opt_cfg = task.configure_optimizers()
         opt, sched = opt_cfg["optimizer"], opt_cfg["lr_scheduler"]["scheduler"]
     n = x_all.shape[0]
-    gen = torch.Generator(device=device).manual_seed(43)
+    gen = torch.Generator(device=device).manual_seed(rank_seed(43))
     params = [p for p in network.parameters() if p.grad is not None]
+    steps_per_epoch = max(1, -(-n // batch_size))
     for step in range(max_steps):
+        task.current_epoch = step // steps_per_epoch      # Lightning advances it per pass over the data (task.py:213-220)
         idx = torch.randint(0, n, (batch_size,), generator=gen, device=device)
         batch = (x_all[idx], None if not use_heads else cell_prop_vals[idx], None if not use_heads else cell_mask[idx],
                  None, None, idx, None, None)
@@ -121,7 +130,8 @@ def _main_datamodule(dm, model_cfg, task_cfg, trainer_cfg, max_steps, log_every,
     task.train()
     if dist.is_initialized():
         task.dropout_seed += 0x9E3779B97F4A7C15 * dist.get_rank() % (2 ** 63)
-        np.random.seed(43 + dist.get_rank())       # every rank draws its own batches
+        np.random.seed(rank_seed(43))              # every rank draws its own balanced batches / mixup partners
+    sampler_gen = torch.Generator().manual_seed(rank_seed(43))   # ... and its own RandomSampler permutations
     arena = task.attach_arena(ds.device)
     broadcast_parameters(arena)
     reducer = GradAllReducer(arena) if dist.is_initialized() and dist.get_world_size() > 1 else None
@@ -139,7 +149,7 @@ def _main_datamodule(dm, model_cfg, task_cfg, trainer_cfg, max_steps, log_every,
     step = 0
     while step < max_steps:
         n_before = step
-        for batch in dm.train_dataloader():
+        for batch in dm.train_dataloader(generator=sampler_gen):
             out = task.training_step_fused(batch, reducer=reducer)
             if reducer is not None:
                 reducer.finish()
@@ -154,6 +164,7 @@ def _main_datamodule(dm, model_cfg, task_cfg, trainer_cfg, max_steps, log_every,
             step += 1
             if step >= max_steps:
                 break
+        task.current_epoch += 1                      # one pass over the train loader = one epoch (task.py:213-220)
         if step == n_before:
             raise ValueError("vae_amd.train.main: the training loader yields no batch (fewer cells than one batch)")
     return task
