@@ -59,6 +59,17 @@ int vae_gemm(int layout, int precision, int64_t M, int64_t N, int64_t K, const f
              int64_t ldb, float* C, int64_t ldc, const float* bias, const float* x_mean, int accumulate,
              float* workspace, int64_t workspace_bytes, void* stream);
 
+/* vae_gemm for callers that cannot allocate device memory or bring a workspace (code under HIP graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc).  NO counterpart in the reference.  Same arguments and results (bit
+ * for bit) as vae_gemm without the workspace pair: the split-K slabs go to a static device array of
+ * vae_gemm_noalloc_max_bytes() = 40 MiB that every GPU the library runs on holds until the process ends; shapes whose
+ * vae_gemm_workspace_bytes exceeds it are rejected with VAE_ERR_ARG.  Calls no hipMalloc / hipFree.  All calls on one
+ * GPU share that GPU's array: calls that overlap on one GPU (different streams, or threads) race -- serialise them. */
+int64_t vae_gemm_noalloc_max_bytes(void);
+int vae_gemm_noalloc(int layout, int precision, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
+                     const float* B, int64_t ldb, float* C, int64_t ldc, const float* bias, const float* x_mean,
+                     int accumulate, void* stream);
+
 /* The same product left as *n_slabs partial (M,N) slabs (row stride N, slab stride M*N) in the
  * workspace: no reduce pass, no bias.  For a consumer that sums the split-K slabs while it reads
  * them (the fused encoder-tail / decoder-head kernels of vae_elbo_step_*).                       */

@@ -24,6 +24,8 @@
 
 #include <stdlib.h>
 
+#include <mutex>
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
@@ -1397,6 +1399,56 @@ extern "C" int vae_gemm(int layout, int precision, int64_t M, int64_t N, int64_t
                         int accumulate, float* workspace, int64_t workspace_bytes, void* stream) {
   return gemm_impl(layout, precision, M, N, K, A, lda, B, ldb, C, ldc, bias, x_mean, accumulate, workspace,
                    workspace_bytes, stream, nullptr);
+}
+
+// ---- vae_gemm for callers that cannot allocate (include/vae_amd.h) --------------------------------------------------
+// The split-K slabs live in a file-scope device array instead of a caller workspace.  `scratch` is a host-side stand-in
+// in host code, never a device address: every GPU holds its own copy at its own address, looked up once per device
+// with hipGetSymbolAddress and kept; only that pointer goes to kernels.
+namespace {
+constexpr int64_t NOALLOC_BYTES = 40ll << 20;   // covers the cfg2 encoder forward (42 slabs x 512 x 384 floats = 33.0 MB)
+constexpr int NOALLOC_MAX_DEVICES = 64;
+}  // namespace
+static __device__ __align__(256) float scratch[NOALLOC_BYTES / sizeof(float)];
+namespace {
+float* g_scratch_ptr[NOALLOC_MAX_DEVICES];       // per device, null until the first call on that device
+std::mutex g_scratch_mutex;
+
+int noalloc_scratch(float** out) {
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess) return vae_set_error(VAE_ERR_LAUNCH, "vae_gemm_noalloc: hipGetDevice failed (no GPU?)");
+  VAE_REQUIRE(dev >= 0 && dev < NOALLOC_MAX_DEVICES, "vae_gemm_noalloc: device ordinal %d outside [0, %d)", dev, NOALLOC_MAX_DEVICES);
+  std::lock_guard<std::mutex> lock(g_scratch_mutex);
+  if (!g_scratch_ptr[dev]) {
+    void* p = nullptr;
+    const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));   // the address of THIS device's copy
+    if (e != hipSuccess || !p)
+      return vae_set_error(VAE_ERR_LAUNCH, "vae_gemm_noalloc: hipGetSymbolAddress failed: %s", hipGetErrorString(e));
+    g_scratch_ptr[dev] = static_cast<float*>(p);
+  }
+  *out = g_scratch_ptr[dev];
+  return VAE_OK;
+}
+}  // namespace
+
+extern "C" int64_t vae_gemm_noalloc_max_bytes(void) { return NOALLOC_BYTES; }
+
+extern "C" int vae_gemm_noalloc(int layout, int precision, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
+                                const float* B, int64_t ldb, float* C, int64_t ldc, const float* bias, const float* x_mean,
+                                int accumulate, void* stream) {
+  VAE_REQUIRE(M > 0 && N > 0 && K > 0 && M < (1 << 30) && N < (1 << 30) && K < (1 << 30),
+              "vae_gemm_noalloc: bad shape M=%lld N=%lld K=%lld", (long long)M, (long long)N, (long long)K);
+  const int64_t need = vae_gemm_workspace_bytes(M, N, K);
+  VAE_REQUIRE(need <= NOALLOC_BYTES,
+              "vae_gemm_noalloc: M=%lld N=%lld K=%lld needs %lld bytes of split-K scratch, the static scratch holds %lld "
+              "(use vae_gemm with a caller workspace)", (long long)M, (long long)N, (long long)K, (long long)need,
+              (long long)NOALLOC_BYTES);
+  float* ws = nullptr;
+  if (need > 0) {   // slabs are fully overwritten before they are read: nothing to clear between calls
+    const int rc = noalloc_scratch(&ws);
+    if (rc != VAE_OK) return rc;
+  }
+  return gemm_impl(layout, precision, M, N, K, A, lda, B, ldb, C, ldc, bias, x_mean, accumulate, ws, need, stream, nullptr);
 }
 
 extern "C" int64_t vae_gemm_slabs_workspace_bytes(int64_t M, int64_t N, int64_t K) {
