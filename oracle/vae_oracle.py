@@ -78,13 +78,23 @@ def _linear(a: Tensor, w: Tensor, b: Optional[Tensor], gemm_dtype) -> Tensor:
     return y if b is None else y + b
 
 
-def fc_layers(p: Dict[str, Tensor], prefix: str, x: Tensor, n_layers: int, gemm_dtype=None, masks=None) -> Tensor:
-    """FCLayers without batch covariates; modules.py:110-115,121-132.
+def batch_covariates(batch_labels: Tensor, batch_mask: Tensor, sizes) -> Tensor:
+    """The masked one-hot block FCLayers.forward appends to its input (modules.py:123-130): labels below 0 count as 0
+    (the reference clamps them in place), every property's one-hot is multiplied by its mask column."""
+    lab = batch_labels.clamp(min=0)
+    cols = [F.one_hot(lab[:, n], num_classes=int(k)) * batch_mask[:, n:n + 1] for n, k in enumerate(sizes)]
+    return torch.cat(cols, dim=-1)
+
+
+def fc_layers(p: Dict[str, Tensor], prefix: str, x: Tensor, n_layers: int, gemm_dtype=None, masks=None, cov=None) -> Tensor:
+    """FCLayers; modules.py:110-115,121-132.  ``cov``: the batch-covariate block, concatenated to the input.
 
     Per layer n: Linear (index 4n) -> GELU(erf) -> LayerNorm(eps 1e-5, affine; index 4n+2) -> Dropout
     (index 4n+3).  ``masks[n]`` is the dropout MULTIPLIER of layer n (keep / (1 - p), what nn.Dropout
     multiplies by in training mode); None = dropout off / eval.
     """
+    if cov is not None:
+        x = torch.cat((x, cov.to(x.dtype)), dim=-1)
     for n in range(n_layers):
         w = p[f"{prefix}.fc_layers.{4 * n}.weight"]
         b = p[f"{prefix}.fc_layers.{4 * n}.bias"]
@@ -98,23 +108,23 @@ def fc_layers(p: Dict[str, Tensor], prefix: str, x: Tensor, n_layers: int, gemm_
     return x
 
 
-def encoder_forward(p, prefix: str, x: Tensor, noise: Tensor, n_layers: int, gemm_dtype=None, masks=None):
+def encoder_forward(p, prefix: str, x: Tensor, noise: Tensor, n_layers: int, gemm_dtype=None, masks=None, cov=None):
     """Encoder.forward, modules.py:261-271 (GeneDropout identity, z_transformation identity).
 
     ``noise`` is the standard-normal draw Normal.rsample would make (modules.py:11-12);
     q_v has ONE column (shared_variance, modules.py:249) and broadcasts over the latent.
     """
     xn = x / x.mean(dim=-1, keepdim=True) - 1
-    q = fc_layers(p, f"{prefix}.encoder", xn, n_layers, gemm_dtype, masks)
+    q = fc_layers(p, f"{prefix}.encoder", xn, n_layers, gemm_dtype, masks, cov)   # covariates join AFTER the normalisation
     q_m = _linear(q, p[f"{prefix}.mean_encoder.weight"], p[f"{prefix}.mean_encoder.bias"], gemm_dtype)
     q_v = F.softplus(_linear(q, p[f"{prefix}.var_encoder.weight"], p[f"{prefix}.var_encoder.bias"], gemm_dtype)) + 1e-4
     latent = q_m + noise * torch.sqrt(q_v)
     return q_m, q_v, latent
 
 
-def decoder_forward(p, z: Tensor, library: Tensor, n_layers: int, gemm_dtype=None, masks=None):
+def decoder_forward(p, z: Tensor, library: Tensor, n_layers: int, gemm_dtype=None, masks=None, cov=None):
     """DecoderSCVI.forward for dispersion != 'gene-cell'; modules.py:371-406."""
-    px = fc_layers(p, "decoder.px_decoder", z, n_layers, gemm_dtype, masks)
+    px = fc_layers(p, "decoder.px_decoder", z, n_layers, gemm_dtype, masks, cov)
     logit_scale = _linear(px, p["decoder.px_scale_decoder.0.weight"], p["decoder.px_scale_decoder.0.bias"], gemm_dtype)
     px_scale = torch.softmax(logit_scale, dim=-1)
     px_dropout = _linear(px, p["decoder.px_dropout_decoder.weight"], p["decoder.px_dropout_decoder.bias"], gemm_dtype)
@@ -184,6 +194,7 @@ def training_step(
     drop_masks: Optional[dict] = None,
     x_z: Optional[Tensor] = None,
     dispersion: str = "gene",
+    cov: Optional[Tensor] = None,
 ) -> Dict[str, Tensor]:
     """Forward of one training step; returns every intermediate the goldens pin.
 
@@ -191,12 +202,13 @@ def training_step(
     ``drop_masks = {"z_encoder": [m_0, ...], "decoder": [m_0, ...]}`` are the nn.Dropout multipliers
     of each hidden layer (modules.py:115; the library encoder is built with dropout 0,
     networks.py:215-222); ``x_z`` is the z-encoder's input after GeneDropout (modules.py:190-209,263)
-    -- the library encoder and the likelihood see ``x`` itself."""
+    -- the library encoder and the likelihood see ``x`` itself.  ``cov``: ``batch_covariates(...)`` of a model built
+    with ``batch_properties`` (it enters both encoders and the decoder, modules.py:121-130)."""
     dm = drop_masks or {}
     qz_m, qz_v, z = encoder_forward(p, "z_encoder", x if x_z is None else x_z, eps_z, n_layers, gemm_dtype,
-                                    dm.get("z_encoder"))
-    ql_m, ql_v, library = encoder_forward(p, "l_encoder", x, eps_l, 1, gemm_dtype)  # networks.py:215-222
-    px_scale, px_rate, px_dropout = decoder_forward(p, z, library, n_layers, gemm_dtype, dm.get("decoder"))
+                                    dm.get("z_encoder"), cov)
+    ql_m, ql_v, library = encoder_forward(p, "l_encoder", x, eps_l, 1, gemm_dtype, None, cov)  # networks.py:215-222
+    px_scale, px_rate, px_dropout = decoder_forward(p, z, library, n_layers, gemm_dtype, dm.get("decoder"), cov)
     if dispersion == "gene":
         theta = torch.exp(p["px_r"])  # task.py:481-483
     elif dispersion == "gene-cell":

@@ -166,3 +166,56 @@ def build_case_inputs(case):
         mask[1, 1] = 0.0
         targets[0, 0] = -100.0  # ignore_index path (task.py:132), masked out as the loader would
     return params, x, eps_z, eps_l, targets, mask
+
+
+# ---- row f4: batch covariates (modules.py:121-130) and GroupedEncoder (modules.py:134-188) ----------------------
+_F4_PROPS = OrderedDict(
+    A={"discrete": True, "values": [0, 1], "stop_grad": False},
+    Dc={"discrete": False, "values": [-1], "stop_grad": False},
+    C={"discrete": True, "values": [0, 1, 2], "stop_grad": True},
+)
+_F4_BATCH = OrderedDict(Brain_bank={"values": ["A", "B", "C"]}, Sex={"values": ["M", "F"]})
+F4_CASES = [
+    dict(name="batchcov", G=64, H=16, Hd=12, Hl=8, L=4, L_cell=4, n_layers=2, B=12, likelihood="zinb", seed=101,
+         cell_properties=_F4_PROPS, batch_properties=_F4_BATCH, grouped=False, grad_reverse={"C": 0.3}, gene_loss_coeff=5e-3,
+         stream=41),
+    # grouped: the decoder and the cell heads see the concatenation of one latent per property (L * 3)
+    dict(name="grouped", G=64, H=16, Hd=12, Hl=8, L=3, L_cell=9, n_layers=1, B=10, likelihood="zinb", seed=102,
+         cell_properties=_F4_PROPS, batch_properties=None, grouped=True, grad_reverse={}, gene_loss_coeff=5e-3, stream=43),
+]
+
+
+def build_f4_inputs(case):
+    """-> (x64, [eps_z64 per z-encoder], eps_l64, batch_labels i64|None, batch_mask i64|None, targets f32, mask f32);
+    fills case['l_mean'/'l_var'].  batch labels contain -1 (unknown: the reference clamps them to 0 IN PLACE and the mask
+    removes them) and fully masked rows."""
+    B, G, L = case["B"], case["G"], case["L"]
+    s = case["stream"] * 1000
+    x = formula_counts(B, G, s + 500)
+    n_enc = len(case["cell_properties"]) if case["grouped"] else 1
+    eps_z = [formula_tensor((B, L), s + 600 + 10 * j, "normal") for j in range(n_enc)]
+    eps_l = formula_tensor((B, 1), s + 601, "normal")
+    lib = np.log1p(x.numpy().astype(np.float32).sum(axis=1))
+    case["l_mean"], case["l_var"] = float(np.mean(lib)), float(max(np.var(lib), 0.05))
+    batch_labels = batch_mask = None
+    if case["batch_properties"]:
+        nb = len(case["batch_properties"])
+        u = _uniform(B * nb, s + 800).reshape(B, nb)
+        sizes = np.array([len(v["values"]) for v in case["batch_properties"].values()])
+        lab = np.floor(u * sizes[None, :]).astype(np.int64)
+        m = np.ones((B, nb), dtype=np.int64)
+        lab[1, 0], m[1, 0] = -1, 0          # unknown label: clamped to 0 by the reference, masked out
+        m[2, :] = 0                          # a cell with no covariate at all
+        batch_labels, batch_mask = torch.from_numpy(lab), torch.from_numpy(m)
+    P = len(case["cell_properties"])
+    targets = torch.zeros(B, P, dtype=torch.float32)
+    mask = torch.ones(B, P, dtype=torch.float32)
+    u = _uniform(B * P, s + 700).reshape(B, P)
+    for n, (k, prop) in enumerate(case["cell_properties"].items()):
+        if prop["discrete"]:
+            targets[:, n] = torch.from_numpy(np.floor(u[:, n] * len(prop["values"]))).float()
+        else:
+            targets[:, n] = torch.from_numpy(u[:, n] * 4 - 2).float()
+    mask[0, :] = 0.0
+    targets[0, 0] = -100.0
+    return x, eps_z, eps_l, batch_labels, batch_mask, targets, mask

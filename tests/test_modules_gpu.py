@@ -311,3 +311,106 @@ def test_train_main_with_the_shipped_regularisers():
     run = task.network.z_encoder.drop.running_non_zero_means
     assert torch.is_tensor(run) and run.is_cuda and 0.0 < float(run.mean()) < 1.0
     assert task._fused.dropout_rate == 0.5 and task._fused.input_dropout_rate == 0.5
+
+
+# ---- row f4: batch covariates (modules.py:121-130) and GroupedEncoder (modules.py:134-188) vs reference-made goldens ----
+def _f4_network(case, gold):
+    from vae_amd.networks import VAE
+    with contextlib.redirect_stdout(io.StringIO()):
+        net = VAE(case["G"], n_hidden=case["H"], n_hidden_decoder=case["Hd"], n_hidden_library=case["Hl"], n_latent=case["L"],
+                  n_latent_cell_decoder=case["L_cell"], n_layers=case["n_layers"], dropout_rate=0.0, input_dropout_rate=0.0,
+                  cell_properties=case["cell_properties"], batch_properties=case["batch_properties"],
+                  grouped_encoder=case["grouped"], grad_reverse_dict=case["grad_reverse"],
+                  reconstruction_loss=case["likelihood"], cell_decoder_hidden_layer=False)
+    params = {k[len("param/"):]: torch.from_numpy(gold[k]).float() for k in gold.files if k.startswith("param/")}
+    assert set(params) == set(net.state_dict())                       # the reference's state-dict keys, shapes below
+    net.load_state_dict(params)
+    return net.cuda()
+
+
+def test_batch_covariates_training_step_matches_the_reference(monkeypatch):
+    """VAE(batch_properties=...) through LitVAE.training_step on the HIP ops: the masked one-hot covariates enter both
+    encoders (after the count normalisation, as a small second product next to the gene-wide count GEMM) and the decoder;
+    -1 labels are clamped in place and masked, one cell has no covariate at all.  Values and every parameter gradient
+    against the fp64 run of the reference (tests/golden/make_goldens_f4.py)."""
+    import vae_amd.modules as M
+    from golden_inputs import F4_CASES, build_f4_inputs
+    from vae_amd.task import LitVAE
+    case = copy.deepcopy(F4_CASES[0])
+    gold = load_golden("f4_batchcov.npz")
+    x, eps_z, eps_l, bl, bm, targets, mask = build_f4_inputs(case)
+    net = _f4_network(case, gold)
+    G = case["G"]
+    assert net.z_encoder.encoder.fc_layers[0].weight.shape == (case["H"], G + 5)      # 3 + 2 covariate columns
+    task = LitVAE(net, cell_properties=case["cell_properties"], batch_properties=case["batch_properties"],
+                  reconstruction_loss="zinb", n_epochs_kl_warmup=None, gene_loss_coeff=case["gene_loss_coeff"],
+                  library_mean=np.float32(case["l_mean"]), library_var=np.float32(case["l_var"])).train()
+    labels = bl.clone().cuda()
+    batch = (x.float().cuda(), targets.cuda(), mask.cuda(), labels, bm.cuda(), None, None, None)
+    queue = [eps_z[0].float().cuda(), eps_l.float().cuda()]
+    seen = {}
+
+    def rsample(mu, var):
+        out = mu + queue.pop(0) * var.sqrt()
+        seen.setdefault("z", out)
+        return out
+
+    monkeypatch.setattr(M, "reparameterize_gaussian", rsample)
+    loss = task.training_step(batch, 0)
+    loss.backward()
+    torch.cuda.synchronize()
+    assert int(labels.min()) == 0                                        # clamped in place, as the reference does
+    assert abs(float(loss.detach()) - float(gold["out/loss"])) < TOL_CELL * abs(float(gold["out/loss"]))
+    assert rel_err(seen["z"].detach().cpu().numpy(), gold["out/z"]) < TOL_CELL
+    assert abs(float(task.logged["gene_loss"]) - float(gold["out/gene_loss"])) < TOL_CELL * abs(float(gold["out/gene_loss"]))
+    assert abs(float(task.logged["cell_loss"]) - float(gold["out/cell_loss"])) < TOL_CELL * abs(float(gold["out/cell_loss"]))
+    n = 0
+    for k, p in net.named_parameters():
+        if f"gradnone/{k}" in gold.files:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+            continue
+        assert p.grad is not None, k
+        g = gold[f"grad/{k}"]
+        assert rel_err(p.grad.cpu().numpy(), g) < TOL_GRAD, k
+        if k.endswith("encoder.fc_layers.0.weight"):                     # the covariate columns on their own scale
+            assert rel_err(p.grad[:, G:].cpu().numpy(), g[:, G:]) < TOL_GRAD, k + " (covariate columns)"
+        n += 1
+    assert n >= 30
+    # the fused step refuses this configuration loudly (INTEGRATION.md)
+    with pytest.raises(NotImplementedError):
+        task.training_step_fused(batch)
+
+
+def test_grouped_encoder_forward_matches_the_reference(monkeypatch):
+    """VAE(grouped_encoder=True): one Encoder per cell property, latents concatenated (modules.py:134-188).  The
+    reference itself cannot take a training step with it (its gene_loss, task.py:188-193, pairs a (B, 3L) mean with a
+    (B, 3) variance and the broadcast raises), so what it can run is pinned: the forward of the encoders, the decoder on
+    the concatenated latent and the heads."""
+    import vae_amd.modules as M
+    from golden_inputs import F4_CASES, build_f4_inputs
+    case = copy.deepcopy(F4_CASES[1])
+    gold = load_golden("f4_grouped.npz")
+    x, eps_z, eps_l, _, _, _, _ = build_f4_inputs(case)
+    net = _f4_network(case, gold).train()
+    queue = [e.float().cuda() for e in eps_z] + [eps_l.float().cuda()]
+    monkeypatch.setattr(M, "reparameterize_gaussian", lambda mu, var: mu + queue.pop(0) * var.sqrt())
+    xd = x.float().cuda()
+    qz_m, qz_v, z = net.z_encoder(xd, None, None)
+    ql_m, ql_v, library = net.l_encoder(xd, None, None)
+    _, _, px_rate, px_dropout = net.decoder("gene", z, library, None, None)
+    pred = net.cell_decoder(z)
+    torch.cuda.synchronize()
+    L, P = case["L"], len(case["cell_properties"])
+    assert qz_m.shape == (case["B"], L * P) and qz_v.shape == (case["B"], P) and z.shape == (case["B"], L * P)
+    got = dict(qz_m=qz_m, qz_v=qz_v, z=z, ql_m=ql_m, ql_v=ql_v, library=library, px_dropout=px_dropout,
+               **{"pred_" + k: v for k, v in pred.items()})
+    for k, v in got.items():
+        g = gold[f"out/{k}"]
+        assert rel_err(v.detach().cpu().numpy().reshape(g.shape), g) < TOL_CELL, k
+    g = gold["out/px_rate"]
+    assert np.max(np.abs(px_rate.detach().cpu().numpy() - g) / np.abs(g).max(axis=1, keepdims=True)) < TOL_CELL
+    # gradients flow through every per-property encoder (autograd over the HIP ops)
+    (px_rate.sum() * 1e-3 + sum(v.sum() for v in pred.values())).backward()
+    for name in case["cell_properties"]:
+        w = net.z_encoder.z_enc[name].encoder.fc_layers[0].weight
+        assert w.grad is not None and float(w.grad.abs().max()) > 0

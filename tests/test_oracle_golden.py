@@ -100,3 +100,31 @@ def test_host_philox_known_answers():
     assert int(philox_word0(0xFFFFFFFFFFFFFFFF, 0xFFFFFFFF, 0xFFFFFFFF, ones)[0]) == 0x408F276D
     m = dropout_multiplier(0.5, 1234, 7, 0, 512, 256)
     assert set(np.unique(m)) == {0.0, 2.0} and abs((m > 0).mean() - 0.5) < 0.01
+
+
+def test_oracle_with_batch_covariates_matches_the_reference():
+    """Row f4: masked one-hot batch covariates in both encoders and the decoder (modules.py:121-130), fp64, against the
+    reference's own run (tests/golden/make_goldens_f4.py)."""
+    import copy
+    from golden_inputs import F4_CASES, build_f4_inputs
+    case = copy.deepcopy(F4_CASES[0])
+    gold = load_golden("f4_batchcov.npz")
+    x, eps_z, eps_l, bl, bm, targets, mask = build_f4_inputs(case)
+    p = {k[len("param/"):]: torch.from_numpy(gold[k]) for k in gold.files if k.startswith("param/")}
+    cov = O.batch_covariates(bl, bm, [len(v["values"]) for v in case["batch_properties"].values()]).double()
+    assert cov.shape == (case["B"], 5) and float(cov[2].abs().sum()) == 0.0 and float(cov[1, :3].abs().sum()) == 0.0
+    out, grads = O.training_step_with_grads(p, x, eps_z[0], eps_l, n_layers=case["n_layers"], likelihood="zinb",
+                                            l_mean=case["l_mean"], l_var=case["l_var"], gene_loss_coeff=case["gene_loss_coeff"],
+                                            cell_properties=case["cell_properties"], grad_reverse=case["grad_reverse"],
+                                            cell_targets=targets.double(), cell_mask=mask.double(), cov=cov)
+    for k in ("qz_m", "z", "library", "recon", "kl_z", "kl_l", "loss", "cell_loss"):
+        g = gold[f"out/{k}"]
+        assert rel_err(out[k].numpy().reshape(g.shape), g) < 1e-11, k
+    n = 0
+    for k, g in grads.items():
+        if f"gradnone/{k}" in gold.files:
+            assert g is None, k
+            continue
+        assert rel_err(g.numpy(), gold[f"grad/{k}"]) < 1e-10, k
+        n += 1
+    assert n >= 30

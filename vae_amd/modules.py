@@ -79,13 +79,22 @@ class FCLayers(nn.Module):
             layers.append(nn.Dropout(p=float(dropout_rate)))
         self.fc_layers = nn.Sequential(*layers)
 
-    def _run(self, x: torch.Tensor, count_input: bool) -> torch.Tensor:
+    def _run(self, x: torch.Tensor, count_input: bool, cov: Optional[torch.Tensor] = None) -> torch.Tensor:
         mods = list(self.fc_layers)
         per = 4 if self.layer_norm else 3
         for n in range(self.n_layers):
             lin = mods[per * n]
             if n == 0 and count_input:
-                pre = CountLinearFn.apply(x, lin.weight, lin.bias, self.precision)
+                # Encoder.forward normalises the counts BEFORE FCLayers appends the covariates (modules.py:264,267), so
+                # with W = [W_x | W_c] the first layer is (x/mean - 1) W_x^T + cov W_c^T + b: the gene-wide product stays
+                # on the count GEMM (normalisation fused into its operand staging), the few covariate columns add a
+                # (B, n_cov) x (n_cov, H) product -- nothing 20k wide is concatenated or copied
+                if cov is not None:
+                    G = x.shape[1]
+                    pre = CountLinearFn.apply(x, lin.weight[:, :G], lin.bias, self.precision)
+                    pre = pre + LinearFn.apply(cov, lin.weight[:, G:], None, self.precision)
+                else:
+                    pre = CountLinearFn.apply(x, lin.weight, lin.bias, self.precision)
             else:
                 pre = LinearFn.apply(x, lin.weight, lin.bias, self.precision)
             if self.layer_norm:
@@ -97,16 +106,18 @@ class FCLayers(nn.Module):
         return x
 
     def forward(self, x: torch.Tensor, batch_vals: torch.Tensor, batch_mask: torch.Tensor, _count_input: bool = False):
+        cov = None
         if np.sum(self.batch_dims) > 0:
-            if _count_input:
-                raise NotImplementedError("vae_amd: batch covariates on the count input are not on the HIP path yet")
-            batch_vals[batch_vals < 0] = 0
+            batch_vals[batch_vals < 0] = 0                      # in place, as the reference (modules.py:124)
             batch_vars = []
             for n in range(len(self.batch_dims)):
                 b = F.one_hot(batch_vals[:, n], num_classes=self.batch_dims[n])
                 batch_vars.append(b * batch_mask[:, n: n + 1])
-            x = torch.cat((x, *batch_vars), dim=-1)
-        return self._run(x, _count_input)
+            if _count_input:
+                cov = torch.cat(batch_vars, dim=-1).to(torch.float32)
+            else:
+                x = torch.cat((x, *batch_vars), dim=-1)
+        return self._run(x, _count_input, cov)
 
 
 class GeneDropout(nn.Module):

@@ -78,7 +78,8 @@ class VAE(nn.Module):
                                    dropout_rate=dropout_rate)
 
     def set_gemm_precision(self, precision: int) -> None:
-        """ops.FP32 (exact fp32 MFMA) or ops.BF16 (bf16 operands, fp32 accumulate) for every Linear."""
+        """ops.FP32 (fp32-grade: operands split exactly into three bf16 terms, six bf16 MFMA products, fp32 accumulate)
+        or ops.BF16 (operands rounded to bf16, fp32 accumulate) for every Linear of the module path."""
         for m in self.modules():
             if hasattr(m, "precision"):
                 m.precision = precision
