@@ -294,6 +294,13 @@ typedef struct {
   float input_dropout_rate;   /* p of GeneDropout on the z-encoder input (modules.py:190-209); 0 = off   */
   float input_dropout_alpha;  /* its running-average factor (0.95 in the reference)                      */
   float* gene_running;        /* (G) device: GeneDropout.running_non_zero_means, updated by the forward  */
+  /* VAE_FP32_F16X2 only, optional: partial maxima of |enc_w0| and |heads_w| (weight_max_n floats each, 16-byte aligned,
+   * every entry >= 0 and their maximum = the matrix's largest magnitude) kept up to date by whoever last changed the
+   * weights -- vae_adamw_step_wmax writes them while it stores the updated weights.  With both set the forward skips its
+   * own scan of the two weight matrices (72 MB at 20k genes).  NULL: the step scans.                              */
+  const float* weight_max_enc;
+  const float* weight_max_heads;
+  int32_t weight_max_n;
 } vae_step_config;
 
 typedef struct {
@@ -362,6 +369,14 @@ int vae_adamw_step(float* params, const float* grads, float* exp_avg, float* exp
                    const vae_adamw_segment* segments, int n_segments, double lr, double beta1, double beta2, double eps,
                    int64_t step, double max_grad_norm, double grad_scale, float* workspace, int64_t workspace_bytes,
                    float* grad_norm_out, void* stream);
+/* The same step that also leaves, for two element ranges [max_ranges[0], max_ranges[1]) and [max_ranges[2], max_ranges[3])
+ * of the arena, vae_adamw_wmax_partials() partial maxima each of the UPDATED |params| in wmax_out (range 0 first): what
+ * vae_step_config.weight_max_enc / weight_max_heads take.  HBM-bound as before: the maxima ride in the update pass.   */
+int64_t vae_adamw_wmax_partials(void);
+int vae_adamw_step_wmax(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
+                        const vae_adamw_segment* segments, int n_segments, double lr, double beta1, double beta2, double eps,
+                        int64_t step, double max_grad_norm, double grad_scale, float* workspace, int64_t workspace_bytes,
+                        float* grad_norm_out, const int64_t* max_ranges, float* wmax_out, void* stream);
 
 /* L1 penalty of LitVAE.training_step (task.py:491-496): sum_out[0] = sum of |p| over the segments (their
  * weight_decay field is ignored) and, when grads is not null, grads += grad_coeff * sign(p) -- the gradient of

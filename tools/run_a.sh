@@ -1,7 +1,7 @@
 # GPU round trip: parity suite, bench line, rocprofv3 kernel summary (one gpurun call).  TAG names the outputs.
 TAG=${TAG:-a}
 mkdir -p gpurun_out
-timeout -k 10 900 python -u -m pytest tests tests/wip_no_alloc.py -m gpu -q --timeout 300 --timeout-method thread -p no:cacheprovider -s > gpurun_out/r2_tests_$TAG.log 2>&1
+timeout -k 10 900 python -u -m pytest tests -m gpu -q --timeout 300 --timeout-method thread -p no:cacheprovider -s > gpurun_out/r2_tests_$TAG.log 2>&1
 rc=$?
 tail -8 gpurun_out/r2_tests_$TAG.log
 if [ $rc -ne 0 ] && [ $rc -ne 1 ]; then exit $rc; fi

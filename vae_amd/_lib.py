@@ -78,6 +78,9 @@ SIGNATURES = {
     "vae_adamw_workspace_bytes": (_i64, []),
     "vae_adamw_step": (_i32, [_ptr, _ptr, _ptr, _ptr, _i64, _ptr, _i32, C.c_double, C.c_double, C.c_double, C.c_double,
                               _i64, C.c_double, C.c_double, _ptr, _i64, _ptr, _ptr]),
+    "vae_adamw_wmax_partials": (_i64, []),
+    "vae_adamw_step_wmax": (_i32, [_ptr, _ptr, _ptr, _ptr, _i64, _ptr, _i32, C.c_double, C.c_double, C.c_double, C.c_double,
+                                   _i64, C.c_double, C.c_double, _ptr, _i64, _ptr, _ptr, _ptr, _ptr]),
     "vae_loglik_elem_fwd": (_i32, [_i32, _ptr, _i64, _ptr, _i64, _ptr, _i64, _ptr, _i64, _i64, _i64, _ptr, _i64, _ptr]),
     "vae_loglik_elem_bwd": (_i32, [_i32, _ptr, _i64, _ptr, _i64, _ptr, _i64, _ptr, _i64, _ptr, _i64, _i64, _i64, _ptr, _ptr, _ptr, _ptr]),
 }
@@ -97,7 +100,8 @@ class StepConfig(C.Structure):
                 ("n_layers", C.c_int32), ("zinb", C.c_int32), ("precision", C.c_int32),
                 ("l_mean", _f32), ("l_var", _f32), ("kl_weight", _f32), ("gene_loss_coeff", _f32), ("loss_scale", _f32),
                 ("x_dtype", C.c_int32), ("dropout_rate", _f32), ("rng_step", C.c_uint32), ("rng_seed", C.c_uint64),
-                ("input_dropout_rate", _f32), ("input_dropout_alpha", _f32), ("gene_running", _ptr)]
+                ("input_dropout_rate", _f32), ("input_dropout_alpha", _f32), ("gene_running", _ptr),
+                ("weight_max_enc", _ptr), ("weight_max_heads", _ptr), ("weight_max_n", C.c_int32)]
 
 
 class StepTensors(C.Structure):

@@ -62,8 +62,10 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
                                                     float* __restrict__ m, float* __restrict__ v, int64_t n, Segs s,
                                                     float gscale, float beta1, float beta2, float eps, float step_size,
                                                     float bc2_sqrt, float max_norm, const float* __restrict__ partial,
-                                                    int npartial, float* __restrict__ norm_out) {
+                                                    int npartial, float* __restrict__ norm_out, int64_t r0b, int64_t r0e,
+                                                    int64_t r1b, int64_t r1e, float* __restrict__ wmax) {
   __shared__ float red[4];
+  float wm0 = 0.f, wm1 = 0.f;   // max |updated parameter| of this workgroup inside the two tracked ranges (wmax != null)
   // clip coefficient: every workgroup sums the same partials in the same order
   float coef = 1.f;
   if (max_norm > 0.f) {
@@ -114,12 +116,22 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
         reinterpret_cast<float4*>(p)[idx[u]] = pv[u];
         reinterpret_cast<float4*>(m)[idx[u]] = mv[u];
         reinterpret_cast<float4*>(v)[idx[u]] = vv[u];
+        if (wmax) {   // a 16-byte chunk inside one segment lies inside at most one tracked range (ranges are segments' parts)
+          const int64_t e = idx[u] << 2;
+          const float mx = fmaxf(fmaxf(fabsf(pv[u].x), fabsf(pv[u].y)), fmaxf(fabsf(pv[u].z), fabsf(pv[u].w)));
+          if (e >= r0b && e < r0e) wm0 = fmaxf(wm0, mx);          // range ends are multiples of 4: a chunk is in or out
+          else if (e >= r1b && e < r1e) wm1 = fmaxf(wm1, mx);
+        }
       } else if (kk[u] == -1) {
         const int64_t e = idx[u] << 2;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int k = seg_of(s, e + j);
-          if (k >= 0) upd(p[e + j], g[e + j], m[e + j], v[e + j], s.decay[k]);
+          if (k >= 0) {
+            upd(p[e + j], g[e + j], m[e + j], v[e + j], s.decay[k]);
+            if (wmax && e + j >= r0b && e + j < r0e) wm0 = fmaxf(wm0, fabsf(p[e + j]));
+            if (wmax && e + j >= r1b && e + j < r1e) wm1 = fmaxf(wm1, fabsf(p[e + j]));
+          }
         }
       }
     }
@@ -128,6 +140,14 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
     const int64_t e = (n4 << 2) + threadIdx.x;
     const int k = seg_of(s, e);
     if (k >= 0) upd(p[e], g[e], m[e], v[e], s.decay[k]);
+  }
+  if (wmax) {   // plain stores, every entry every step: nothing to clear (the tracked ranges are 16-byte aligned multiples of 4)
+    wm0 = block_max<4>(wm0, red);
+    wm1 = block_max<4>(wm1, red);
+    if (threadIdx.x == 0) {
+      wmax[blockIdx.x] = wm0;
+      wmax[gridDim.x + blockIdx.x] = wm1;
+    }
   }
 }
 
@@ -186,12 +206,53 @@ extern "C" int vae_l1_penalty(const float* params, float* grads, int64_t n, cons
   return VAE_OK;
 }
 
-extern "C" int64_t vae_adamw_workspace_bytes(void) { return NORM_BLOCKS * (int64_t)sizeof(float); }
+// NORM_BLOCKS partial sums of g^2, then 2 x 4096 raw partial maxima of vae_adamw_step_wmax
+extern "C" int64_t vae_adamw_workspace_bytes(void) { return (NORM_BLOCKS + 2 * 4096) * (int64_t)sizeof(float); }
+
+constexpr int WMAX_OUT = 64;         // vae_adamw_wmax_partials(): entries per tracked range a consumer has to reduce
+extern "C" int64_t vae_adamw_wmax_partials(void) { return WMAX_OUT; }
+namespace {
+// raw[r * blocks + b] (one per update workgroup and range) -> out[r * WMAX_OUT + j] = max over b = j (mod WMAX_OUT)
+__global__ __launch_bounds__(2 * WMAX_OUT) void wmax_finish_kernel(const float* __restrict__ raw, int blocks, float* __restrict__ out) {
+  const int r = threadIdx.x / WMAX_OUT, j = threadIdx.x % WMAX_OUT;
+  float m = 0.f;
+  for (int b = j; b < blocks; b += WMAX_OUT) m = fmaxf(m, raw[r * blocks + b]);
+  out[r * WMAX_OUT + j] = m;
+}
+}  // namespace
+
+static int adamw_impl(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
+                      const vae_adamw_segment* segments, int n_segments, double lr, double beta1, double beta2,
+                      double eps, int64_t step, double max_grad_norm, double grad_scale, float* workspace,
+                      int64_t workspace_bytes, float* grad_norm_out, const int64_t* max_ranges, float* wmax, void* stream);
 
 extern "C" int vae_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
                               const vae_adamw_segment* segments, int n_segments, double lr, double beta1, double beta2,
                               double eps, int64_t step, double max_grad_norm, double grad_scale, float* workspace,
                               int64_t workspace_bytes, float* grad_norm_out, void* stream) {
+  return adamw_impl(params, grads, exp_avg, exp_avg_sq, n, segments, n_segments, lr, beta1, beta2, eps, step, max_grad_norm,
+                    grad_scale, workspace, workspace_bytes, grad_norm_out, nullptr, nullptr, stream);
+}
+
+extern "C" int vae_adamw_step_wmax(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
+                                   const vae_adamw_segment* segments, int n_segments, double lr, double beta1, double beta2,
+                                   double eps, int64_t step, double max_grad_norm, double grad_scale, float* workspace,
+                                   int64_t workspace_bytes, float* grad_norm_out, const int64_t* max_ranges, float* wmax_out,
+                                   void* stream) {
+  VAE_REQUIRE(max_ranges && wmax_out, "vae_adamw_step_wmax: null max_ranges / wmax_out");
+  VAE_REQUIRE(workspace && workspace_bytes >= vae_adamw_workspace_bytes(), "vae_adamw_step_wmax: needs vae_adamw_workspace_bytes()");
+  for (int r = 0; r < 2; ++r)
+    VAE_REQUIRE(max_ranges[2 * r] >= 0 && max_ranges[2 * r] <= max_ranges[2 * r + 1] && max_ranges[2 * r + 1] <= n &&
+                    max_ranges[2 * r] % 4 == 0 && max_ranges[2 * r + 1] % 4 == 0,
+                "vae_adamw_step_wmax: tracked range %d must lie in the arena with both ends multiples of 4", r);
+  return adamw_impl(params, grads, exp_avg, exp_avg_sq, n, segments, n_segments, lr, beta1, beta2, eps, step, max_grad_norm,
+                    grad_scale, workspace, workspace_bytes, grad_norm_out, max_ranges, wmax_out, stream);
+}
+
+static int adamw_impl(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
+                      const vae_adamw_segment* segments, int n_segments, double lr, double beta1, double beta2,
+                      double eps, int64_t step, double max_grad_norm, double grad_scale, float* workspace,
+                      int64_t workspace_bytes, float* grad_norm_out, const int64_t* max_ranges, float* wmax, void* stream) {
   VAE_REQUIRE(params && grads && exp_avg && exp_avg_sq && n > 0, "vae_adamw_step: null pointer or empty arena");
   VAE_REQUIRE(segments && n_segments > 0 && n_segments <= MAX_SEG, "vae_adamw_step: 1..%d segments, got %d", MAX_SEG, n_segments);
   VAE_REQUIRE(step >= 1, "vae_adamw_step: step counts from 1");
@@ -224,7 +285,12 @@ extern "C" int vae_adamw_step(float* params, const float* grads, float* exp_avg,
   }
   hipLaunchKernelGGL(adamw_kernel, dim3(blocks), dim3(256), 0, st, params, grads, exp_avg, exp_avg_sq, n, s,
                      (float)grad_scale, (float)beta1, (float)beta2, (float)eps, step_size, bc2_sqrt, (float)max_grad_norm,
-                     workspace, nblocks, grad_norm_out);
+                     workspace, nblocks, grad_norm_out, max_ranges ? max_ranges[0] : 0, max_ranges ? max_ranges[1] : 0,
+                     max_ranges ? max_ranges[2] : 0, max_ranges ? max_ranges[3] : 0, wmax ? workspace + NORM_BLOCKS : nullptr);
   VAE_CHECK_LAUNCH("vae_adamw_step");
+  if (wmax) {
+    hipLaunchKernelGGL(wmax_finish_kernel, dim3(1), dim3(2 * WMAX_OUT), 0, st, workspace + NORM_BLOCKS, blocks, wmax);
+    VAE_CHECK_LAUNCH("vae_adamw_step_wmax(finish)");
+  }
   return VAE_OK;
 }

@@ -119,13 +119,21 @@ struct Ctx {
   void* st;
   // the two-f16-term pipeline needs 16-byte rows everywhere; ragged shapes run as VAE_FP32
   bool fx() const { return c.precision == VAE_FP32_F16X2 && c.G % 4 == 0 && c.Hd % 4 == 0 && (c.H + c.Hl) % 4 == 0; }
-  float* am(int slot) const { return fx() ? ws + lo.amax[slot] : nullptr; }
+  // the two weight matrices' maxima may come from outside (vae_step_config.weight_max_*: the optimiser keeps them)
+  bool wext() const { return c.weight_max_enc && c.weight_max_heads && c.weight_max_n > 0; }
+  float* am(int slot) const {
+    if (!fx()) return nullptr;
+    if (wext() && slot == AM_WENC) return const_cast<float*>(c.weight_max_enc);
+    if (wext() && slot == AM_WHEADS) return const_cast<float*>(c.weight_max_heads);
+    return ws + lo.amax[slot];
+  }
+  int an(int slot) const { return (wext() && (slot == AM_WENC || slot == AM_WHEADS)) ? c.weight_max_n : lo.amax_n[slot]; }
   // one of the five gene-sized products: two-f16-term split when the step runs in VAE_FP32_F16X2, else as `gemm`;
   // slabs_out != null leaves split-K slabs in the scratch (no bias) for the fused middle
   int big(int layout, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, int slot_a, const float* Bm, int64_t ldb,
           int slot_b, float* C, int64_t ldc, const float* bias, int* slabs_out, VaeGemmRowStats* stats = nullptr) const {
     if (fx())
-      return vae_gemm_f16x2(layout, M, N, K, A, lda, am(slot_a), lo.amax_n[slot_a], Bm, ldb, am(slot_b), lo.amax_n[slot_b], C, ldc,
+      return vae_gemm_f16x2(layout, M, N, K, A, lda, am(slot_a), an(slot_a), Bm, ldb, am(slot_b), an(slot_b), C, ldc,
                             bias, 0, ws + lo.scratch,
                             lo.scratch_floats * 4, st, slabs_out, stats);
     // a VAE_FP32_F16X2 step whose shapes are outside the two-f16-term pipeline (fx() false) has no operand maxima:
@@ -210,7 +218,11 @@ extern "C" int vae_elbo_step_forward(const vae_step_config* cfg, const vae_step_
   const int64_t B = c.B, G = c.G, H = c.H, Hl = c.Hl, L = c.L, Hd = c.Hd, HE = c.H + c.Hl;
   const int64_t NH = c.zinb ? 2 * G : G;
 
-  if (k.fx())  // weight maxima of the two-f16-term products and the gene table, one launch
+  if (k.fx() && k.wext()) {  // the caller keeps the weight maxima current: only the gene table is left to build
+    if (!vae_aligned16(c.weight_max_enc) || !vae_aligned16(c.weight_max_heads))
+      return vae_set_error(VAE_ERR_ARG, "vae_elbo_step_forward: weight_max_* must be 16-byte aligned");
+    TRY(vae_gene_table(p->px_r, G, ws + lo.table, stream));
+  } else if (k.fx())  // weight maxima of the two-f16-term products and the gene table, one launch
     TRY(vae_step_prologue(p->enc_w0, HE * G, p->heads_w, NH * Hd, k.am(AM_WENC), k.am(AM_WHEADS), p->px_r, G, ws + lo.table,
                           stream));
   // encoders: x/mean-1 -> Linear(G, H+Hl) -> GELU -> LayerNorm (z and library halves)

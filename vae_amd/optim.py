@@ -28,9 +28,16 @@ class FusedAdamW:
     def __init__(self, arena: ParamArena, lr: float = 5e-4, betas: Tuple[float, float] = (0.9, 0.998), eps: float = 1e-7,
                  weight_decay: float = 0.0, max_grad_norm: float = 0.5,
                  decay_of: Callable[[str, float], float] = reference_weight_decay,
-                 lr_lambda: Optional[Callable[[int], float]] = None, skip: Iterable[str] = ()):
+                 lr_lambda: Optional[Callable[[int], float]] = None, skip: Iterable[str] = (),
+                 track_weight_maxima: bool = False):
         """``skip``: parameter names that receive no gradient in this run (e.g. the cell heads when no
-        cell loss is used) in addition to ``arena.no_grad``: torch leaves grad=None parameters alone."""
+        cell loss is used) in addition to ``arena.no_grad``: torch leaves grad=None parameters alone.
+
+        ``track_weight_maxima``: every step also leaves the partial maxima of the two gene-sized weight matrices
+        (first-layer encoder weights, decoder-head weights) in ``self.weight_maxima`` (2, P) while it stores the updated
+        weights; ``ElboStep.use_weight_maxima(opt)`` then skips the step's own 72 MB scan for the two-f16-term GEMM
+        scales.  Anything else that changes those weights (loading a checkpoint, a broadcast) must call
+        ``refresh_weight_maxima()``."""
         if not arena.flat.is_cuda:
             raise RuntimeError("vae_amd: FusedAdamW needs the arena on a GPU (there is no CPU fallback)")
         self.lib = _lib.load()
@@ -79,6 +86,30 @@ class FusedAdamW:
             raise RuntimeError(f"vae_amd: FusedAdamW supports up to 16 ranges, this arena needs {len(merged)}")
         self.ranges = merged
         self._segs = (_lib.AdamWSegment * len(merged))(*[_lib.AdamWSegment(b, e, wd) for b, e, wd in merged])
+        self.weight_maxima = None
+        if track_weight_maxima:
+            from .arena import _enc
+            def span(first, last):
+                b = arena.offsets[first][0]
+                e = arena.offsets[last][0] + arena.p(last).numel()
+                return b, e
+            enc = span(_enc("z_encoder", 0, "w"), _enc("l_encoder", 0, "w"))
+            heads = span("decoder.px_scale_decoder.0.weight",
+                         "decoder.px_dropout_decoder.weight" if arena.likelihood == "zinb" else "decoder.px_scale_decoder.0.weight")
+            if any(v % 4 for v in enc + heads):
+                raise RuntimeError("vae_amd: FusedAdamW(track_weight_maxima): the weight matrices are not 16-byte multiples")
+            self._max_ranges = (C.c_int64 * 4)(enc[0], enc[1], heads[0], heads[1])
+            self._max_spans = (enc, heads)
+            self.weight_maxima = torch.zeros(2, int(self.lib.vae_adamw_wmax_partials()), dtype=torch.float32, device=arena.device)
+            self.refresh_weight_maxima()
+
+    def refresh_weight_maxima(self) -> None:
+        """Recompute the tracked maxima from the weights as they are now (after anything but ``step()`` changed them)."""
+        if self.weight_maxima is None:
+            return
+        self.weight_maxima.zero_()
+        for r, (b, e) in enumerate(self._max_spans):
+            self.weight_maxima[r, 0] = self.arena.flat[b:e].abs().max()
 
     @property
     def lr(self) -> float:
@@ -89,6 +120,15 @@ class FusedAdamW:
         lr = self.lr
         self.steps += 1
         a = self.arena
+        if self.weight_maxima is not None:
+            rc = self.lib.vae_adamw_step_wmax(a.flat.data_ptr(), a.flat_grad.data_ptr(), self.exp_avg.data_ptr(),
+                                              self.exp_avg_sq.data_ptr(), a.total, self._segs, len(self.ranges), lr, self.betas[0],
+                                              self.betas[1], self.eps, self.steps, self.max_grad_norm, float(grad_scale),
+                                              self._ws.data_ptr(), self._ws.numel() * 4, self.grad_norm.data_ptr(),
+                                              self._max_ranges, self.weight_maxima.data_ptr(),
+                                              C.c_void_p(torch.cuda.current_stream().cuda_stream))
+            _lib.check(rc, "adamw_step_wmax")
+            return
         rc = self.lib.vae_adamw_step(a.flat.data_ptr(), a.flat_grad.data_ptr(), self.exp_avg.data_ptr(),
                                      self.exp_avg_sq.data_ptr(), a.total, self._segs, len(self.ranges), lr, self.betas[0],
                                      self.betas[1], self.eps, self.steps, self.max_grad_norm, float(grad_scale),

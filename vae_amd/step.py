@@ -125,10 +125,21 @@ class ElboStep:
                 raise ValueError("ElboStep: gene_running must be a contiguous float32 GPU tensor of G elements")
         self.params = _tensors(a.p, a.pcat, self.n_layers, self.zinb)
         self.grads = _tensors(a.g, a.gcat, self.n_layers, self.zinb)
+        self.weight_maxima = None
         self._plans: Dict[int, tuple] = {}
         self._ev_heads = self._ev_small = None
         self._zero = None
         self._last_fwd = None
+
+    def use_weight_maxima(self, source) -> None:
+        """Take the partial maxima of the two gene-sized weight matrices from ``source`` (a ``FusedAdamW`` built with
+        ``track_weight_maxima=True``, or a (2, P) float32 GPU tensor kept current by the caller; ``None`` = scan again)
+        instead of scanning 72 MB of weights at the start of every two-f16-term forward."""
+        t = getattr(source, "weight_maxima", source)
+        if t is not None and (not torch.is_tensor(t) or t.dim() != 2 or t.shape[0] != 2 or t.dtype != torch.float32
+                              or not t.is_cuda or not t.is_contiguous() or t.shape[1] % 4):
+            raise ValueError("ElboStep.use_weight_maxima: need a contiguous (2, P) float32 GPU tensor, P a multiple of 4")
+        self.weight_maxima = t
 
     def _plan(self, B: int, loss_scale: float, train: bool = False):
         """Config struct, workspace and named views for batch size B (cached).  GeneDropout changes the
@@ -171,6 +182,10 @@ class ElboStep:
         cfg, ws, nbytes, v = self._plans[key]
         cfg.loss_scale = float(loss_scale)
         cfg.kl_weight = self.kl_weight
+        wm = self.weight_maxima
+        cfg.weight_max_enc = wm[0].data_ptr() if wm is not None else None
+        cfg.weight_max_heads = wm[1].data_ptr() if wm is not None else None
+        cfg.weight_max_n = wm.shape[1] if wm is not None else 0
         cfg.x_dtype = 0
         return cfg, ws, nbytes, v
 

@@ -98,6 +98,7 @@ class LitVAE(nn.Module):
         self._fused: Optional[ElboStep] = None
         self._fused_val: Optional[ElboStep] = None
         self._l1 = None
+        self.weight_maxima_source = None   # a FusedAdamW(track_weight_maxima=True): the fused step then skips its weight scan
         self._create_results_dict()
         if use_gdro:
             raise NotImplementedError("vae_amd: GroupDRO re-weighting (off in the shipped config) is not wired in")
@@ -268,6 +269,7 @@ class LitVAE(nn.Module):
         if eps_z is None:
             eps_z = torch.empty(B, L, device=gene_vals.device).normal_()
             eps_l = torch.empty(B, 1, device=gene_vals.device).normal_()
+        self._fused_val.use_weight_maxima(self.weight_maxima_source)
         self._fused_val.kl_weight = self.kl_weight      # KL warm-up: a field of the step's config, not a new step
         out = self._fused_val.infer(gene_vals, eps_z, eps_l, want_px_rate=self.save_gene_vals)
         self.log("recon_loss_val", out["recon_mean"])
@@ -343,6 +345,7 @@ class LitVAE(nn.Module):
                                    precision=self.precision, dropout_rate=p_drop, seed=self.dropout_seed,
                                    input_dropout_rate=p_in, input_dropout_alpha=float(gdrop.alpha), gene_running=running)
             self._fused.rng_step = self.train_step
+        self._fused.use_weight_maxima(self.weight_maxima_source)
         gene_vals, cell_prop_vals, cell_mask = batch[0], batch[1], batch[2]
         B, L = gene_vals.shape[0], self.network.n_latent
         if eps_z is None:  # same draw order as the reference: z-encoder noise, then library noise
