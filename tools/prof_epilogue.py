@@ -27,8 +27,14 @@ def t_ms(fn, n=iters):
     for _ in range(n): fn()
     b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b) / n
-ll, rmax, rsum, S = ops.nbzinb_fwd(True, logits[:, :G], logits[:, G:], x, lib, table)
-tf = t_ms(lambda: ops.nbzinb_fwd(True, logits[:, :G], logits[:, G:], x, lib, table))
+# the streaming forward of the step (statistics handed in, per-strip partials left to the caller), then the per-cell kernel
+fo = torch.stack(ops.nbzinb_fwd(True, logits[:, :G], logits[:, G:], x, lib, table, streaming=True))
+ll, rmax, rsum, S = fo[0], fo[1], fo[2], fo[3]
+tf = t_ms(lambda: ops.nbzinb_fwd(True, logits[:, :G], logits[:, G:], x, lib, table, streaming=True, out=fo, have_stats=True,
+                                 partials_only=True))
+if os.environ.get("PER_CELL") and G <= 32768:
+    tpc = t_ms(lambda: ops.nbzinb_fwd(True, logits[:, :G], logits[:, G:], x, lib, table))
+    print(f"per-cell forward kernel {tpc*1e3:.1f} us")
 tb = t_ms(lambda: ops.nbzinb_bwd(True, logits[:, :G], logits[:, G:], x, lib, table, rmax, rsum, S, None, -1e-5, dl[:, :G], dl[:, G:],
                    dlib, dpxr, dbs, dbp, deterministic=det))
 print(f"B={B} G={G} det={det} wg={os.environ.get('VAE_BWD_WORKGROUPS')} fwd {tf*1e3:.1f} us ({12*B*G/tf/1e6:.0f} GB/s)  bwd {tb*1e3:.1f} us ({20*B*G/tb/1e6:.0f} GB/s)")

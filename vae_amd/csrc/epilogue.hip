@@ -45,6 +45,14 @@ __device__ __forceinline__ float flog(float v) { return __builtin_amdgcn_logf(v)
 __device__ __forceinline__ float fexp(float v) { return __builtin_amdgcn_exp2f(v * 1.44269504088896341f); }
 __device__ __forceinline__ float frcp(float v) { return __builtin_amdgcn_rcpf(v); }
 __device__ __forceinline__ float fexp_acc(float v) { return vae_exp_acc(v); }   // compensated exp (common.h)
+// softmax weight exp(l - lse) of the streaming passes: ONE fused multiply-add (l * log2(e) - lse * log2(e), the second
+// product precomputed per cell) and the hardware exp2.  |l - lse| <= ~25, so the single rounding of the argument is
+// <= 2e-6 absolute = 1.3e-6 relative in the weight; the forward, the backward and the px_rate export use the SAME
+// expression, so S_b, the gradients and the exported mean stay mutually consistent (the statistics keep the compensated exp).
+constexpr float LOG2E = 1.44269504088896341f;
+__device__ __forceinline__ float softmax_w(float l, float neg_lse_log2e) {
+  return __builtin_amdgcn_exp2f(fmaf(l, LOG2E, neg_lse_log2e));
+}
 __device__ __forceinline__ float fsoftplus(float v) { return v > 20.f ? v : flog(1.f + fexp(v)); }
 __device__ __forceinline__ float fsigmoid20(float v) {  // softplus'(v) as torch evaluates it
   const float z = fexp(fminf(v, 20.f));
@@ -366,7 +374,10 @@ __global__ __launch_bounds__(THREADS, 4) void nbzinb_fwd_kernel(
 // by the ELBO reduction (deterministic).
 constexpr int BWD_STRIP = 1024;   // 256 threads x float4
 constexpr int BWD_MAX_ROWS = 64;  // cells per workgroup (per-cell constants staged in LDS)
-constexpr int FWD_STRIP = BWD_STRIP;   // one grid function serves both directions
+constexpr int FWD_STRIP = BWD_STRIP;
+constexpr int FWD_MAX_ROWS = 64;  // cells per workgroup of the streaming forward
+// (98 registers = 4 waves per SIMD; compiled for 5 (8 spills) or 6 (24 spills) the pass takes the same 40.6 us at
+// B = 512: occupancy is not what bounds it -- profiles/r02_pmc_epilogue.txt)
 
 // One workgroup per cell: running (max, sum of exp(v - max)) per thread over the row, merged across the workgroup.
 template <bool VEC>
@@ -422,12 +433,15 @@ __global__ __launch_bounds__(256) void nbzinb_fwd_tiled_kernel(
     const float* __restrict__ ls, int64_t ld_s, const float* __restrict__ lp, int64_t ld_p, const XT* __restrict__ x,
     int64_t ld_x, const float* __restrict__ library, const float* __restrict__ T, const float* __restrict__ rowmax,
     const float* __restrict__ rowsum, int B, int G, int rows_per_block, float* __restrict__ part) {
-  __shared__ float2 rc[BWD_MAX_ROWS];         // per cell: {max + log(sum exp), exp(library)}
-  __shared__ float2 red[BWD_MAX_ROWS][4];     // per cell and wave: {sum ll, sum a}
+  __shared__ float2 rc[FWD_MAX_ROWS];         // per cell: {-(max + log(sum exp)) log2(e), exp(library)}
+  // per cell and wave: {sum ll, sum a}.  (Per-THREAD partials in LDS, reduced once at the end, were measured: the same
+  // 41 us, and 32 KB of LDS per workgroup caps the occupancy at four workgroups.)
+  __shared__ float2 red[FWD_MAX_ROWS][4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b0 = blockIdx.y * rows_per_block;
   const int b1 = min(B, b0 + rows_per_block);
-  for (int r = tid; r < b1 - b0; r += 256) rc[r] = make_float2(rowmax[b0 + r] + logf(rowsum[b0 + r]), expf(library[b0 + r]));
+  for (int r = tid; r < b1 - b0; r += 256)
+    rc[r] = make_float2(-(rowmax[b0 + r] + logf(rowsum[b0 + r])) * LOG2E, expf(library[b0 + r]));
   __syncthreads();
   // lanes past the last gene keep running (the wave reductions need every lane): clamped addresses, zero weight
   const int g_raw = blockIdx.x * FWD_STRIP + tid * 4;
@@ -475,13 +489,13 @@ __global__ __launch_bounds__(256) void nbzinb_fwd_tiled_kernel(
     float sll = 0.f, sa = 0.f;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const float p = fexp_acc(l4[j] - k.x);      // softmax weight, as the backward evaluates it
+      const float p = softmax_w(l4[j], k.x);      // softmax weight, as the backward evaluates it
       const Fwd f = elem_fwd<ZINB>(x4[j], k.y * p, p4[j], th[j], lt[j], it[j], d0[j], Tg[j], G);
-      sll += j < nv ? f.ll : 0.f;
-      sa += j < nv ? f.a : 0.f;
+      sll += (VEC || j < nv) ? f.ll : 0.f;        // VEC: G % 4 == 0, a thread's four genes are all valid or all past G
+      sa += (VEC || j < nv) ? f.a : 0.f;
     }
-    sll = wave_sum(sll);
-    sa = wave_sum(sa);
+    sll = wave_sum(nv > 0 ? sll : 0.f);
+    sa = wave_sum(nv > 0 ? sa : 0.f);
     if (lane == 0) red[b - b0][wave] = make_float2(sll, sa);
     c0 = c1;
     c1 = c2;
@@ -522,12 +536,12 @@ __global__ __launch_bounds__(256) void px_rate_kernel(const float* __restrict__ 
   const int b = blockIdx.y;
   const int i = blockIdx.x * 256 + threadIdx.x;  // float4 index in the row
   if (4 * i >= G) return;
-  const float m = rowmax[b] + logf(rowsum[b]);
+  const float m = -(rowmax[b] + logf(rowsum[b])) * LOG2E;
   const float scale = expf(library[b]);
   const float4 l = ld4<VEC>(ls + (int64_t)b * ld_s, i, G, 0.f);
   float4 r;
-  r.x = scale * fexp_acc(l.x - m); r.y = scale * fexp_acc(l.y - m);
-  r.z = scale * fexp_acc(l.z - m); r.w = scale * fexp_acc(l.w - m);
+  r.x = scale * softmax_w(l.x, m); r.y = scale * softmax_w(l.y, m);
+  r.z = scale * softmax_w(l.z, m); r.w = scale * softmax_w(l.w, m);
   float* o = out + (int64_t)b * ld_o;
   if (VEC) {
     reinterpret_cast<float4*>(o)[i] = r;
@@ -562,7 +576,7 @@ __global__ __launch_bounds__(256) void nbzinb_bwd_kernel(
     int G, int rows_per_block, float* dls, int64_t ld_ds, float* dlp, int64_t ld_dp, float* __restrict__ dlibrary,
     float* __restrict__ dpx_r, float* __restrict__ dbias_s, float* __restrict__ dbias_p, float* __restrict__ slab,
     float* __restrict__ absmax) {
-  __shared__ float4 rc[BWD_MAX_ROWS];  // per cell: {max + log(sumexp), exp(library), S_b, delta_b}
+  __shared__ float4 rc[BWD_MAX_ROWS];  // per cell: {-(max + log(sumexp)) log2(e), exp(library), S_b, delta_b}
   __shared__ unsigned int wg_absmax;    // max |gradient| written by this workgroup (absmax != null), as float bits
   if (threadIdx.x == 0) wg_absmax = 0u;
   float am = 0.f;
@@ -572,7 +586,7 @@ __global__ __launch_bounds__(256) void nbzinb_bwd_kernel(
   for (int r = threadIdx.x; r < b1 - b0; r += 256) {
     const int b = b0 + r;
     const float delta = g_scalar * (g_ll ? g_ll[b] : 1.f);
-    rc[r] = make_float4(rowmax[b] + logf(rowsum[b]), expf(library[b]), S[b], delta);
+    rc[r] = make_float4(-(rowmax[b] + logf(rowsum[b])) * LOG2E, expf(library[b]), S[b], delta);
     if (blockIdx.x == 0 && dlibrary) dlibrary[b] = delta * S[b];
   }
   __syncthreads();
@@ -616,7 +630,7 @@ __global__ __launch_bounds__(256) void nbzinb_bwd_kernel(
     float o_s[4], o_p[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const float p = fexp_acc(l4[j] - k.x);
+      const float p = softmax_w(l4[j], k.x);
       const Bwd e = elem_bwd<ZINB>(x4[j], k.y * p, p4[j], th[j], lt[j], it[j], d0[j], Tg[j], G);
       o_s[j] = k.w * (e.a - p * k.z);
       o_p[j] = k.w * e.dpi;
@@ -928,9 +942,16 @@ extern "C" int vae_nbzinb_bwd_u8(int zinb, const float* logit_scale, int64_t ld_
 }
 
 // ---- forward, streaming form (host side) ----------------------------------------------------------------------------
+namespace {
+void fwd_grid(int64_t B, int64_t G, int* strips, int* chunks, int* rows_per_block) {
+  bwd_grid(B, G, strips, chunks, rows_per_block);
+  if (*rows_per_block > FWD_MAX_ROWS) *rows_per_block = FWD_MAX_ROWS;
+  *chunks = (int)((B + *rows_per_block - 1) / *rows_per_block);
+}
+}  // namespace
 extern "C" int64_t vae_nbzinb_fwd_workspace_bytes(int64_t B, int64_t G) {
   int strips, chunks, rpb;
-  bwd_grid(B, G, &strips, &chunks, &rpb);
+  fwd_grid(B, G, &strips, &chunks, &rpb);
   return (int64_t)strips * 2 * B * (int64_t)sizeof(float);
 }
 
@@ -959,7 +980,8 @@ int vae_nbzinb_fwd_tiled_ex(int x_dtype, int zinb, const float* logit_scale, int
     VAE_CHECK_LAUNCH("vae_nbzinb_fwd_ws(stats)");
   }
   int strips, chunks, rows_per_block;
-  bwd_grid(B, G, &strips, &chunks, &rows_per_block);
+  fwd_grid(B, G, &strips, &chunks, &rows_per_block);
+  VAE_REQUIRE(chunks <= 65535, "vae_nbzinb_fwd_ws: batch too large for one launch (B <= 16 * 65535)");
   const dim3 grid(strips, chunks);
 #define LAUNCH_FT(Z, V, XT_)                                                                                              \
   hipLaunchKernelGGL((nbzinb_fwd_tiled_kernel<Z, V, XT_>), grid, dim3(256), 0, st, logit_scale, ld_s, logit_dropout, ld_p,   \
