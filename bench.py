@@ -122,7 +122,10 @@ def kernel_breakdown(arena, cfg, x, precision):
     ks["gemm_dec_fwd"] = (time_kernel(lambda: mm(ops.NT, px, w_heads, logits)), "mfma", fl(B, NH, Hd))
     if P == ops.F16X2:
         sc[id(logits)] = ops.absmax_scale(logits)
-    ks["gemm_dec_wgrad"] = (time_kernel(lambda: mm(ops.TN, logits, px, gw_heads)), "mfma", fl(NH, Hd, B))
+    # the decoder wgrad runs the exact three-term split in both fp32-grade modes (step.hip: per-gene dynamic range of dlogits)
+    wg = (lambda: ops.gemm(ops.TN, logits, px, out=gw_heads, precision=ops.FP32)) if P == ops.F16X2 else \
+        (lambda: mm(ops.TN, logits, px, gw_heads))
+    ks["gemm_dec_wgrad"] = (time_kernel(wg), "mfma", fl(NH, Hd, B))
     ks["gemm_dec_dgrad"] = (time_kernel(lambda: mm(ops.NN, logits, w_heads)), "mfma", fl(B, Hd, NH))
     ks["gemm_enc_wgrad"] = (time_kernel(lambda: mm(ops.TN, dpre, xn, gw_enc)), "mfma", fl(H + Hl, G, B))
     logits.normal_()
@@ -158,7 +161,7 @@ def pmc_traffic(config, precision, B, kernel):
     if not rec:
         return None
     return {"bytes": rec["fetch_bytes"] + rec["write_bytes"], "fetch_bytes": rec["fetch_bytes"], "write_bytes": rec["write_bytes"],
-            "unit": "B per launch", "source": rec.get("source")}
+            "unit": "B per launch", "mfma_busy_frac": rec.get("mfma_util"), "source": rec.get("source")}
 
 
 def cpu_baseline(cfg, threads):
