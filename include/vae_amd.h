@@ -95,6 +95,20 @@ int vae_gemm_scaled_slabs(int layout, int64_t M, int64_t N, int64_t K, const flo
                           const float* B, int64_t ldb, const float* scale_b, float* workspace, int64_t workspace_bytes,
                           int* n_slabs, void* stream);
 
+/* VAE_BF16 products with ONE operand, or the output, stored as bf16 in HBM (io = exactly one VAE_IO_* bit; the other
+ * matrices fp32).  This is the reference's autocast(bfloat16) storage (config.py:87: nn.Linear outputs are bf16 tensors,
+ * and what autograd saves / hands to the wgrad and dgrad products is bf16): the bytes of the three gene-sized
+ * activations (normalised counts, logits, logit gradients) halve.  Rounding an operand to bf16 when it is WRITTEN is
+ * bit-identical to rounding it when the product reads it (vae_gemm(VAE_BF16)); a bf16 OUTPUT is the fp32 accumulator + bias
+ * rounded to nearest even.  Leading dimensions count elements of the matrix's own type; bf16 matrices need 8-byte
+ * aligned rows (the output: 16-byte, ldc % 8 == 0).  Shapes: vae_gemm_bf16_storage_ok() != 0 (the 128-wide tile pipeline:
+ * no dimension <= 64, K % 4 == 0, 16-byte rows); layouts: A bf16 in any, B bf16 in VAE_TN, C bf16 in VAE_NT. */
+enum { VAE_IO_A_BF16 = 1, VAE_IO_B_BF16 = 2, VAE_IO_C_BF16 = 4 };
+int vae_gemm_bf16_storage_ok(int layout, int io, int64_t M, int64_t N, int64_t K);
+int vae_gemm_bf16_storage(int layout, int io, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B,
+                          int64_t ldb, void* C, int64_t ldc, const float* bias, float* workspace, int64_t workspace_bytes,
+                          void* stream);
+
 /* ---- row kernels ----------------------------------------------------------------------------- */
 /* mean[b] = mean_g x[b,g]                                   Encoder.forward, modules.py:264      */
 int vae_row_mean(const float* x, int64_t ldx, int64_t B, int64_t G, float* mean, void* stream);
@@ -314,6 +328,12 @@ typedef struct {
   float *dec_ln_g[VAE_MAX_LAYERS], *dec_ln_b[VAE_MAX_LAYERS];   /* (Hd)                              */
   float *heads_w, *heads_b;                      /* (2G or G, Hd), (2G or G)                         */
 } vae_step_tensors;
+
+/* != 0 when a step of this configuration keeps its gene-sized activations (the decoder-head logits and their
+ * gradients) as bf16 in the workspace: precision == VAE_BF16 and shapes on the tile pipeline (G % 8 == 0, B > 64, ...).
+ * This is the reference's autocast(bfloat16) storage (config.py:87); the parity tests pick the oracle definition with
+ * it (oracle/vae_oracle.py, logits_bf16).  Environment VAE_BF16_F32_STORAGE=1 switches it off (A/B measurements). */
+int vae_elbo_step_bf16_activations(const vae_step_config* cfg);
 
 /* named slices of the workspace that a caller may read after the forward (offsets in floats)      */
 enum { VAE_WS_QZ_HEADS = 0, /* (B, L+1): [:, :L] = qz_m                                            */

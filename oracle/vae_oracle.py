@@ -18,6 +18,10 @@ restatement reproduces them.  The reference itself never travels to the GPU box.
 bf16 mode (``gemm_dtype=torch.bfloat16``): defined by this project (SURVEY.md §5,
 "Mixed precision") as: both operands of every Linear GEMM are rounded to bf16
 (round-to-nearest-even), products accumulate in fp32, every other op is fp32.
+``logits_bf16=True`` adds what the reference's autocast(bfloat16) does to the two gene-sized decoder heads
+(config.py:87: an nn.Linear under autocast RETURNS a bf16 tensor): their outputs (accumulator + bias) are rounded to
+bf16 before the softmax / the likelihood read them; the gradient passes the rounding unchanged (as a dtype cast does
+in autograd).  The product path stores those logits as bf16 for shapes on its tile pipeline.
 """
 from __future__ import annotations
 
@@ -122,12 +126,19 @@ def encoder_forward(p, prefix: str, x: Tensor, noise: Tensor, n_layers: int, gem
     return q_m, q_v, latent
 
 
-def decoder_forward(p, z: Tensor, library: Tensor, n_layers: int, gemm_dtype=None, masks=None, cov=None):
+def _as_bf16_tensor(y: Tensor) -> Tensor:
+    """Value of y after a round trip through a bf16 tensor; gradient = identity (what a dtype cast back-propagates)."""
+    return y + (y.detach().to(torch.bfloat16).to(y.dtype) - y.detach())
+
+
+def decoder_forward(p, z: Tensor, library: Tensor, n_layers: int, gemm_dtype=None, masks=None, cov=None, logits_bf16=False):
     """DecoderSCVI.forward for dispersion != 'gene-cell'; modules.py:371-406."""
     px = fc_layers(p, "decoder.px_decoder", z, n_layers, gemm_dtype, masks, cov)
     logit_scale = _linear(px, p["decoder.px_scale_decoder.0.weight"], p["decoder.px_scale_decoder.0.bias"], gemm_dtype)
-    px_scale = torch.softmax(logit_scale, dim=-1)
     px_dropout = _linear(px, p["decoder.px_dropout_decoder.weight"], p["decoder.px_dropout_decoder.bias"], gemm_dtype)
+    if logits_bf16:
+        logit_scale, px_dropout = _as_bf16_tensor(logit_scale), _as_bf16_tensor(px_dropout)
+    px_scale = torch.softmax(logit_scale, dim=-1)
     px_rate = torch.exp(library) * px_scale
     return px_scale, px_rate, px_dropout
 
@@ -195,6 +206,7 @@ def training_step(
     x_z: Optional[Tensor] = None,
     dispersion: str = "gene",
     cov: Optional[Tensor] = None,
+    logits_bf16: bool = False,
 ) -> Dict[str, Tensor]:
     """Forward of one training step; returns every intermediate the goldens pin.
 
@@ -208,7 +220,7 @@ def training_step(
     qz_m, qz_v, z = encoder_forward(p, "z_encoder", x if x_z is None else x_z, eps_z, n_layers, gemm_dtype,
                                     dm.get("z_encoder"), cov)
     ql_m, ql_v, library = encoder_forward(p, "l_encoder", x, eps_l, 1, gemm_dtype, None, cov)  # networks.py:215-222
-    px_scale, px_rate, px_dropout = decoder_forward(p, z, library, n_layers, gemm_dtype, dm.get("decoder"), cov)
+    px_scale, px_rate, px_dropout = decoder_forward(p, z, library, n_layers, gemm_dtype, dm.get("decoder"), cov, logits_bf16)
     if dispersion == "gene":
         theta = torch.exp(p["px_r"])  # task.py:481-483
     elif dispersion == "gene-cell":

@@ -54,12 +54,12 @@ def _run_both(B, G, H, Hd, Hl, L, n_layers, precision, *, heads=False, seed=43, 
     cast = (lambda t: t.float()) if bf16 else (lambda t: t.double())
     if heads:
         kw.update(cell_targets=cast(targets), cell_mask=cast(mask))
-    if bf16:
-        kw.update(gemm_dtype=torch.bfloat16)
-    o_out, o_grads = O.training_step_with_grads({k: cast(v) for k, v in p.items()}, cast(x), cast(eps_z), cast(eps_l), **kw)
-
     arena = ParamArena(p, n_layers, likelihood, "cuda")
     step = ElboStep(arena, l_mean=lm, l_var=lv, precision=precision)
+    if bf16:   # at these sizes the step keeps the logits as bf16 tensors, as autocast does: the oracle that rounds them
+        assert step.bf16_activations(B) == (B > 64 and G % 8 == 0)
+        kw.update(gemm_dtype=torch.bfloat16, logits_bf16=step.bf16_activations(B))
+    o_out, o_grads = O.training_step_with_grads({k: cast(v) for k, v in p.items()}, cast(x), cast(eps_z), cast(eps_l), **kw)
     fn = None
     if heads:
         from vae_amd.modules import CellDecoder
@@ -225,3 +225,42 @@ def test_per_gene_row_gradient_accuracy_over_24_octaves(precision):
     for k, val in report.items():
         print("row accuracy", "f16x2" if precision == 3 else "bf16x3", k[0], "rows" if k[1] else "gene columns",
               {a: (f"{b:.2e}" if isinstance(b, float) else b) for a, b in val.items()})
+
+
+@pytest.mark.parametrize("counts", ["f32", "u8"])
+def test_bf16_storage_with_gene_dropout_and_inference(counts):
+    """A bf16-mode step whose shapes are on the tile pipeline keeps xn, the logits and their gradients as bf16:
+    with GeneDropout (one encoder product per encoder, the masked xn also bf16) and hidden dropout vs the bf16 oracle fed
+    the host-regenerated masks; then the inference step's px_rate (vae_elbo_step_px_rate reads the bf16 logits)."""
+    from oracle import vae_oracle as O
+    from vae_amd.arena import ParamArena
+    from vae_amd.step import ElboStep
+    from helpers import dropout_multiplier, gene_dropout_keep
+    B, G, H, Hd, Hl, L = 256, 4000, 128, 128, 128, 10
+    p_in, p_hid, alpha, seed = 0.5, 0.25, 0.95, 777
+    p = O.init_params(G, H, Hd, Hl, L, 1, seed=19)
+    arena = ParamArena(p, 1, "zinb", "cuda")
+    gen = torch.Generator().manual_seed(20)
+    step = ElboStep(arena, l_mean=5.0, l_var=1.5, dropout_rate=p_hid, seed=seed, input_dropout_rate=p_in,
+                    input_dropout_alpha=alpha, precision=1)
+    assert step.bf16_activations(B, train=True) and step.bf16_activations(B)
+    x = O.synthetic_counts(B, G, seed=21, zero_inflate=0.4).clamp(max=255)
+    eps_z, eps_l = torch.randn(B, L, generator=gen), torch.randn(B, 1, generator=gen)
+    xd = x.to(torch.uint8).cuda() if counts == "u8" else x.cuda()
+    out = step.run(xd, eps_z.cuda(), eps_l.cuda(), rng_step=5)
+    torch.cuda.synchronize()
+    thr = out["gene_threshold"].cpu().numpy().view(np.uint32)
+    keep = gene_dropout_keep(thr, seed, 5, B)
+    x_z = x * torch.from_numpy(keep).float()
+    masks = {"z_encoder": [torch.from_numpy(dropout_multiplier(p_hid, seed, 5, 0, B, H)).float()],
+             "decoder": [torch.from_numpy(dropout_multiplier(p_hid, seed, 5, 2, B, Hd)).float()]}
+    kw = dict(n_layers=1, likelihood="zinb", l_mean=5.0, l_var=1.5, gemm_dtype=torch.bfloat16, logits_bf16=True)
+    o_out, o_grads = O.training_step_with_grads(p, x, eps_z, eps_l, drop_masks=masks, x_z=x_z, **kw)
+    _check(o_out, o_grads, out, arena, TOL_CELL_BF16, TOL_GRAD_BF16, 20)
+    # inference: forward only, no masks; the exported mean is the one the likelihood used
+    ev = step.infer(xd, eps_z.cuda(), eps_l.cuda(), want_px_rate=True)
+    o_plain = O.training_step(p, x, eps_z, eps_l, **kw)
+    assert abs(float(ev["loss"]) - float(o_plain["loss"])) < TOL_CELL_BF16 * abs(float(o_plain["loss"]))
+    r, r0 = ev["px_rate"].cpu().double().numpy(), o_plain["px_rate"].double().numpy()
+    assert np.max(np.abs(r - r0) / r0.max(axis=1, keepdims=True)) < 2e-2      # one bf16 ulp of a logit = 0.4 % of a rate
+    assert np.median(np.abs(r - r0) / r0) < 2e-3

@@ -139,6 +139,56 @@ def test_gemm_bf16(ops, layout, shape):
     assert rel_err(out.cpu().numpy(), ref.numpy()) < 1e-5  # operands rounded identically; fp32 accumulate
 
 
+@pytest.mark.parametrize("case", [
+    # (layout, io, M, N, K): the five gene-sized products of a bf16-mode step, reduced; ragged M / N edges, K tails, split-K
+    (0, 1, 520, 384, 4100), (0, 4, 516, 4104, 256), (0, 4, 2304, 4000, 128), (2, 1, 4104, 256, 516), (1, 1, 516, 256, 4104),
+    (2, 2, 384, 4100, 520), (0, 1, 384, 388, 1028), (2, 2, 260, 2052, 520),
+])
+def test_gemm_bf16_storage(ops, case):
+    """vae_gemm_bf16_storage: an operand that is ALREADY bf16 in HBM gives the bits of vae_gemm(VAE_BF16) on its fp32
+    image (rounding at the write = rounding at the read); a bf16 output is vae_gemm(VAE_BF16)'s fp32 result + bias rounded
+    to nearest even -- exact, because both run the same kernel with the same tiles."""
+    layout, io, M, N, K = case
+    a64, b64, bias64 = _rand((M, K), 51), _rand((K, N), 52, 0.1), _rand((N,), 53)
+    A = (a64 if layout != ops.TN else a64.t().contiguous()).float().cuda()
+    Bm = (b64.t().contiguous() if layout == ops.NT else b64).float().cuda()
+    bias = bias64.float().cuda()
+    if io == ops.IO_A_BF16:
+        A16 = A.bfloat16()
+        want = ops.gemm(layout, A16.float(), Bm, bias=bias, precision=ops.BF16)
+        got = ops.gemm_bf16_storage(layout, A16, Bm, io, bias=bias)
+        # a strided bf16 operand (rows padded), as the step's workspace holds it
+        pad = torch.zeros(A16.shape[0], A16.shape[1] + 8, dtype=torch.bfloat16, device="cuda")
+        pad[:, :A16.shape[1]] = A16
+        got2 = ops.gemm_bf16_storage(layout, pad[:, :A16.shape[1]], Bm, io, bias=bias)
+        assert torch.equal(got2, got)
+    elif io == ops.IO_B_BF16:
+        B16 = Bm.bfloat16()
+        want = ops.gemm(layout, A, B16.float(), bias=bias, precision=ops.BF16)
+        got = ops.gemm_bf16_storage(layout, A, B16, io, bias=bias)
+    else:
+        want = ops.gemm(layout, A, Bm, bias=bias, precision=ops.BF16).bfloat16()
+        big = torch.full((M, N + 16), 7.0, dtype=torch.bfloat16, device="cuda")
+        got = ops.gemm_bf16_storage(layout, A, Bm, io, bias=bias, out=big[:, :N])
+        assert float(big[:, N:].float().min()) == 7.0 and float(big[:, N:].float().max()) == 7.0      # nothing past N
+    torch.cuda.synchronize()
+    assert got.dtype == want.dtype and torch.equal(got, want)
+    ref = A.bfloat16().double().cpu() if layout != ops.TN else A.bfloat16().double().cpu().t()
+    ref = ref @ (Bm.bfloat16().double().cpu().t() if layout == ops.NT else Bm.bfloat16().double().cpu()) + bias64
+    assert rel_err(got.float().cpu().numpy(), ref.numpy()) < (1e-5 if io != ops.IO_C_BF16 else 4e-3)
+
+
+def test_gemm_bf16_storage_refuses_what_it_cannot_run(ops):
+    a = torch.zeros(32, 64, device="cuda")
+    with pytest.raises(ValueError):      # small shapes are outside the tile pipeline
+        ops.gemm_bf16_storage(ops.NT, a.bfloat16(), a, ops.IO_A_BF16)
+    b = torch.zeros(512, 512, device="cuda")
+    with pytest.raises(ValueError):      # B as bf16 exists for the wgrad layout only
+        ops.gemm_bf16_storage(ops.NT, b, b.bfloat16(), ops.IO_B_BF16)
+    with pytest.raises(TypeError):
+        ops.gemm_bf16_storage(ops.NT, b, b, ops.IO_A_BF16)
+
+
 @pytest.mark.parametrize("layout", [0, 2])
 def test_gemm_normalised_counts(ops, layout):
     """x/mean - 1 applied on the fly to the count operand (modules.py:264)."""

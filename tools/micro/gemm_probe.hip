@@ -33,7 +33,7 @@ int main(int argc, char** argv) {
   hipMemset(A, 0, na * 4); hipMemset(B, 0, nb * 4);
   GemmArgs g{};
   g.A = A; g.B = B; g.C = C; g.lda = K; g.ldb = K; g.ldc = N; g.M = M; g.N = N; g.K = K;
-  g.k_per_split = K; g.split = 1; g.vecA = g.vecB = 1; g.tiles_m = (M + 127) / 128; g.tiles_n = (N + PROBE_BN - 1) / PROBE_BN;
+  g.k_per_split = K; g.split = 1; g.vecA = g.vecB = 1; g.vecC = 1; g.group_m = getenv("GROUP") ? atoi(getenv("GROUP")) : 0; g.tiles_m = (M + 127) / 128; g.tiles_n = (N + PROBE_BN - 1) / PROBE_BN;
   if (lay == 1) { /* NN dgrad: M=512, N=256, K=40000 (A (M,K), B (K,N)) split 8 */
     g.lda = 40000; g.ldb = 256; g.ldc = 256; g.M = 512; g.N = 256; g.K = 40000;
     g.tiles_m = 4; g.tiles_n = 2; g.split = 50; g.k_per_split = 800;

@@ -25,6 +25,9 @@ SIGNATURES = {
     "vae_gemm": (_i32, [_i32, _i32, _i64, _i64, _i64, _ptr, _i64, _ptr, _i64, _ptr, _i64, _ptr, _ptr, _i32, _ptr, _i64, _ptr]),
     "vae_gemm_noalloc_max_bytes": (_i64, []),
     "vae_gemm_noalloc": (_i32, [_i32, _i32, _i64, _i64, _i64, _ptr, _i64, _ptr, _i64, _ptr, _i64, _ptr, _ptr, _i32, _ptr]),
+    "vae_elbo_step_bf16_activations": (_i32, [_ptr]),
+    "vae_gemm_bf16_storage_ok": (_i32, [_i32, _i32, _i64, _i64, _i64]),
+    "vae_gemm_bf16_storage": (_i32, [_i32, _i32, _i64, _i64, _i64, _ptr, _i64, _ptr, _i64, _ptr, _i64, _ptr, _ptr, _i64, _ptr]),
     "vae_gemm_slabs_workspace_bytes": (_i64, [_i64, _i64, _i64]),
     "vae_gemm_slabs": (_i32, [_i32, _i32, _i64, _i64, _i64, _ptr, _i64, _ptr, _i64, _ptr, _i64, C.POINTER(C.c_int), _ptr]),
     "vae_px_rate": (_i32, [_ptr, _i64, _ptr, _ptr, _ptr, _i64, _i64, _ptr, _i64, _ptr]),

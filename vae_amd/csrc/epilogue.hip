@@ -269,6 +269,38 @@ __device__ __forceinline__ float4 ld4(const uint8_t* __restrict__ row, int i, in
   return v;
 }
 
+// logits kept as bf16 (a bf16-mode step: the reference's autocast leaves nn.Linear outputs in bf16, config.py:87):
+// 8 B per lane; the element is the upper half of the fp32 pattern.  Vector path only (the step checks the alignment).
+typedef uint16_t bf16_t;
+__device__ __forceinline__ float bf16_up(uint32_t h) { return __uint_as_float(h << 16); }
+template <bool VEC>
+__device__ __forceinline__ float4 ld4(const bf16_t* __restrict__ row, int i, int G, float fill) {
+  if (VEC) {
+    const uint2 u = reinterpret_cast<const uint2*>(row)[i];
+    return make_float4(bf16_up(u.x & 0xffffu), __uint_as_float(u.x & 0xffff0000u), bf16_up(u.y & 0xffffu),
+                       __uint_as_float(u.y & 0xffff0000u));
+  }
+  float4 v;
+  const int g = 4 * i;
+  v.x = g < G ? bf16_up(row[g]) : fill;
+  v.y = g + 1 < G ? bf16_up(row[g + 1]) : fill;
+  v.z = g + 2 < G ? bf16_up(row[g + 2]) : fill;
+  v.w = g + 3 < G ? bf16_up(row[g + 3]) : fill;
+  return v;
+}
+__device__ __forceinline__ bf16_t bf16_rn(float v) { return __builtin_bit_cast(bf16_t, (__bf16)v); }   // nearest even
+__device__ __forceinline__ void st4(float* p, float a, float b, float c, float d) {
+  *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d);
+}
+__device__ __forceinline__ void st4(bf16_t* p, float a, float b, float c, float d) {
+  uint2 u;
+  u.x = (uint32_t)bf16_rn(a) | ((uint32_t)bf16_rn(b) << 16);
+  u.y = (uint32_t)bf16_rn(c) | ((uint32_t)bf16_rn(d) << 16);
+  *reinterpret_cast<uint2*>(p) = u;
+}
+__device__ __forceinline__ void st1(float* p, float v) { *p = v; }
+__device__ __forceinline__ void st1(bf16_t* p, float v) { *p = bf16_rn(v); }
+
 template <bool ZINB, bool VEC, int EPT, int THREADS, typename XT>
 __global__ __launch_bounds__(THREADS, 4) void nbzinb_fwd_kernel(
     const float* __restrict__ ls, int64_t ld_s, const float* __restrict__ lp, int64_t ld_p, const XT* __restrict__ x,
@@ -380,12 +412,12 @@ constexpr int FWD_MAX_ROWS = 64;  // cells per workgroup of the streaming forwar
 // B = 512: occupancy is not what bounds it -- profiles/r02_pmc_epilogue.txt)
 
 // One workgroup per cell: running (max, sum of exp(v - max)) per thread over the row, merged across the workgroup.
-template <bool VEC>
-__global__ __launch_bounds__(256) void softmax_stats_kernel(const float* __restrict__ ls, int64_t ld_s, int G,
+template <bool VEC, typename LT>
+__global__ __launch_bounds__(256) void softmax_stats_kernel(const LT* __restrict__ ls, int64_t ld_s, int G,
                                                             float* __restrict__ rowmax, float* __restrict__ rowsum) {
   __shared__ float red[4];
   const int b = blockIdx.x, tid = threadIdx.x;
-  const float* r_s = ls + (int64_t)b * ld_s;
+  const LT* r_s = ls + (int64_t)b * ld_s;
   const int n4 = (G + 3) >> 2;
   const float NEG = -INFINITY;
   float m = NEG, s = 0.f;
@@ -428,9 +460,9 @@ __global__ __launch_bounds__(256) void softmax_stats_merge_kernel(const float* _
 
 struct RowInF { float4 l, p, x; };
 
-template <bool ZINB, bool VEC, typename XT>
+template <bool ZINB, bool VEC, typename XT, typename LT>
 __global__ __launch_bounds__(256) void nbzinb_fwd_tiled_kernel(
-    const float* __restrict__ ls, int64_t ld_s, const float* __restrict__ lp, int64_t ld_p, const XT* __restrict__ x,
+    const LT* __restrict__ ls, int64_t ld_s, const LT* __restrict__ lp, int64_t ld_p, const XT* __restrict__ x,
     int64_t ld_x, const float* __restrict__ library, const float* __restrict__ T, const float* __restrict__ rowmax,
     const float* __restrict__ rowsum, int B, int G, int rows_per_block, float* __restrict__ part) {
   __shared__ float2 rc[FWD_MAX_ROWS];         // per cell: {-(max + log(sum exp)) log2(e), exp(library)}
@@ -527,8 +559,8 @@ __global__ __launch_bounds__(256) void fwd_partials_finish_kernel(const float* _
 // ---- px_rate export (validation / inference: LitVAE.validation_step, task.py:240,263) ------
 // px_rate[b,g] = exp(library[b]) * exp(l[b,g] - max_b) / sum_b: the mu the likelihood pass above used
 // (same expression, same rounding), from the row statistics it saved.  Grid (strips of 1024 genes, cells).
-template <bool VEC>
-__global__ __launch_bounds__(256) void px_rate_kernel(const float* __restrict__ ls, int64_t ld_s,
+template <bool VEC, typename LT>
+__global__ __launch_bounds__(256) void px_rate_kernel(const LT* __restrict__ ls, int64_t ld_s,
                                                       const float* __restrict__ library,
                                                       const float* __restrict__ rowmax,
                                                       const float* __restrict__ rowsum, int G, float* __restrict__ out,
@@ -558,8 +590,8 @@ __global__ __launch_bounds__(256) void px_rate_kernel(const float* __restrict__ 
 
 struct RowIn { float4 l, p, x; };
 
-template <bool ZINB, bool VEC, typename XT>
-__device__ __forceinline__ RowIn load_row(const float* ls, int64_t ld_s, const float* lp, int64_t ld_p,
+template <bool ZINB, bool VEC, typename XT, typename LT>
+__device__ __forceinline__ RowIn load_row(const LT* ls, int64_t ld_s, const LT* lp, int64_t ld_p,
                                           const XT* __restrict__ x, int64_t ld_x, int b, int g0, int G) {
   RowIn r;
   r.l = ld4<VEC>(ls + (int64_t)b * ld_s, g0 >> 2, G, 0.f);
@@ -568,12 +600,12 @@ __device__ __forceinline__ RowIn load_row(const float* ls, int64_t ld_s, const f
   return r;
 }
 
-template <bool ZINB, bool VEC, bool SLAB, typename XT>
+template <bool ZINB, bool VEC, bool SLAB, typename XT, typename LT>
 __global__ __launch_bounds__(256) void nbzinb_bwd_kernel(
-    const float* ls, int64_t ld_s, const float* lp, int64_t ld_p, const XT* __restrict__ x, int64_t ld_x,
+    const LT* ls, int64_t ld_s, const LT* lp, int64_t ld_p, const XT* __restrict__ x, int64_t ld_x,
     const float* __restrict__ library, const float* __restrict__ T, const float* __restrict__ rowmax,
     const float* __restrict__ rowsum, const float* __restrict__ S, const float* __restrict__ g_ll, float g_scalar, int B,
-    int G, int rows_per_block, float* dls, int64_t ld_ds, float* dlp, int64_t ld_dp, float* __restrict__ dlibrary,
+    int G, int rows_per_block, LT* dls, int64_t ld_ds, LT* dlp, int64_t ld_dp, float* __restrict__ dlibrary,
     float* __restrict__ dpx_r, float* __restrict__ dbias_s, float* __restrict__ dbias_p, float* __restrict__ slab,
     float* __restrict__ absmax) {
   __shared__ float4 rc[BWD_MAX_ROWS];  // per cell: {-(max + log(sumexp)) log2(e), exp(library), S_b, delta_b}
@@ -605,9 +637,9 @@ __global__ __launch_bounds__(256) void nbzinb_bwd_kernel(
   //   stage A (cell b+2): HBM loads of (logit_scale, logit_dropout, x)
   //   stage B (cell b+1): x has landed -> issue the count-indexed table loads (L2)
   //   stage C (cell b)  : evaluate, store both gradients (they alias the logits of cell b only)
-  RowIn c0 = load_row<ZINB, VEC, XT>(ls, ld_s, lp, ld_p, x, ld_x, b0, g0, G);
+  RowIn c0 = load_row<ZINB, VEC, XT, LT>(ls, ld_s, lp, ld_p, x, ld_x, b0, g0, G);
   RowIn c1 = c0;
-  if (b0 + 1 < b1) c1 = load_row<ZINB, VEC, XT>(ls, ld_s, lp, ld_p, x, ld_x, b0 + 1, g0, G);
+  if (b0 + 1 < b1) c1 = load_row<ZINB, VEC, XT, LT>(ls, ld_s, lp, ld_p, x, ld_x, b0 + 1, g0, G);
   float d0[4], d1[4] = {0.f, 0.f, 0.f, 0.f};
   {
     const float xv[4] = {c0.x.x, c0.x.y, c0.x.z, c0.x.w};
@@ -622,7 +654,7 @@ __global__ __launch_bounds__(256) void nbzinb_bwd_kernel(
       for (int j = 0; j < 4; ++j) d1[j] = Tg[j][(ROW_DGD + tab_index(xv[j])) * G];
     }
     RowIn c2 = c1;
-    if (b + 2 < b1) c2 = load_row<ZINB, VEC, XT>(ls, ld_s, lp, ld_p, x, ld_x, b + 2, g0, G);
+    if (b + 2 < b1) c2 = load_row<ZINB, VEC, XT, LT>(ls, ld_s, lp, ld_p, x, ld_x, b + 2, g0, G);
     const float4 k = rc[b - b0];
     const float l4[4] = {c0.l.x, c0.l.y, c0.l.z, c0.l.w};
     const float p4[4] = {c0.p.x, c0.p.y, c0.p.z, c0.p.w};
@@ -639,17 +671,17 @@ __global__ __launch_bounds__(256) void nbzinb_bwd_kernel(
       acc_s[j] += o_s[j];
       acc_p[j] += o_p[j];
     }
-    float* w_s = dls + (int64_t)b * ld_ds + g0;
-    float* w_p = ZINB ? dlp + (int64_t)b * ld_dp + g0 : nullptr;
+    LT* w_s = dls + (int64_t)b * ld_ds + g0;
+    LT* w_p = ZINB ? dlp + (int64_t)b * ld_dp + g0 : nullptr;
     if (VEC) {
-      *reinterpret_cast<float4*>(w_s) = make_float4(o_s[0], o_s[1], o_s[2], o_s[3]);
-      if (ZINB) *reinterpret_cast<float4*>(w_p) = make_float4(o_p[0], o_p[1], o_p[2], o_p[3]);
+      st4(w_s, o_s[0], o_s[1], o_s[2], o_s[3]);
+      if (ZINB) st4(w_p, o_p[0], o_p[1], o_p[2], o_p[3]);
     } else {
 #pragma unroll
       for (int j = 0; j < 4; ++j)
         if (j < nv) {
-          w_s[j] = o_s[j];
-          if (ZINB) w_p[j] = o_p[j];
+          st1(w_s + j, o_s[j]);
+          if (ZINB) st1(w_p + j, o_p[j]);
         }
     }
     c0 = c1;
@@ -798,21 +830,34 @@ extern "C" int vae_nbzinb_fwd_u8(int zinb, const float* logit_scale, int64_t ld_
                                   rowmax, rowsum, S, stream);
 }
 
-extern "C" int vae_px_rate(const float* logit_scale, int64_t ld_s, const float* library, const float* rowmax,
-                           const float* rowsum, int64_t B, int64_t G, float* px_rate, int64_t ld_r, void* stream) {
+static bool logits_aligned(const void* p, int l_dtype) {
+  return l_dtype == VAE_L_BF16 ? (reinterpret_cast<uintptr_t>(p) & 7u) == 0 : vae_aligned16(p);
+}
+
+int vae_px_rate_ex(int l_dtype, const void* logit_scale, int64_t ld_s, const float* library, const float* rowmax,
+                   const float* rowsum, int64_t B, int64_t G, float* px_rate, int64_t ld_r, void* stream) {
   VAE_REQUIRE(logit_scale && library && rowmax && rowsum && px_rate, "vae_px_rate: null pointer");
   VAE_REQUIRE(B > 0 && B <= 65535 && G > 0 && ld_s >= G && ld_r >= G, "vae_px_rate: bad shape B=%lld G=%lld", (long long)B,
               (long long)G);
-  const bool vec = (G % 4 == 0) && (ld_s % 4 == 0) && (ld_r % 4 == 0) && vae_aligned16(logit_scale) && vae_aligned16(px_rate);
+  const bool vec = (G % 4 == 0) && (ld_s % 4 == 0) && (ld_r % 4 == 0) && logits_aligned(logit_scale, l_dtype) && vae_aligned16(px_rate);
   const dim3 grid((unsigned)((G + 1023) / 1024), (unsigned)B);
-  if (vec)
-    hipLaunchKernelGGL(px_rate_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, logit_scale, ld_s, library, rowmax,
-                       rowsum, (int)G, px_rate, ld_r);
+  if (l_dtype == VAE_L_BF16) {
+    VAE_REQUIRE(vec, "vae_px_rate: bf16 logits need G %% 4 == 0 and aligned rows");
+    hipLaunchKernelGGL((px_rate_kernel<true, bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)logit_scale, ld_s,
+                       library, rowmax, rowsum, (int)G, px_rate, ld_r);
+  } else if (vec)
+    hipLaunchKernelGGL((px_rate_kernel<true, float>), grid, dim3(256), 0, (hipStream_t)stream, (const float*)logit_scale, ld_s,
+                       library, rowmax, rowsum, (int)G, px_rate, ld_r);
   else
-    hipLaunchKernelGGL(px_rate_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, logit_scale, ld_s, library, rowmax,
-                       rowsum, (int)G, px_rate, ld_r);
+    hipLaunchKernelGGL((px_rate_kernel<false, float>), grid, dim3(256), 0, (hipStream_t)stream, (const float*)logit_scale, ld_s,
+                       library, rowmax, rowsum, (int)G, px_rate, ld_r);
   VAE_CHECK_LAUNCH("vae_px_rate");
   return VAE_OK;
+}
+
+extern "C" int vae_px_rate(const float* logit_scale, int64_t ld_s, const float* library, const float* rowmax,
+                           const float* rowsum, int64_t B, int64_t G, float* px_rate, int64_t ld_r, void* stream) {
+  return vae_px_rate_ex(VAE_L_F32, logit_scale, ld_s, library, rowmax, rowsum, B, G, px_rate, ld_r, stream);
 }
 
 namespace {
@@ -840,12 +885,12 @@ int64_t vae_nbzinb_bwd_workgroups(int64_t B, int64_t G) {
   return (int64_t)strips * chunks;
 }
 
-template <typename XT>
-static int nbzinb_bwd_impl(int zinb, const float* logit_scale, int64_t ld_s, const float* logit_dropout, int64_t ld_p,
+template <typename XT, typename LT = float>
+static int nbzinb_bwd_impl(int zinb, const LT* logit_scale, int64_t ld_s, const LT* logit_dropout, int64_t ld_p,
                            const XT* x, int64_t ld_x, const float* library, const float* gene_table,
                            const float* rowmax, const float* rowsum, const float* S, const float* g_ll,
-                           float g_scalar, int64_t B, int64_t G, float* dlogit_scale, int64_t ld_ds,
-                           float* dlogit_dropout, int64_t ld_dp, float* dlibrary, float* dpx_r, float* dbias_scale,
+                           float g_scalar, int64_t B, int64_t G, LT* dlogit_scale, int64_t ld_ds,
+                           LT* dlogit_dropout, int64_t ld_dp, float* dlibrary, float* dpx_r, float* dbias_scale,
                            float* dbias_dropout, float* workspace, int64_t workspace_bytes, void* stream, int overwrite,
                            float* absmax = nullptr, VaeDeferredColreduce* defer = nullptr) {
   VAE_REQUIRE(!overwrite || workspace, "vae_nbzinb_bwd_overwrite: needs the workspace (deterministic mode)");
@@ -856,10 +901,13 @@ static int nbzinb_bwd_impl(int zinb, const float* logit_scale, int64_t ld_s, con
   VAE_REQUIRE(ld_s >= G && ld_x >= G && ld_ds >= G && (!zinb || (ld_p >= G && ld_dp >= G)),
               "vae_nbzinb_bwd: leading dimension too small");
   constexpr bool U8 = sizeof(XT) == 1;
+  constexpr bool L16 = sizeof(LT) == 2;
+  constexpr int LD = L16 ? VAE_L_BF16 : VAE_L_F32;
   const bool x_ok = U8 ? ((reinterpret_cast<uintptr_t>(x) & 3u) == 0) : vae_aligned16(x);
   const bool vec = (G % 4 == 0) && (ld_s % 4 == 0) && (ld_x % 4 == 0) && (ld_ds % 4 == 0) &&
-                   (!zinb || (ld_p % 4 == 0 && ld_dp % 4 == 0)) && vae_aligned16(logit_scale) && x_ok &&
-                   vae_aligned16(dlogit_scale) && (!zinb || (vae_aligned16(logit_dropout) && vae_aligned16(dlogit_dropout)));
+                   (!zinb || (ld_p % 4 == 0 && ld_dp % 4 == 0)) && logits_aligned(logit_scale, LD) && x_ok &&
+                   logits_aligned(dlogit_scale, LD) && (!zinb || (logits_aligned(logit_dropout, LD) && logits_aligned(dlogit_dropout, LD)));
+  VAE_REQUIRE(!L16 || vec, "vae_nbzinb_bwd: bf16 logits need G %% 4 == 0, leading dimensions %% 4 == 0 and aligned rows");
   int strips, chunks, rows_per_block;
   bwd_grid(B, G, &strips, &chunks, &rows_per_block);
   const bool slab = workspace != nullptr;
@@ -868,12 +916,12 @@ static int nbzinb_bwd_impl(int zinb, const float* logit_scale, int64_t ld_s, con
   dim3 grid(strips, chunks);
   hipStream_t st = (hipStream_t)stream;
 #define LAUNCH_BWD(Z, V, S_)                                                                                          \
-  hipLaunchKernelGGL((nbzinb_bwd_kernel<Z, V, S_, XT>), grid, dim3(256), 0, st, logit_scale, ld_s, logit_dropout, ld_p, x,  \
+  hipLaunchKernelGGL((nbzinb_bwd_kernel<Z, V, S_, XT, LT>), grid, dim3(256), 0, st, logit_scale, ld_s, logit_dropout, ld_p, x,  \
                      ld_x, library, gene_table, rowmax, rowsum, S, g_ll, g_scalar, (int)B, (int)G, rows_per_block,    \
                      dlogit_scale, ld_ds, dlogit_dropout, ld_dp, dlibrary, dpx_r, dbias_scale, dbias_dropout, workspace, absmax)
 #define LAUNCH_BWD2(Z, V) do { if (slab) LAUNCH_BWD(Z, V, true); else LAUNCH_BWD(Z, V, false); } while (0)
   VAE_REQUIRE(!U8 || vec, "vae_nbzinb_bwd_u8: needs G %% 4 == 0, leading dimensions %% 4 == 0 and aligned rows");
-  if (U8) { if (zinb) LAUNCH_BWD2(true, true); else LAUNCH_BWD2(false, true); }
+  if (U8 || L16) { if (zinb) LAUNCH_BWD2(true, true); else LAUNCH_BWD2(false, true); }
   else if (zinb) { if (vec) LAUNCH_BWD2(true, true); else LAUNCH_BWD2(true, false); }
   else           { if (vec) LAUNCH_BWD2(false, true); else LAUNCH_BWD2(false, false); }
 #undef LAUNCH_BWD2
@@ -891,12 +939,25 @@ static int nbzinb_bwd_impl(int zinb, const float* logit_scale, int64_t ld_s, con
   return VAE_OK;
 }
 
-int vae_nbzinb_bwd_ex(int x_dtype, int zinb, const float* logit_scale, int64_t ld_s, const float* logit_dropout, int64_t ld_p,
-                      const void* x, int64_t ld_x, const float* library, const float* gene_table, const float* rowmax,
+int vae_nbzinb_bwd_ex(int x_dtype, int l_dtype, int zinb, const void* logit_scale_v, int64_t ld_s, const void* logit_dropout_v,
+                      int64_t ld_p, const void* x, int64_t ld_x, const float* library, const float* gene_table, const float* rowmax,
                       const float* rowsum, const float* S, const float* g_ll, float g_scalar, int64_t B, int64_t G,
-                      float* dlogit_scale, int64_t ld_ds, float* dlogit_dropout, int64_t ld_dp, float* dlibrary, float* dpx_r,
+                      void* dlogit_scale_v, int64_t ld_ds, void* dlogit_dropout_v, int64_t ld_dp, float* dlibrary, float* dpx_r,
                       float* dbias_scale, float* dbias_dropout, float* workspace, int64_t workspace_bytes, float* absmax,
                       VaeDeferredColreduce* defer, void* stream) {
+  if (l_dtype == VAE_L_BF16) {
+    const bf16_t *ls = (const bf16_t*)logit_scale_v, *lp = (const bf16_t*)logit_dropout_v;
+    bf16_t *ds = (bf16_t*)dlogit_scale_v, *dp = (bf16_t*)dlogit_dropout_v;
+    if (x_dtype == VAE_X_U8)
+      return nbzinb_bwd_impl<uint8_t, bf16_t>(zinb, ls, ld_s, lp, ld_p, (const uint8_t*)x, ld_x, library, gene_table, rowmax, rowsum, S,
+                                              g_ll, g_scalar, B, G, ds, ld_ds, dp, ld_dp, dlibrary, dpx_r, dbias_scale,
+                                              dbias_dropout, workspace, workspace_bytes, stream, 1, absmax, defer);
+    return nbzinb_bwd_impl<float, bf16_t>(zinb, ls, ld_s, lp, ld_p, (const float*)x, ld_x, library, gene_table, rowmax, rowsum, S, g_ll,
+                                          g_scalar, B, G, ds, ld_ds, dp, ld_dp, dlibrary, dpx_r, dbias_scale, dbias_dropout,
+                                          workspace, workspace_bytes, stream, 1, absmax, defer);
+  }
+  const float *logit_scale = (const float*)logit_scale_v, *logit_dropout = (const float*)logit_dropout_v;
+  float *dlogit_scale = (float*)dlogit_scale_v, *dlogit_dropout = (float*)dlogit_dropout_v;
   if (x_dtype == VAE_X_U8)
     return nbzinb_bwd_impl<uint8_t>(zinb, logit_scale, ld_s, logit_dropout, ld_p, (const uint8_t*)x, ld_x, library, gene_table,
                                     rowmax, rowsum, S, g_ll, g_scalar, B, G, dlogit_scale, ld_ds, dlogit_dropout, ld_dp,
@@ -957,7 +1018,7 @@ extern "C" int64_t vae_nbzinb_fwd_workspace_bytes(int64_t B, int64_t G) {
 
 // have_stats != 0: rowmax / rowsum already hold the softmax statistics of every row (decoder-head GEMM epilogue).
 // ll / S may be null: the per-strip partials then stay in `workspace` ([strips][2][B]) for vae_elbo_reduce_parts.
-int vae_nbzinb_fwd_tiled_ex(int x_dtype, int zinb, const float* logit_scale, int64_t ld_s, const float* logit_dropout,
+int vae_nbzinb_fwd_tiled_ex(int x_dtype, int l_dtype, int zinb, const void* logit_scale, int64_t ld_s, const void* logit_dropout,
                             int64_t ld_p, const void* x, int64_t ld_x, const float* library, const float* gene_table, int64_t B,
                             int64_t G, float* ll, float* rowmax, float* rowsum, float* S, int have_stats, float* workspace,
                             int64_t workspace_bytes, int* strips_out, void* stream) {
@@ -970,25 +1031,34 @@ int vae_nbzinb_fwd_tiled_ex(int x_dtype, int zinb, const float* logit_scale, int
   VAE_REQUIRE(workspace_bytes >= vae_nbzinb_fwd_workspace_bytes(B, G), "vae_nbzinb_fwd_ws: workspace too small");
   const bool u8 = x_dtype == VAE_X_U8;
   const bool x_ok = u8 ? ((reinterpret_cast<uintptr_t>(x) & 3u) == 0) : vae_aligned16(x);
+  const bool l16 = l_dtype == VAE_L_BF16;
+  VAE_REQUIRE(l16 || l_dtype == VAE_L_F32, "vae_nbzinb_fwd_ws: bad logit dtype");
   const bool vec = (G % 4 == 0) && (ld_s % 4 == 0) && (ld_x % 4 == 0) && (!zinb || ld_p % 4 == 0) &&
-                   vae_aligned16(logit_scale) && x_ok && (!zinb || vae_aligned16(logit_dropout)) && vae_aligned16(gene_table);
-  VAE_REQUIRE(!u8 || vec, "vae_nbzinb_fwd_u8: needs G %% 4 == 0, leading dimensions %% 4 == 0 and aligned rows");
+                   logits_aligned(logit_scale, l_dtype) && x_ok && (!zinb || logits_aligned(logit_dropout, l_dtype)) &&
+                   vae_aligned16(gene_table);
+  VAE_REQUIRE(!(u8 || l16) || vec, "vae_nbzinb_fwd_ws: uint8 counts / bf16 logits need G %% 4 == 0, leading dimensions %% 4 == 0 and aligned rows");
   hipStream_t st = (hipStream_t)stream;
   if (!have_stats) {
-    if (vec) hipLaunchKernelGGL(softmax_stats_kernel<true>, dim3((unsigned)B), dim3(256), 0, st, logit_scale, ld_s, (int)G, rowmax, rowsum);
-    else     hipLaunchKernelGGL(softmax_stats_kernel<false>, dim3((unsigned)B), dim3(256), 0, st, logit_scale, ld_s, (int)G, rowmax, rowsum);
+    if (l16)      hipLaunchKernelGGL((softmax_stats_kernel<true, bf16_t>), dim3((unsigned)B), dim3(256), 0, st, (const bf16_t*)logit_scale, ld_s, (int)G, rowmax, rowsum);
+    else if (vec) hipLaunchKernelGGL((softmax_stats_kernel<true, float>), dim3((unsigned)B), dim3(256), 0, st, (const float*)logit_scale, ld_s, (int)G, rowmax, rowsum);
+    else          hipLaunchKernelGGL((softmax_stats_kernel<false, float>), dim3((unsigned)B), dim3(256), 0, st, (const float*)logit_scale, ld_s, (int)G, rowmax, rowsum);
     VAE_CHECK_LAUNCH("vae_nbzinb_fwd_ws(stats)");
   }
   int strips, chunks, rows_per_block;
   fwd_grid(B, G, &strips, &chunks, &rows_per_block);
   VAE_REQUIRE(chunks <= 65535, "vae_nbzinb_fwd_ws: batch too large for one launch (B <= 16 * 65535)");
   const dim3 grid(strips, chunks);
-#define LAUNCH_FT(Z, V, XT_)                                                                                              \
-  hipLaunchKernelGGL((nbzinb_fwd_tiled_kernel<Z, V, XT_>), grid, dim3(256), 0, st, logit_scale, ld_s, logit_dropout, ld_p,   \
-                     (const XT_*)x, ld_x, library, gene_table, rowmax, rowsum, (int)B, (int)G, rows_per_block, workspace)
-  if (u8) { if (zinb) LAUNCH_FT(true, true, uint8_t); else LAUNCH_FT(false, true, uint8_t); }
-  else if (zinb) { if (vec) LAUNCH_FT(true, true, float); else LAUNCH_FT(true, false, float); }
-  else           { if (vec) LAUNCH_FT(false, true, float); else LAUNCH_FT(false, false, float); }
+#define LAUNCH_FT(Z, V, XT_, LT_)                                                                                         \
+  hipLaunchKernelGGL((nbzinb_fwd_tiled_kernel<Z, V, XT_, LT_>), grid, dim3(256), 0, st, (const LT_*)logit_scale, ld_s,       \
+                     (const LT_*)logit_dropout, ld_p, (const XT_*)x, ld_x, library, gene_table, rowmax, rowsum, (int)B, (int)G, \
+                     rows_per_block, workspace)
+  if (l16) {
+    if (u8) { if (zinb) LAUNCH_FT(true, true, uint8_t, bf16_t); else LAUNCH_FT(false, true, uint8_t, bf16_t); }
+    else    { if (zinb) LAUNCH_FT(true, true, float, bf16_t); else LAUNCH_FT(false, true, float, bf16_t); }
+  }
+  else if (u8) { if (zinb) LAUNCH_FT(true, true, uint8_t, float); else LAUNCH_FT(false, true, uint8_t, float); }
+  else if (zinb) { if (vec) LAUNCH_FT(true, true, float, float); else LAUNCH_FT(true, false, float, float); }
+  else           { if (vec) LAUNCH_FT(false, true, float, float); else LAUNCH_FT(false, false, float, float); }
 #undef LAUNCH_FT
   VAE_CHECK_LAUNCH("vae_nbzinb_fwd_ws");
   if (strips_out) *strips_out = strips;
@@ -1003,8 +1073,8 @@ extern "C" int vae_nbzinb_fwd_ws(int zinb, const float* logit_scale, int64_t ld_
                                  const void* x, int x_dtype, int64_t ld_x, const float* library, const float* gene_table,
                                  int64_t B, int64_t G, float* ll, float* rowmax, float* rowsum, float* S, int have_stats,
                                  float* workspace, int64_t workspace_bytes, void* stream) {
-  return vae_nbzinb_fwd_tiled_ex(x_dtype, zinb, logit_scale, ld_s, logit_dropout, ld_p, x, ld_x, library, gene_table, B, G, ll,
-                                 rowmax, rowsum, S, have_stats, workspace, workspace_bytes, nullptr, stream);
+  return vae_nbzinb_fwd_tiled_ex(x_dtype, VAE_L_F32, zinb, logit_scale, ld_s, logit_dropout, ld_p, x, ld_x, library, gene_table, B, G,
+                                 ll, rowmax, rowsum, S, have_stats, workspace, workspace_bytes, nullptr, stream);
 }
 
 int vae_softmax_stats_merge(const float* stat_m, const float* stat_s, int slots, int64_t B, float* rowmax, float* rowsum,

@@ -25,6 +25,7 @@
 #include <stdlib.h>
 
 #include <mutex>
+#include <type_traits>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -50,6 +51,7 @@ struct GemmArgs {
   int vecC;            // 16-byte vector stores allowed (C / the slabs 16-byte aligned, ldc % 4 == 0, N % 4 == 0)
   int accumulate;      // C += (only when split == 1)
   int tiles_m, tiles_n;
+  int group_m;         // gemm_x3_kernel: > 0 = row tiles rasterised in groups of this many (see the kernel)
   const float* sa;     // gemm_x3_kernel<NP = 2> (two f16 terms): device pointers to the power-of-two factors the
   const float* sb;     // operands are multiplied by before the split (null = 1); the product is scaled back
   int na, nb;          // > 0: sa / sb are arrays of na / nb partial maxima of |A| / |B| written by the producers of the
@@ -638,8 +640,18 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
 
-template <int LAYOUT, int BM, int BN, int WAVES_M, int NP>
+// IO (NP == 1 only): storage type of the operands / the output in HBM.  bit 0: A holds bf16, bit 1: B holds bf16 (staged
+// by 8-byte loads straight into the operand plane -- no conversion, half the bytes), bit 2: C is written as bf16 (rounded
+// to nearest even; the softmax statistics are then taken from the ROUNDED values, the ones the consumer will read).
+// Leading dimensions count elements of the respective type.
+template <int LAYOUT, int BM, int BN, int WAVES_M, int NP, int IO = 0>
 __global__ __launch_bounds__(256, (NP <= 2 ? 3 : 2)) void gemm_x3_kernel(GemmArgs g) {
+  static_assert(IO == 0 || NP == 1, "bf16 storage goes with the one-plane bf16 product");
+  constexpr bool ABF = (IO & 1) != 0, BBF = (IO & 2) != 0, CBF = (IO & 4) != 0;
+  using TA = std::conditional_t<ABF, uint16_t, float>;
+  using TB = std::conditional_t<BBF, uint16_t, float>;
+  using RA = std::conditional_t<ABF, uint2, float4>;   // four consecutive elements
+  using RB = std::conditional_t<BBF, uint2, float4>;
   constexpr bool A_KC = (LAYOUT != TN);
   constexpr bool B_KC = (LAYOUT == NT);
   constexpr int WAVES_N = 4 / WAVES_M;
@@ -659,8 +671,19 @@ __global__ __launch_bounds__(256, (NP <= 2 ? 3 : 2)) void gemm_x3_kernel(GemmArg
   const int per_split = tiles_m * tiles_n;
   const int s = id / per_split, t = id - s * per_split;
   int tm, tn;
-  if (tiles_m <= tiles_n) { tm = t % tiles_m; tn = t / tiles_m; }
-  else                    { tn = t % tiles_n; tm = t / tiles_n; }
+  if (g.group_m > 0) {
+    // many row tiles AND many column tiles (decoder heads at B >= 2048): walking all row tiles per column tile makes the
+    // workgroups resident on an XCD sweep the whole A operand (4 MB at B = 4096) between two uses of a line, and the
+    // output stream evicts it from the 4 MB L2 (measured: 787 MB fetched for 45 MB of operands).  Row tiles go in groups
+    // of group_m: ids walk the group's rows fastest, then every column tile, then the next group -- the resident set is
+    // group_m A panels + a dozen B tiles.
+    const int gsz = g.group_m * tiles_n;
+    const int grp = t / gsz, r = t - grp * gsz;
+    const int rows = min(g.group_m, tiles_m - grp * g.group_m);
+    tm = grp * g.group_m + r % rows;
+    tn = r / rows;
+  } else if (tiles_m <= tiles_n) { tm = t % tiles_m; tn = t / tiles_m; }
+  else                           { tn = t % tiles_n; tm = t / tiles_n; }
   const int m0 = tm * BM, n0 = tn * BN;
   const int kbeg = s * g.k_per_split;
   const int kend = min(g.K, kbeg + g.k_per_split);
@@ -669,20 +692,22 @@ __global__ __launch_bounds__(256, (NP <= 2 ? 3 : 2)) void gemm_x3_kernel(GemmArg
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
   const int l31 = lane & 31, h = lane >> 5;
 
-  // ---- global -> register staging: unconditional 16-byte loads from clamped addresses ----
-  const float* pa[NA];
-  const float* pb[NB];
+  // ---- global -> register staging: unconditional 16-byte (bf16 storage: 8-byte) loads from clamped addresses ----
+  const TA* gA = reinterpret_cast<const TA*>(g.A);
+  const TB* gB = reinterpret_cast<const TB*>(g.B);
+  const TA* pa[NA];
+  const TB* pb[NB];
   int wa[NA], wb[NB];  // LDS element offsets inside a plane
 #pragma unroll
   for (int i = 0; i < NA; ++i) {
     const int c = tid + 256 * i;
     if (A_KC) {
       const int row = c >> 3, k4 = c & 7;
-      pa[i] = g.A + (int64_t)min(m0 + row, g.M - 1) * g.lda + kbeg + 4 * k4;
+      pa[i] = gA + (int64_t)min(m0 + row, g.M - 1) * g.lda + kbeg + 4 * k4;
       wa[i] = row * LDK + 4 * k4;
     } else {
       const int k = c / (BM / 4), r4 = c % (BM / 4);
-      pa[i] = g.A + (int64_t)(kbeg + k) * g.lda + min(m0 + 4 * r4, g.M - 4);
+      pa[i] = gA + (int64_t)(kbeg + k) * g.lda + min(m0 + 4 * r4, g.M - 4);
       wa[i] = k * LDR + 4 * r4;
     }
   }
@@ -691,37 +716,41 @@ __global__ __launch_bounds__(256, (NP <= 2 ? 3 : 2)) void gemm_x3_kernel(GemmArg
     const int c = tid + 256 * i;
     if (B_KC) {
       const int row = c >> 3, k4 = c & 7;
-      pb[i] = g.B + (int64_t)min(n0 + row, g.N - 1) * g.ldb + kbeg + 4 * k4;
+      pb[i] = gB + (int64_t)min(n0 + row, g.N - 1) * g.ldb + kbeg + 4 * k4;
       wb[i] = row * LDK + 4 * k4;
     } else {
       const int k = c / (BN / 4), r4 = c % (BN / 4);
-      pb[i] = g.B + (int64_t)(kbeg + k) * g.ldb + min(n0 + 4 * r4, g.N - 4);
+      pb[i] = gB + (int64_t)(kbeg + k) * g.ldb + min(n0 + 4 * r4, g.N - 4);
       wb[i] = k * LDR + 4 * r4;
     }
   }
   const int64_t step_a = A_KC ? 32 : 32 * g.lda;
   const int64_t step_b = B_KC ? 32 : 32 * g.ldb;
-  float4 ra[NA], rb[NB];
+  RA ra[NA];
+  RB rb[NB];
   auto fetch = [&]() {
 #pragma unroll
-    for (int i = 0; i < NA; ++i) { ra[i] = *reinterpret_cast<const float4*>(pa[i]); pa[i] += step_a; }
+    for (int i = 0; i < NA; ++i) { ra[i] = *reinterpret_cast<const RA*>(pa[i]); pa[i] += step_a; }
 #pragma unroll
-    for (int i = 0; i < NB; ++i) { rb[i] = *reinterpret_cast<const float4*>(pb[i]); pb[i] += step_b; }
+    for (int i = 0; i < NB; ++i) { rb[i] = *reinterpret_cast<const RB*>(pb[i]); pb[i] += step_b; }
   };
   // last, partial K step (K % 32 != 0, K % 4 == 0): chunks past kend read a safe address and count as zeros
   auto fetch_tail = [&](int tail) {
-    const float4 Z = make_float4(0.f, 0.f, 0.f, 0.f);
+    RA ZA;
+    RB ZB;
+    memset(&ZA, 0, sizeof(ZA));
+    memset(&ZB, 0, sizeof(ZB));
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       const int c = tid + 256 * i;
       const int kk = A_KC ? 4 * (c & 7) : c / (BM / 4);
-      ra[i] = kk < tail ? *reinterpret_cast<const float4*>(pa[i]) : Z;
+      ra[i] = kk < tail ? *reinterpret_cast<const RA*>(pa[i]) : ZA;
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
       const int c = tid + 256 * i;
       const int kk = B_KC ? 4 * (c & 7) : c / (BN / 4);
-      rb[i] = kk < tail ? *reinterpret_cast<const float4*>(pb[i]) : Z;
+      rb[i] = kk < tail ? *reinterpret_cast<const RB*>(pb[i]) : ZB;
     }
   };
   float scA = 1.f, scB = 1.f;   // NP == 2: operand scales
@@ -760,7 +789,12 @@ __global__ __launch_bounds__(256, (NP <= 2 ? 3 : 2)) void gemm_x3_kernel(GemmArg
       if (g.sb) scB = *g.sb;
     }
   };
-  auto put = [&](__bf16* base, int plane, int off, const float4& v, float sc) {
+  auto put = [&](__bf16* base, int plane, int off, const auto& vin, float sc) {
+    if constexpr (std::is_same_v<std::decay_t<decltype(vin)>, uint2>) {   // bf16 in HBM: already the operand image
+      *reinterpret_cast<uint2*>(base + off) = vin;
+      return;
+    } else {
+    const float4 v = vin;
     const float f[4] = {v.x, v.y, v.z, v.w};
     if (NP == 2) {  // two f16 terms of the scaled value: hi = rn(a s), lo = rn(a s - hi): 22 significant bits
       f16x4 h4, l4;
@@ -786,6 +820,7 @@ __global__ __launch_bounds__(256, (NP <= 2 ? 3 : 2)) void gemm_x3_kernel(GemmArg
     if (NP == 3) {
       *reinterpret_cast<bf16x4*>(base + plane + off) = mi;
       *reinterpret_cast<bf16x4*>(base + 2 * plane + off) = lo;
+    }
     }
   };
 #ifdef VAE_PROBE
@@ -927,6 +962,53 @@ __global__ __launch_bounds__(256, (NP <= 2 ? 3 : 2)) void gemm_x3_kernel(GemmArg
       const int nb = n0 + wn * (32 * TNN) + ni * 32;
       const int n = nb + l31;
       const float bv = (g.split == 1 && g.bias && n < g.N) ? g.bias[n] : 0.f;
+      if (CBF && vec_out && nb + 32 <= g.N) {
+        // bf16 output: the 32 x 32 block leaves as 2 instructions of 16 rows x 64 B (8 bf16 per lane)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * h) * 40 + l31] = acc[mi][ni][r] + bv;
+        uint16_t* out16 = reinterpret_cast<uint16_t*>(out);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int row = (lane >> 2) + 16 * i;
+          const int m = m0 + wm * (32 * TM) + mi * 32 + row;
+          const float4 v0 = *reinterpret_cast<const float4*>(patch + row * 40 + 8 * (lane & 3));
+          const float4 v1 = *reinterpret_cast<const float4*>(patch + row * 40 + 8 * (lane & 3) + 4);
+          bf16x8 o;
+          o[0] = (__bf16)v0.x; o[1] = (__bf16)v0.y; o[2] = (__bf16)v0.z; o[3] = (__bf16)v0.w;
+          o[4] = (__bf16)v1.x; o[5] = (__bf16)v1.y; o[6] = (__bf16)v1.z; o[7] = (__bf16)v1.w;
+          if (m < g.M) *reinterpret_cast<bf16x8*>(out16 + (int64_t)m * ldc + nb + 8 * (lane & 3)) = o;
+          if (STAT_OK && stats && nb < g.stat_cols) {   // as below, over the 8 ROUNDED values this lane stores
+            constexpr int MI = STAT_OK ? 1 : 0;
+            constexpr float L2E = 1.44269504088896341f;
+            const int c0 = nb + 8 * (lane & 3);
+            float a[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a[j] = c0 + j < g.stat_cols ? (float)o[j] : -INFINITY;
+            const float om = rmax[mi * MI][i];
+            const float nm = fmaxf(fmaxf(fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3])), fmaxf(fmaxf(a[4], a[5]), fmaxf(a[6], a[7]))), om);
+            const float nb2 = -nm * L2E;
+            if (nm > -INFINITY) {
+              float e = 0.f;
+#pragma unroll
+              for (int j = 0; j < 8; ++j) e += __builtin_amdgcn_exp2f(fmaf(a[j], L2E, nb2));
+              const float rescale = om == nm ? 1.f : __builtin_amdgcn_exp2f(fmaxf(fmaf(om, L2E, nb2), -126.f));
+              rsum[mi * MI][i] = fmaf(rsum[mi * MI][i], rescale, e);
+              rmax[mi * MI][i] = nm;
+            }
+          }
+        }
+        continue;
+      }
+      if (CBF) {   // ragged edge block of a bf16 output: element stores
+        if (n >= g.N) continue;
+        uint16_t* out16 = reinterpret_cast<uint16_t*>(out);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = m0 + wm * (32 * TM) + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          if (m < g.M) out16[(int64_t)m * ldc + n] = __builtin_bit_cast(uint16_t, (__bf16)(acc[mi][ni][r] + bv));
+        }
+        continue;
+      }
       if (vec_out && nb + 32 <= g.N) {
 #pragma unroll
         for (int r = 0; r < 16; ++r)
@@ -978,17 +1060,18 @@ __global__ __launch_bounds__(256, (NP <= 2 ? 3 : 2)) void gemm_x3_kernel(GemmArg
     for (int mi = 0; mi < (STAT_OK ? TM : 1); ++mi)
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        // merge the 8 lanes that share this row: max, rescale, sum
+        // merge the 8 (bf16 output: 4) lanes that share this row: max, rescale, sum
+        if (CBF && i >= 2) continue;
         float M = rmax[mi][i];
         M = fmaxf(M, __shfl_xor(M, 1, 64));
         M = fmaxf(M, __shfl_xor(M, 2, 64));
-        M = fmaxf(M, __shfl_xor(M, 4, 64));
+        if (!CBF) M = fmaxf(M, __shfl_xor(M, 4, 64));
         float sv = rmax[mi][i] > -INFINITY ? rsum[mi][i] * vae_exp_acc(rmax[mi][i] - M) : 0.f;
         sv += __shfl_xor(sv, 1, 64);
         sv += __shfl_xor(sv, 2, 64);
-        sv += __shfl_xor(sv, 4, 64);
-        const int m = m0 + wm * (32 * TM) + mi * 32 + (lane >> 3) + 8 * i;
-        if ((lane & 7) == 0 && m < g.M) {
+        if (!CBF) sv += __shfl_xor(sv, 4, 64);
+        const int m = m0 + wm * (32 * TM) + mi * 32 + (CBF ? (lane >> 2) + 16 * i : (lane >> 3) + 8 * i);
+        if ((lane & (CBF ? 3 : 7)) == 0 && m < g.M) {
           g.stat_m[(int64_t)slot * g.M + m] = M;
           g.stat_s[(int64_t)slot * g.M + m] = sv;
         }
@@ -1136,7 +1219,8 @@ namespace {
 int gemm_impl(int layout, int precision, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B,
               int64_t ldb, float* C, int64_t ldc, const float* bias, const float* x_mean, int accumulate,
               float* workspace, int64_t workspace_bytes, void* stream, int* slabs_out, const float* scale_a = nullptr,
-              const float* scale_b = nullptr, int n_max_a = 0, int n_max_b = 0, VaeGemmRowStats* stats = nullptr) {
+              const float* scale_b = nullptr, int n_max_a = 0, int n_max_b = 0, VaeGemmRowStats* stats = nullptr,
+              int io = 0) {
   VAE_REQUIRE(layout >= 0 && layout <= 2, "vae_gemm: layout must be 0 (NT), 1 (NN) or 2 (TN), got %d", layout);
   VAE_REQUIRE(precision >= 0 && precision <= 3, "vae_gemm: precision must be 0 (fp32), 1 (bf16), 2 (bf16x3) or 3 (f16x2), got %d",
               precision);
@@ -1164,8 +1248,9 @@ int gemm_impl(int layout, int precision, int64_t M, int64_t N, int64_t K, const 
   g.lda = lda; g.ldb = ldb; g.ldc = ldc;
   g.M = (int)M; g.N = (int)N; g.K = (int)K;
   g.accumulate = accumulate;
-  g.vecA = (lda % 4 == 0) && vae_aligned16(A);
-  g.vecB = (ldb % 4 == 0) && vae_aligned16(B);
+  g.vecA = (lda % 4 == 0) && ((io & 1) ? (reinterpret_cast<uintptr_t>(A) & 7u) == 0 : vae_aligned16(A));
+  g.vecB = (ldb % 4 == 0) && ((io & 2) ? (reinterpret_cast<uintptr_t>(B) & 7u) == 0 : vae_aligned16(B));
+  g.group_m = 0;
   const Plan plan = make_plan(g.M, g.N, g.K);
   static const int no_dma = getenv("VAE_GEMM_NO_DMA") ? atoi(getenv("VAE_GEMM_NO_DMA")) : 0;  // tuning knob
   const bool norm = x_mean != nullptr;
@@ -1179,7 +1264,12 @@ int gemm_impl(int layout, int precision, int64_t M, int64_t N, int64_t K, const 
   if (dma_ok) {
     const DmaPlan d = make_dma_plan(g.M, g.N, g.K);
     bm = d.bm; bn = d.bn; split = d.split;
+    if (io & 4) split = 1;   // a bf16 output is written by the product kernel itself
   }
+  // bf16 storage exists in the one-plane split kernel only: the caller (step.hip) checks the shapes with vae_gemm_bf16io_ok
+  VAE_REQUIRE(io == 0 || (precision == 1 && dma_ok && (io == 1 || io == 2 || io == 4) && !(io == 2 && layout != TN) &&
+                          !(io == 4 && (layout != NT || slabs_out || accumulate || ldc % 8 != 0 || !vae_aligned16(C)))),
+              "vae_gemm: bf16 operand / output storage is not available for this shape, layout or alignment");
   const int tiles_m = (g.M + bm - 1) / bm;
   g.tiles_m = tiles_m;
   g.tiles_n = (g.N + bn - 1) / bn;
@@ -1205,6 +1295,10 @@ int gemm_impl(int layout, int precision, int64_t M, int64_t N, int64_t K, const 
     g.C = workspace;
   }
   g.vecC = (N % 4 == 0) && vae_aligned16(g.C) && (split > 1 || slabs_out || ldc % 4 == 0);
+  {  // grouped rasterisation of the row tiles (kernel comment): when both tile counts are large
+    static const int gm_env = getenv("VAE_GEMM_GROUP_M") ? atoi(getenv("VAE_GEMM_GROUP_M")) : 8;
+    if (dma_ok && split == 1 && gm_env > 0 && tiles_m >= 2 * gm_env && g.tiles_n >= 2 * gm_env) g.group_m = gm_env;
+  }
   dim3 grid(tiles_m * g.tiles_n, split);
   // softmax statistics ride in the 16-byte-store epilogue of the split kernel: every 32-column block must take it
   if (stats && stats->m && stats->s && stats->cols > 0 && dma_ok && layout == NT && split == 1 && !slabs_out && !accumulate &&
@@ -1232,7 +1326,19 @@ int gemm_impl(int layout, int precision, int64_t M, int64_t N, int64_t K, const 
       else                        hipLaunchKernelGGL((gemm_x3_kernel<LAY, 160, 128, 1, NPL>), grid1, dim3(256), 0, st, g); \
     } while (0)
     static const int use_x3 = getenv("VAE_GEMM_X3") ? atoi(getenv("VAE_GEMM_X3")) : 1;  // 0: fp32 MFMA pipeline
-    if (precision == 1) {
+#define VAE_X3_LAUNCH_IO(LAY, IOF)                                                                          \
+    do {                                                                                                   \
+      if (bm == 128 && bn == 128) hipLaunchKernelGGL((gemm_x3_kernel<LAY, 128, 128, 2, 1, IOF>), grid1, dim3(256), 0, st, g); \
+      else if (bn == 160)         hipLaunchKernelGGL((gemm_x3_kernel<LAY, 128, 160, 4, 1, IOF>), grid1, dim3(256), 0, st, g); \
+      else                        hipLaunchKernelGGL((gemm_x3_kernel<LAY, 160, 128, 1, 1, IOF>), grid1, dim3(256), 0, st, g); \
+    } while (0)
+    if (io) {   // bf16 storage of one operand or of the output (combinations the step uses)
+      if (layout == NT && io == 1) VAE_X3_LAUNCH_IO(NT, 1);
+      else if (layout == NT) VAE_X3_LAUNCH_IO(NT, 4);
+      else if (layout == NN) VAE_X3_LAUNCH_IO(NN, 1);
+      else if (io == 1) VAE_X3_LAUNCH_IO(TN, 1);
+      else VAE_X3_LAUNCH_IO(TN, 2);
+    } else if (precision == 1) {
       if (layout == NT) VAE_X3_LAUNCH(NT, 1);
       else if (layout == NN) VAE_X3_LAUNCH(NN, 1);
       else VAE_X3_LAUNCH(TN, 1);
@@ -1249,6 +1355,7 @@ int gemm_impl(int layout, int precision, int64_t M, int64_t N, int64_t K, const 
     else VAE_DMA_LAUNCH(TN);
 #undef VAE_DMA_LAUNCH
 #undef VAE_X3_LAUNCH
+#undef VAE_X3_LAUNCH_IO
   } else if (precision == 0) {
     if (layout == NT) launch_t<NT, 0>(g, norm, grid, st, plan.tile);
     else if (layout == NN) launch_t<NN, 0>(g, false, grid, st, plan.tile);
@@ -1360,6 +1467,29 @@ int vae_gemm_rowstats(int layout, int precision, int64_t M, int64_t N, int64_t K
                       VaeGemmRowStats* stats, void* stream) {
   return gemm_impl(layout, precision, M, N, K, A, lda, B, ldb, C, ldc, bias, nullptr, 0, workspace, workspace_bytes, stream,
                    nullptr, nullptr, nullptr, 0, 0, stats);
+}
+
+// bf16-mode product with ONE operand or the output stored as bf16 in HBM (io: VAE_IO_*).  n_slabs != null: split-K slabs
+// (fp32) stay in the workspace as for vae_gemm_slabs (not with VAE_IO_C_BF16).  stats: as vae_gemm_rowstats.
+int vae_gemm_bf16io(int layout, int io, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B, int64_t ldb,
+                    void* C, int64_t ldc, const float* bias, float* workspace, int64_t workspace_bytes, int* n_slabs,
+                    VaeGemmRowStats* stats, void* stream) {
+  return gemm_impl(layout, 1, M, N, K, (const float*)A, lda, (const float*)B, ldb, n_slabs ? nullptr : (float*)C, n_slabs ? N : ldc,
+                   n_slabs ? nullptr : bias, nullptr, 0, workspace, workspace_bytes, stream, n_slabs, nullptr, nullptr, 0, 0, stats,
+                   io);
+}
+extern "C" int vae_gemm_bf16_storage_ok(int layout, int io, int64_t M, int64_t N, int64_t K) {
+  if (layout < 0 || layout > 2 || M < 4 || N < 4 || K < 4 || M >= (1 << 30) || N >= (1 << 30) || K >= (1 << 30)) return 0;
+  if (!(io == 1 || io == 2 || io == 4) || (io == 2 && layout != TN) || (io == 4 && layout != NT)) return 0;
+  if (make_plan((int)M, (int)N, (int)K).tile != 128 || K % 4 != 0) return 0;
+  if ((layout == TN && M % 4 != 0) || (layout != NT && N % 4 != 0)) return 0;
+  if (io == 4 && N % 8 != 0) return 0;
+  return 1;
+}
+extern "C" int vae_gemm_bf16_storage(int layout, int io, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B,
+                                     int64_t ldb, void* C, int64_t ldc, const float* bias, float* workspace,
+                                     int64_t workspace_bytes, void* stream) {
+  return vae_gemm_bf16io(layout, io, M, N, K, A, lda, B, ldb, C, ldc, bias, workspace, workspace_bytes, nullptr, nullptr, stream);
 }
 
 extern "C" int64_t vae_absmax_workspace_bytes(void) { return 1024 * (int64_t)sizeof(float); }

@@ -35,6 +35,11 @@ int vae_gemm_f16x2(int layout, int64_t M, int64_t N, int64_t K, const float* A, 
 int vae_gemm_rowstats(int layout, int precision, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B,
                       int64_t ldb, float* C, int64_t ldc, const float* bias, float* workspace, int64_t workspace_bytes,
                       VaeGemmRowStats* stats, void* stream);
+// bf16-mode product with one operand or the output held as bf16 in HBM (io = VAE_IO_A_BF16 | VAE_IO_B_BF16 | VAE_IO_C_BF16,
+// one bit; shapes: vae_gemm_bf16_storage_ok); n_slabs != null leaves fp32 split-K slabs in the workspace
+int vae_gemm_bf16io(int layout, int io, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B, int64_t ldb,
+                    void* C, int64_t ldc, const float* bias, float* workspace, int64_t workspace_bytes, int* n_slabs,
+                    VaeGemmRowStats* stats, void* stream);
 // rowmax[b] / rowsum[b] from the `slots` per-slot statistics a GEMM left (epilogue.hip)
 int vae_softmax_stats_merge(const float* stat_m, const float* stat_s, int slots, int64_t B, float* rowmax, float* rowsum,
                             void* stream);
@@ -45,12 +50,13 @@ int vae_softmax_stats_merge(const float* stat_m, const float* stat_s, int slots,
 int64_t vae_nbzinb_bwd_workgroups(int64_t B, int64_t G);   /* vae_nbzinb_bwd_ex: one entry per workgroup */
 
 // vae_normalize_rows / _u8 (x_dtype) that also stores the per-wave maxima of |xn| (absmax may be null)
-int vae_normalize_rows_ex(const void* x, int x_dtype, int64_t ldx, int64_t B, int64_t G, float* mean, float* xn,
+// xn_bf16 != 0: xn is written as bf16 (ld_xn in elements, % 8 == 0)
+int vae_normalize_rows_ex(const void* x, int x_dtype, int64_t ldx, int64_t B, int64_t G, float* mean, void* xn, int xn_bf16,
                           int64_t ld_xn, float* absmax, void* stream);
 // vae_gene_dropout that also stores the per-wave maxima of |xn| of the masked, normalised counts
 int vae_gene_dropout_ex(const void* x, int x_dtype, int64_t ldx, int64_t B, int64_t G, float p, float alpha, uint64_t seed,
                         uint32_t step, float* running, int32_t* counts, uint32_t* threshold, float* stats, float* mean,
-                        float* xn, int64_t ld_xn, float* absmax, void* stream);
+                        void* xn, int xn_bf16, int64_t ld_xn, float* absmax, void* stream);
 // The column reduction that vae_nbzinb_bwd_ex leaves to a later launch (defer != null: it fills this in instead of
 // launching colreduce_kernel; the slabs in `workspace` must then stay untouched until that launch has run).
 struct VaeDeferredColreduce {
@@ -60,20 +66,25 @@ struct VaeDeferredColreduce {
 };
 
 // vae_nbzinb_bwd_overwrite / vae_nbzinb_bwd_u8(overwrite = 1) that also stores the per-workgroup maxima of |dlogits|
-int vae_nbzinb_bwd_ex(int x_dtype, int zinb, const float* logit_scale, int64_t ld_s, const float* logit_dropout, int64_t ld_p,
-                      const void* x, int64_t ld_x, const float* library, const float* gene_table, const float* rowmax,
+// l_dtype: storage of the logits AND of their gradients (VAE_L_F32 | VAE_L_BF16; leading dimensions in elements)
+enum { VAE_L_F32 = 0, VAE_L_BF16 = 1 };
+int vae_nbzinb_bwd_ex(int x_dtype, int l_dtype, int zinb, const void* logit_scale, int64_t ld_s, const void* logit_dropout,
+                      int64_t ld_p, const void* x, int64_t ld_x, const float* library, const float* gene_table, const float* rowmax,
                       const float* rowsum, const float* S, const float* g_ll, float g_scalar, int64_t B, int64_t G,
-                      float* dlogit_scale, int64_t ld_ds, float* dlogit_dropout, int64_t ld_dp, float* dlibrary, float* dpx_r,
+                      void* dlogit_scale, int64_t ld_ds, void* dlogit_dropout, int64_t ld_dp, float* dlibrary, float* dpx_r,
                       float* dbias_scale, float* dbias_dropout, float* workspace, int64_t workspace_bytes, float* absmax,
                       VaeDeferredColreduce* defer, void* stream);
 
 // vae_nbzinb_fwd_ws (streaming forward) for the step: have_stats != 0 skips the statistics launch (rowmax / rowsum came
 // from the decoder-head GEMM); ll == S == null leaves the per-strip partials ([*strips_out][2][B]) in the workspace for
 // vae_elbo_reduce_parts, which adds them up in strip order while it forms the ELBO scalars (one launch less).
-int vae_nbzinb_fwd_tiled_ex(int x_dtype, int zinb, const float* logit_scale, int64_t ld_s, const float* logit_dropout,
+int vae_nbzinb_fwd_tiled_ex(int x_dtype, int l_dtype, int zinb, const void* logit_scale, int64_t ld_s, const void* logit_dropout,
                             int64_t ld_p, const void* x, int64_t ld_x, const float* library, const float* gene_table, int64_t B,
                             int64_t G, float* ll, float* rowmax, float* rowsum, float* S, int have_stats, float* workspace,
                             int64_t workspace_bytes, int* strips_out, void* stream);
+// vae_px_rate over logits of either storage type
+int vae_px_rate_ex(int l_dtype, const void* logit_scale, int64_t ld_s, const float* library, const float* rowmax,
+                   const float* rowsum, int64_t B, int64_t G, float* px_rate, int64_t ld_r, void* stream);
 // vae_elbo_reduce whose ll[b] (and S[b]) are first formed from `strips` per-strip partials part[(s*2 + k)*B + b]
 int vae_elbo_reduce_parts(const float* part, int strips, float* ll, float* S, const float* kl_z, const float* kl_l, int64_t B,
                           float kl_weight, float gene_loss_coeff, float* out5, float* recon, void* stream);

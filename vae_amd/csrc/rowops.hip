@@ -53,10 +53,23 @@ __device__ __forceinline__ float4 load4(const uint8_t* row, int i) {
   return make_float4((float)u.x, (float)u.y, (float)u.z, (float)u.w);
 }
 
-template <bool REG, typename XT>
+// OT = float, or uint16_t: xn written as bf16 (round to nearest even) for a bf16-mode step, whose encoder products would
+// round it to bf16 when they read it anyway (same bits, half the bytes of the largest activation after the logits)
+__device__ __forceinline__ uint16_t to_bf16(float v) { return __builtin_bit_cast(uint16_t, (__bf16)v); }
+__device__ __forceinline__ void store4(float* row, int i, const float4& v) { reinterpret_cast<float4*>(row)[i] = v; }
+__device__ __forceinline__ void store4(uint16_t* row, int i, const float4& v) {
+  uint2 u;
+  u.x = (uint32_t)to_bf16(v.x) | ((uint32_t)to_bf16(v.y) << 16);
+  u.y = (uint32_t)to_bf16(v.z) | ((uint32_t)to_bf16(v.w) << 16);
+  reinterpret_cast<uint2*>(row)[i] = u;
+}
+__device__ __forceinline__ void store1(float* p, float v) { *p = v; }
+__device__ __forceinline__ void store1(uint16_t* p, float v) { *p = to_bf16(v); }
+
+template <bool REG, typename XT, typename OT>
 __global__ __launch_bounds__(256) void normalize_rows_kernel(const XT* __restrict__ x, int64_t ld, int B, int G,
                                                              int vec, float* __restrict__ mean,
-                                                             float* __restrict__ xn, int64_t ld_xn,
+                                                             OT* __restrict__ xn, int64_t ld_xn,
                                                              float* __restrict__ absmax) {
   constexpr int EPT = 20;
   __shared__ float red[4];
@@ -67,7 +80,7 @@ __global__ __launch_bounds__(256) void normalize_rows_kernel(const XT* __restric
   };
   const int b = blockIdx.x;
   const XT* row = x + (int64_t)b * ld;
-  float* orow = xn + (int64_t)b * ld_xn;
+  OT* orow = xn + (int64_t)b * ld_xn;
   if (REG) {
     const int n4 = G >> 2;
     float4 v[EPT];
@@ -90,10 +103,10 @@ __global__ __launch_bounds__(256) void normalize_rows_kernel(const XT* __restric
         float4 o;
         o.x = track(v[j].x / m - 1.f); o.y = track(v[j].y / m - 1.f);
         o.z = track(v[j].z / m - 1.f); o.w = track(v[j].w / m - 1.f);
-        reinterpret_cast<float4*>(orow)[i] = o;
+        store4(orow, i, o);
       }
     }
-    for (int i = (n4 << 2) + threadIdx.x; i < G; i += 256) orow[i] = track((float)row[i] / m - 1.f);
+    for (int i = (n4 << 2) + threadIdx.x; i < G; i += 256) store1(orow + i, track((float)row[i] / m - 1.f));
     finish();
     return;
   }
@@ -110,9 +123,9 @@ __global__ __launch_bounds__(256) void normalize_rows_kernel(const XT* __restric
   for (int i = threadIdx.x; i < n4; i += 256) {
     float4 v = load4(row, i);
     v.x = track(v.x / m - 1.f); v.y = track(v.y / m - 1.f); v.z = track(v.z / m - 1.f); v.w = track(v.w / m - 1.f);
-    reinterpret_cast<float4*>(orow)[i] = v;
+    store4(orow, i, v);
   }
-  for (int i = (n4 << 2) + threadIdx.x; i < G; i += 256) orow[i] = track((float)row[i] / m - 1.f);
+  for (int i = (n4 << 2) + threadIdx.x; i < G; i += 256) store1(orow + i, track((float)row[i] / m - 1.f));
   finish();
 }
 
@@ -439,17 +452,17 @@ __global__ __launch_bounds__(1024) void gene_prob_kernel(const int* __restrict__
 // x/mean - 1 of the MASKED row: xz = x * keep, mean over all G genes, out = xz / mean - 1.  The reference also
 // divides the masked counts by mean_g(p_g) (modules.py:209); the row normalisation that follows (modules.py:264)
 // cancels any per-batch scale, so it is not applied.  Requires G % 4 == 0 (vector path), any G.
-template <typename XT>
+template <typename XT, typename OT>
 __global__ __launch_bounds__(256) void normalize_rows_masked_kernel(const XT* __restrict__ x, int64_t ld, int B, int G,
                                                                     const uint32_t* __restrict__ thr, uint64_t seed,
                                                                     uint32_t step, float* __restrict__ mean,
-                                                                    float* __restrict__ xn, int64_t ld_xn,
+                                                                    OT* __restrict__ xn, int64_t ld_xn,
                                                                     float* __restrict__ absmax) {
   __shared__ float red[4];
   float am = 0.f;
   const int b = blockIdx.x;
   const XT* row = x + (int64_t)b * ld;
-  float* orow = xn + (int64_t)b * ld_xn;
+  OT* orow = xn + (int64_t)b * ld_xn;
   const int n4 = G >> 2;
   auto masked = [&](int i) {
     float4 v = load4(row, i);
@@ -471,20 +484,20 @@ __global__ __launch_bounds__(256) void normalize_rows_masked_kernel(const XT* __
     float4 v = masked(i);
     v.x = v.x / m - 1.f; v.y = v.y / m - 1.f; v.z = v.z / m - 1.f; v.w = v.w / m - 1.f;
     am = fmaxf(fmaxf(am, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
-    reinterpret_cast<float4*>(orow)[i] = v;
+    store4(orow, i, v);
   }
   if (absmax) vae_wave_absmax_store(absmax + blockIdx.x * VAE_NORM_WAVES + (threadIdx.x >> 6), am);
 }
 
-template <typename XT>
+template <typename XT, typename OT = float>
 static int gene_dropout_impl(const XT* x, int64_t ldx, int64_t B, int64_t G, float p, float alpha, uint64_t seed,
-                             uint32_t step, float* running, int* counts, uint32_t* thr, float* stats, float* mean, float* xn,
+                             uint32_t step, float* running, int* counts, uint32_t* thr, float* stats, float* mean, OT* xn,
                              int64_t ld_xn, float* absmax, void* stream) {
   VAE_REQUIRE(x && running && counts && thr && stats && mean && xn && B > 0 && G > 0 && ldx >= G && ld_xn >= G,
               "vae_gene_dropout: bad arguments");
   VAE_REQUIRE(p > 0.f && p <= 1.f && alpha >= 0.f && alpha <= 1.f, "vae_gene_dropout: p in (0, 1], alpha in [0, 1]");
   const bool x_ok = sizeof(XT) == 1 ? ((reinterpret_cast<uintptr_t>(x) & 3u) == 0) : vae_aligned16(x);
-  VAE_REQUIRE(G % 4 == 0 && ldx % 4 == 0 && ld_xn % 4 == 0 && x_ok && vae_aligned16(xn) && vae_aligned16(thr),
+  VAE_REQUIRE(G % 4 == 0 && ldx % 4 == 0 && ld_xn % (sizeof(OT) == 2 ? 8 : 4) == 0 && x_ok && vae_aligned16(xn) && vae_aligned16(thr),
               "vae_gene_dropout: needs G %% 4 == 0, leading dimensions %% 4 == 0 and aligned rows");
   hipStream_t st = (hipStream_t)stream;
   const int rows = 32;
@@ -494,7 +507,7 @@ static int gene_dropout_impl(const XT* x, int64_t ldx, int64_t B, int64_t G, flo
   VAE_CHECK_LAUNCH("vae_gene_dropout(count)");
   hipLaunchKernelGGL(gene_prob_kernel, dim3(1), dim3(1024), 0, st, counts, (int)B, (int)G, p, alpha, running, thr, stats);
   VAE_CHECK_LAUNCH("vae_gene_dropout(prob)");
-  hipLaunchKernelGGL((normalize_rows_masked_kernel<XT>), dim3((unsigned)B), dim3(256), 0, st, x, ldx, (int)B, (int)G, thr,
+  hipLaunchKernelGGL((normalize_rows_masked_kernel<XT, OT>), dim3((unsigned)B), dim3(256), 0, st, x, ldx, (int)B, (int)G, thr,
                      seed, step, mean, xn, ld_xn, absmax);
   VAE_CHECK_LAUNCH("vae_gene_dropout(normalize)");
   return VAE_OK;
@@ -502,8 +515,17 @@ static int gene_dropout_impl(const XT* x, int64_t ldx, int64_t B, int64_t G, flo
 
 int vae_gene_dropout_ex(const void* x, int x_dtype, int64_t ldx, int64_t B, int64_t G, float p, float alpha, uint64_t seed,
                         uint32_t step, float* running, int32_t* counts, uint32_t* threshold, float* stats, float* mean,
-                        float* xn, int64_t ld_xn, float* absmax, void* stream) {
+                        void* xn_v, int xn_bf16, int64_t ld_xn, float* absmax, void* stream) {
   VAE_REQUIRE(x_dtype == VAE_X_F32 || x_dtype == VAE_X_U8, "vae_gene_dropout: bad x_dtype");
+  if (xn_bf16) {
+    uint16_t* xn16 = (uint16_t*)xn_v;
+    if (x_dtype == VAE_X_U8)
+      return gene_dropout_impl<uint8_t, uint16_t>((const uint8_t*)x, ldx, B, G, p, alpha, seed, step, running, counts, threshold,
+                                                  stats, mean, xn16, ld_xn, absmax, stream);
+    return gene_dropout_impl<float, uint16_t>((const float*)x, ldx, B, G, p, alpha, seed, step, running, counts, threshold, stats,
+                                              mean, xn16, ld_xn, absmax, stream);
+  }
+  float* xn = (float*)xn_v;
   if (x_dtype == VAE_X_U8)
     return gene_dropout_impl<uint8_t>((const uint8_t*)x, ldx, B, G, p, alpha, seed, step, running, counts, threshold, stats,
                                       mean, xn, ld_xn, absmax, stream);
@@ -514,28 +536,34 @@ int vae_gene_dropout_ex(const void* x, int x_dtype, int64_t ldx, int64_t B, int6
 extern "C" int vae_gene_dropout(const void* x, int x_dtype, int64_t ldx, int64_t B, int64_t G, float p, float alpha,
                                 uint64_t seed, uint32_t step, float* running, int32_t* counts, uint32_t* threshold,
                                 float* stats, float* mean, float* xn, int64_t ld_xn, void* stream) {
-  return vae_gene_dropout_ex(x, x_dtype, ldx, B, G, p, alpha, seed, step, running, counts, threshold, stats, mean, xn, ld_xn,
+  return vae_gene_dropout_ex(x, x_dtype, ldx, B, G, p, alpha, seed, step, running, counts, threshold, stats, mean, xn, 0, ld_xn,
                              nullptr, stream);
 }
 
-template <typename XT>
-static int normalize_rows_impl(const XT* x, int64_t ldx, int64_t B, int64_t G, float* mean, float* xn, int64_t ld_xn, float* absmax,
+template <typename XT, typename OT = float>
+static int normalize_rows_impl(const XT* x, int64_t ldx, int64_t B, int64_t G, float* mean, OT* xn, int64_t ld_xn, float* absmax,
                                void* stream) {
   VAE_REQUIRE(x && mean && xn && B > 0 && G > 0 && ldx >= G && ld_xn >= G, "vae_normalize_rows: bad arguments");
   const bool x_ok = sizeof(XT) == 1 ? ((reinterpret_cast<uintptr_t>(x) & 3u) == 0) : vae_aligned16(x);
-  const int vec = (ldx % 4 == 0) && (ld_xn % 4 == 0) && x_ok && vae_aligned16(xn);
+  const int vec = (ldx % 4 == 0) && (ld_xn % (sizeof(OT) == 2 ? 8 : 4) == 0) && x_ok && vae_aligned16(xn);
   if (vec && G <= 256 * 4 * 20)
-    hipLaunchKernelGGL((normalize_rows_kernel<true, XT>), dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, x, ldx,
+    hipLaunchKernelGGL((normalize_rows_kernel<true, XT, OT>), dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, x, ldx,
                        (int)B, (int)G, vec, mean, xn, ld_xn, absmax);
   else
-    hipLaunchKernelGGL((normalize_rows_kernel<false, XT>), dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, x, ldx,
+    hipLaunchKernelGGL((normalize_rows_kernel<false, XT, OT>), dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, x, ldx,
                        (int)B, (int)G, vec, mean, xn, ld_xn, absmax);
   VAE_CHECK_LAUNCH("vae_normalize_rows");
   return VAE_OK;
 }
 
-int vae_normalize_rows_ex(const void* x, int x_dtype, int64_t ldx, int64_t B, int64_t G, float* mean, float* xn,
+int vae_normalize_rows_ex(const void* x, int x_dtype, int64_t ldx, int64_t B, int64_t G, float* mean, void* xn_v, int xn_bf16,
                           int64_t ld_xn, float* absmax, void* stream) {
+  if (xn_bf16) {
+    if (x_dtype == VAE_X_U8)
+      return normalize_rows_impl<uint8_t, uint16_t>((const uint8_t*)x, ldx, B, G, mean, (uint16_t*)xn_v, ld_xn, absmax, stream);
+    return normalize_rows_impl<float, uint16_t>((const float*)x, ldx, B, G, mean, (uint16_t*)xn_v, ld_xn, absmax, stream);
+  }
+  float* xn = (float*)xn_v;
   if (x_dtype == VAE_X_U8)
     return normalize_rows_impl<uint8_t>((const uint8_t*)x, ldx, B, G, mean, xn, ld_xn, absmax, stream);
   return normalize_rows_impl<float>((const float*)x, ldx, B, G, mean, xn, ld_xn, absmax, stream);

@@ -37,6 +37,26 @@ struct Layout {
 };
 
 inline int64_t up4(int64_t v) { return (v + 3) & ~(int64_t)3; }
+
+// A VAE_BF16 step keeps its gene-sized ACTIVATIONS -- the normalised counts and the (B, 2G) logits, the latter
+// overwritten in place by their gradient -- as bf16 in the workspace, as the reference's autocast(bfloat16) does
+// (config.py:87: nn.Linear outputs are bf16 tensors, and what autograd saves for the wgrad products is bf16): the
+// decoder-head product rounds its output once, the likelihood passes read 2 B per logit, and the encoder / wgrad / dgrad
+// products stage these operands without a conversion.  Only the logits' rounding changes a result (oracle: logits_bf16);
+// an operand rounded when written has the bits it would get when read.  Needs the tile pipeline's shapes;
+// VAE_BF16_F32_STORAGE=1 keeps fp32 (A/B knob).
+bool bf16_storage(const vae_step_config& c) {
+  static const bool off = getenv("VAE_BF16_F32_STORAGE") != nullptr;
+  if (off || c.precision != VAE_BF16 || c.G % 8 != 0 || c.Hd % 4 != 0 || c.H % 4 != 0 || c.Hl % 4 != 0) return false;
+  const int64_t NH = c.zinb ? 2 * (int64_t)c.G : c.G, HE = c.H + c.Hl;
+  auto ok = vae_gemm_bf16_storage_ok;
+  if (!(ok(VAE_NT, VAE_IO_C_BF16, c.B, NH, c.Hd) && ok(VAE_TN, VAE_IO_A_BF16, NH, c.Hd, c.B) && ok(VAE_NN, VAE_IO_A_BF16, c.B, c.Hd, NH)))
+    return false;
+  if (c.input_dropout_rate > 0.f)   // GeneDropout: one product per encoder
+    return ok(VAE_NT, VAE_IO_A_BF16, c.B, c.H, c.G) && ok(VAE_NT, VAE_IO_A_BF16, c.B, c.Hl, c.G) &&
+           ok(VAE_TN, VAE_IO_B_BF16, c.H, c.G, c.B) && ok(VAE_TN, VAE_IO_B_BF16, c.Hl, c.G, c.B);
+  return ok(VAE_NT, VAE_IO_A_BF16, c.B, HE, c.G) && ok(VAE_TN, VAE_IO_B_BF16, HE, c.G, c.B);
+}
 inline int64_t maxi(int64_t a, int64_t b) { return a > b ? a : b; }
 
 bool make_layout(const vae_step_config& c, Layout* lo) {
@@ -47,8 +67,9 @@ bool make_layout(const vae_step_config& c, Layout* lo) {
   const int64_t B = c.B, G = c.G, H = c.H, Hl = c.Hl, L = c.L, Hd = c.Hd;
   const int64_t NH = c.zinb ? 2 * G : G;
   lo->mean = take(B);
-  lo->ld_xn = up4(G);            // normalised counts x/mean - 1, rows padded to 16 bytes
-  lo->xn = take(B * lo->ld_xn);
+  const bool hb = bf16_storage(c);
+  lo->ld_xn = hb ? (G + 7) & ~(int64_t)7 : up4(G);   // normalised counts x/mean - 1, rows padded to 16 bytes (bf16: 8 elements)
+  lo->xn = take(hb ? B * lo->ld_xn / 2 : B * lo->ld_xn);
   lo->pre_enc0 = take(B * (H + Hl));
   lo->h_enc0 = take(B * (H + Hl));
   for (int n = 0; n < c.n_layers; ++n) { lo->ln_mz[n] = take(B); lo->ln_rz[n] = take(B); }
@@ -60,7 +81,7 @@ bool make_layout(const vae_step_config& c, Layout* lo) {
   for (int n = 0; n < c.n_layers; ++n) {
     lo->dec_pre[n] = take(B * Hd); lo->dec_h[n] = take(B * Hd); lo->ln_md[n] = take(B); lo->ln_rd[n] = take(B);
   }
-  lo->logits = take(B * NH);
+  lo->logits = take(bf16_storage(c) ? (B * NH + 1) / 2 : B * NH);   // bf16 storage: two logits per float slot
   lo->table = take(vae_gene_table_rows() * G);
   lo->ll = take(B); lo->recon = take(B); lo->rowmax = take(B); lo->rowsum = take(B); lo->S = take(B); lo->scalars = take(8);
   lo->dz_extra = take(B * L); lo->dlibrary = take(B);
@@ -77,7 +98,7 @@ bool make_layout(const vae_step_config& c, Layout* lo) {
   }
   lo->xn_z = lo->mean_z = lo->gene_thr = lo->gene_counts = -1;
   if (c.input_dropout_rate > 0.f) {
-    lo->xn_z = take(B * lo->ld_xn);
+    lo->xn_z = take(hb ? B * lo->ld_xn / 2 : B * lo->ld_xn);
     lo->mean_z = take(B);
     lo->gene_thr = take(G + 4);      // G thresholds, then mean_g(p_g)
     lo->gene_counts = take(G);
@@ -118,6 +139,8 @@ struct Ctx {
   Layout lo;
   void* st;
   // the two-f16-term pipeline needs 16-byte rows everywhere; ragged shapes run as VAE_FP32
+  bool hb() const { return bf16_storage(c); }   // logits / logit gradients held as bf16
+  int ldt() const { return hb() ? VAE_L_BF16 : VAE_L_F32; }
   bool fx() const { return c.precision == VAE_FP32_F16X2 && c.G % 4 == 0 && c.Hd % 4 == 0 && (c.H + c.Hl) % 4 == 0; }
   // the two weight matrices' maxima may come from outside (vae_step_config.weight_max_*: the optimiser keeps them)
   bool wext() const { return c.weight_max_enc && c.weight_max_heads && c.weight_max_n > 0; }
@@ -142,6 +165,19 @@ struct Ctx {
     if (slabs_out)
       return vae_gemm_slabs(layout, prec, M, N, K, A, lda, Bm, ldb, ws + lo.scratch, lo.scratch_floats * 4, slabs_out, st);
     return vae_gemm_rowstats(layout, prec, M, N, K, A, lda, Bm, ldb, C, ldc, bias, ws + lo.scratch, lo.scratch_floats * 4, stats, st);
+  }
+  // the two products over the normalised counts (xn: fp32, or bf16 when hb()): forward NT (xn = A), weight gradient TN (xn = B)
+  int enc_fwd(int64_t N, const float* xn, int slot_x, const float* W, float* C, int64_t ldc, const float* bias, int* slabs_out) const {
+    if (hb())
+      return vae_gemm_bf16io(VAE_NT, VAE_IO_A_BF16, c.B, N, c.G, xn, lo.ld_xn, W, c.G, C, ldc, bias, ws + lo.scratch, lo.scratch_floats * 4,
+                             slabs_out, nullptr, st);
+    return big(VAE_NT, c.B, N, c.G, xn, lo.ld_xn, slot_x, W, c.G, AM_WENC, C, ldc, bias, slabs_out);
+  }
+  int enc_wgrad(int64_t M, const float* dpre, int64_t ld_dpre, const float* xn, int slot_x, float* dW) const {
+    if (hb())
+      return vae_gemm_bf16io(VAE_TN, VAE_IO_B_BF16, M, c.G, c.B, dpre, ld_dpre, xn, lo.ld_xn, dW, c.G, nullptr, ws + lo.scratch,
+                             lo.scratch_floats * 4, nullptr, nullptr, st);
+    return big(VAE_TN, M, c.G, c.B, dpre, ld_dpre, AM_DPRE, xn, lo.ld_xn, slot_x, dW, c.G, nullptr, nullptr);
   }
   // nn.Dropout after a hidden LayerNorm (forward: the activation; backward: the gradient arriving there)
   int drop(float* x, int64_t ld, int64_t W, uint32_t site) const {
@@ -187,6 +223,8 @@ extern "C" int64_t vae_elbo_step_workspace_bytes(const vae_step_config* cfg) {
   return lo.total * 4;
 }
 
+extern "C" int vae_elbo_step_bf16_activations(const vae_step_config* cfg) { return cfg && bf16_storage(*cfg) ? 1 : 0; }
+
 extern "C" int64_t vae_elbo_step_ws_offset(const vae_step_config* cfg, int slice) {
   Layout lo;
   if (!cfg || !make_layout(*cfg, &lo)) return -1;
@@ -226,26 +264,25 @@ extern "C" int vae_elbo_step_forward(const vae_step_config* cfg, const vae_step_
     TRY(vae_step_prologue(p->enc_w0, HE * G, p->heads_w, NH * Hd, k.am(AM_WENC), k.am(AM_WHEADS), p->px_r, G, ws + lo.table,
                           stream));
   // encoders: x/mean-1 -> Linear(G, H+Hl) -> GELU -> LayerNorm (z and library halves)
-  TRY(vae_normalize_rows_ex(xv, c.x_dtype, ldx, B, G, ws + lo.mean, ws + lo.xn, lo.ld_xn, k.am(AM_XN), stream));
+  TRY(vae_normalize_rows_ex(xv, c.x_dtype, ldx, B, G, ws + lo.mean, ws + lo.xn, k.hb(), lo.ld_xn, k.am(AM_XN), stream));
   // GeneDropout (training): the z-encoder reads its own masked + normalised counts, the library encoder xn
   const bool gd = c.input_dropout_rate > 0.f;
   if (gd)
     TRY(vae_gene_dropout_ex(xv, c.x_dtype, ldx, B, G, c.input_dropout_rate, c.input_dropout_alpha, c.rng_seed, c.rng_step,
                             c.gene_running, (int32_t*)(ws + lo.gene_counts), (uint32_t*)(ws + lo.gene_thr),
-                            ws + lo.gene_thr + G, ws + lo.mean_z, ws + lo.xn_z, lo.ld_xn, k.am(AM_XNZ), stream));
+                            ws + lo.gene_thr + G, ws + lo.mean_z, ws + lo.xn_z, k.hb(), lo.ld_xn, k.am(AM_XNZ), stream));
   const float* px;
   if (vae_mid_supported(c)) {
     // one launch from the encoder slabs to the decoder hidden layer
     int nslab = 0;
     const float* slabs = ws + lo.scratch;
     if (gd) {  // two products (different inputs), left without bias in pre_enc0 = a single "slab"
-      TRY(k.big(VAE_NT, B, H, G, ws + lo.xn_z, lo.ld_xn, AM_XNZ, p->enc_w0, G, AM_WENC, ws + lo.pre_enc0, HE, nullptr, nullptr));
-      TRY(k.big(VAE_NT, B, Hl, G, ws + lo.xn, lo.ld_xn, AM_XN, p->enc_w0 + H * G, G, AM_WENC, ws + lo.pre_enc0 + H, HE, nullptr,
-                nullptr));
+      TRY(k.enc_fwd(H, ws + lo.xn_z, AM_XNZ, p->enc_w0, ws + lo.pre_enc0, HE, nullptr, nullptr));
+      TRY(k.enc_fwd(Hl, ws + lo.xn, AM_XN, p->enc_w0 + H * G, ws + lo.pre_enc0 + H, HE, nullptr, nullptr));
       slabs = ws + lo.pre_enc0;
       nslab = 1;
     } else {
-      TRY(k.big(VAE_NT, B, HE, G, ws + lo.xn, lo.ld_xn, AM_XN, p->enc_w0, G, AM_WENC, nullptr, HE, nullptr, &nslab));
+      TRY(k.enc_fwd(HE, ws + lo.xn, AM_XN, p->enc_w0, nullptr, HE, nullptr, &nslab));
     }
     TRY(vae_mid_forward(c, p, slabs, nslab, eps_z, eps_l, ws + lo.pre_enc0, ws + lo.h_enc0, ws + lo.ln_mz[0],
                         ws + lo.ln_rz[0], ws + lo.ln_ml, ws + lo.ln_rl, ws + lo.heads_z, ws + lo.heads_l, ws + lo.qz_v,
@@ -254,11 +291,10 @@ extern "C" int vae_elbo_step_forward(const vae_step_config* cfg, const vae_step_
     px = ws + lo.dec_h[0];
   } else {
     if (gd) {
-      TRY(k.big(VAE_NT, B, H, G, ws + lo.xn_z, lo.ld_xn, AM_XNZ, p->enc_w0, G, AM_WENC, ws + lo.pre_enc0, HE, p->enc_b0, nullptr));
-      TRY(k.big(VAE_NT, B, Hl, G, ws + lo.xn, lo.ld_xn, AM_XN, p->enc_w0 + H * G, G, AM_WENC, ws + lo.pre_enc0 + H, HE,
-                p->enc_b0 + H, nullptr));
+      TRY(k.enc_fwd(H, ws + lo.xn_z, AM_XNZ, p->enc_w0, ws + lo.pre_enc0, HE, p->enc_b0, nullptr));
+      TRY(k.enc_fwd(Hl, ws + lo.xn, AM_XN, p->enc_w0 + H * G, ws + lo.pre_enc0 + H, HE, p->enc_b0 + H, nullptr));
     } else {
-      TRY(k.big(VAE_NT, B, HE, G, ws + lo.xn, lo.ld_xn, AM_XN, p->enc_w0, G, AM_WENC, ws + lo.pre_enc0, HE, p->enc_b0, nullptr));
+      TRY(k.enc_fwd(HE, ws + lo.xn, AM_XN, p->enc_w0, ws + lo.pre_enc0, HE, p->enc_b0, nullptr));
     }
     TRY(vae_gelu_ln_fwd(ws + lo.pre_enc0, HE, p->encz_ln_g[0], p->encz_ln_b[0], B, H, ws + lo.h_enc0, HE,
                         ws + lo.ln_mz[0], ws + lo.ln_rz[0], stream));
@@ -299,14 +335,19 @@ extern "C" int vae_elbo_step_forward(const vae_step_config* cfg, const vae_step_
   // runs the split kernel; a tiny launch merges them.  Otherwise the likelihood pass computes them itself.
   VaeGemmRowStats rs{ws + lo.stat_m, ws + lo.stat_s, (int)G, lo.stat_cap, 0};
   static const bool no_gemm_stats = getenv("VAE_NO_GEMM_STATS") != nullptr;   // A/B knob
-  TRY(k.big(VAE_NT, B, NH, Hd, px, Hd, AM_PX, p->heads_w, Hd, AM_WHEADS, ws + lo.logits, NH, p->heads_b, nullptr,
-            no_gemm_stats ? nullptr : &rs));
+  if (k.hb())
+    TRY(vae_gemm_bf16io(VAE_NT, VAE_IO_C_BF16, B, NH, Hd, px, Hd, p->heads_w, Hd, ws + lo.logits, NH, p->heads_b, ws + lo.scratch,
+                        lo.scratch_floats * 4, nullptr, no_gemm_stats ? nullptr : &rs, stream));
+  else
+    TRY(k.big(VAE_NT, B, NH, Hd, px, Hd, AM_PX, p->heads_w, Hd, AM_WHEADS, ws + lo.logits, NH, p->heads_b, nullptr,
+              no_gemm_stats ? nullptr : &rs));
   if (rs.slots > 0) TRY(vae_softmax_stats_merge(ws + lo.stat_m, ws + lo.stat_s, rs.slots, B, ws + lo.rowmax, ws + lo.rowsum, stream));
   if (!k.fx()) TRY(vae_gene_table(p->px_r, G, ws + lo.table, stream));
   // streaming likelihood pass: row statistics, then (gene strip x cell chunk) tiles; its per-strip partial sums are added
   // up by the ELBO reduction
   int strips = 0;
-  TRY(vae_nbzinb_fwd_tiled_ex(c.x_dtype, c.zinb, ws + lo.logits, NH, c.zinb ? ws + lo.logits + G : nullptr, NH, xv, ldx,
+  const void* lgp = k.hb() ? (const void*)((const uint16_t*)(ws + lo.logits) + G) : (const void*)(ws + lo.logits + G);
+  TRY(vae_nbzinb_fwd_tiled_ex(c.x_dtype, k.ldt(), c.zinb, ws + lo.logits, NH, c.zinb ? lgp : nullptr, NH, xv, ldx,
                               ws + lo.library, ws + lo.table, B, G, nullptr, ws + lo.rowmax, ws + lo.rowsum, nullptr, rs.slots > 0,
                               ws + lo.fwd_part, vae_nbzinb_fwd_workspace_bytes(B, G), &strips, stream));
   TRY(vae_elbo_reduce_parts(ws + lo.fwd_part, strips, ws + lo.ll, ws + lo.S, ws + lo.kl_z, ws + lo.kl_l, B, c.kl_weight,
@@ -323,8 +364,8 @@ extern "C" int vae_elbo_step_px_rate(const vae_step_config* cfg, const float* ws
   if (!make_layout(*cfg, &lo)) return vae_set_error(VAE_ERR_ARG, "vae_elbo_step_px_rate: bad configuration");
   if (ws_bytes < lo.total * 4) return vae_set_error(VAE_ERR_ARG, "vae_elbo_step_px_rate: workspace too small");
   const int64_t NH = cfg->zinb ? 2 * (int64_t)cfg->G : cfg->G;
-  return vae_px_rate(ws + lo.logits, NH, ws + lo.library, ws + lo.rowmax, ws + lo.rowsum, cfg->B, cfg->G, px_rate, ld_r,
-                     stream);
+  return vae_px_rate_ex(bf16_storage(*cfg) ? VAE_L_BF16 : VAE_L_F32, ws + lo.logits, NH, ws + lo.library, ws + lo.rowmax,
+                        ws + lo.rowsum, cfg->B, cfg->G, px_rate, ld_r, stream);
 }
 
 extern "C" int vae_elbo_step_backward(const vae_step_config* cfg, const vae_step_tensors* p, const vae_step_tensors* g,
@@ -349,13 +390,13 @@ extern "C" int vae_elbo_step_backward_events(const vae_step_config* cfg, const v
   const float g_ll = -c.gene_loss_coeff / (float)B * c.loss_scale;
   const float g_kl = c.gene_loss_coeff * c.kl_weight / (float)B * c.loss_scale;
   float* logits = ws + lo.logits;
-  float* lp = c.zinb ? logits + G : nullptr;
+  void* lp = !c.zinb ? nullptr : (k.hb() ? (void*)((uint16_t*)logits + G) : (void*)(logits + G));
 
   // epilogue backward: logits := dlogits (in place); d px_r and the head-bias gradients are overwritten
   // its column sums (d px_r, head-bias gradients) stay as per-chunk slabs; on the fused-middle path the last launch of
   // the backward reduces them (one launch less), else a reduce launch follows at once
   VaeDeferredColreduce cr{};
-  TRY(vae_nbzinb_bwd_ex(c.x_dtype, c.zinb, logits, NH, lp, NH, xv, ldx, ws + lo.library, ws + lo.table, ws + lo.rowmax,
+  TRY(vae_nbzinb_bwd_ex(c.x_dtype, k.ldt(), c.zinb, logits, NH, lp, NH, xv, ldx, ws + lo.library, ws + lo.table, ws + lo.rowmax,
                         ws + lo.rowsum, ws + lo.S, nullptr, g_ll, B, G, logits, NH, lp, NH, ws + lo.dlibrary, g->px_r, g->heads_b,
                         c.zinb ? g->heads_b + G : nullptr, ws + lo.bwd_slabs, vae_nbzinb_bwd_workspace_bytes(B, G),
                         k.am(AM_DLOGITS), vae_mid_supported(c) ? &cr : nullptr, stream));
@@ -365,14 +406,22 @@ extern "C" int vae_elbo_step_backward_events(const vae_step_config* cfg, const v
   // whole operand (the two-f16-term scheme) would leave the weight-gradient ROWS of quiet genes with few correct bits --
   // invisible in a tensor-wide norm, but AdamW normalises per element (tests/test_configs_gpu.py, row accuracy).  The
   // dgrad below sums over genes, where the quiet ones do not matter, and every other operand of the step is uniform.
-  TRY(k.gemm(VAE_TN, NH, Hd, B, logits, NH, px, Hd, g->heads_w, Hd, nullptr, nullptr, 0));
+  if (k.hb())
+    TRY(vae_gemm_bf16io(VAE_TN, VAE_IO_A_BF16, NH, Hd, B, logits, NH, px, Hd, g->heads_w, Hd, nullptr, ws + lo.scratch,
+                        lo.scratch_floats * 4, nullptr, nullptr, stream));
+  else
+    TRY(k.gemm(VAE_TN, NH, Hd, B, logits, NH, px, Hd, g->heads_w, Hd, nullptr, nullptr, 0));
   if (event_heads_ready) {
     if (hipEventRecord((hipEvent_t)event_heads_ready, (hipStream_t)stream) != hipSuccess)
       return vae_set_error(VAE_ERR_LAUNCH, "vae_elbo_step_backward: hipEventRecord failed");
   }
   if (vae_mid_supported(c)) {
     int nslab = 0;
-    TRY(k.big(VAE_NN, B, Hd, NH, logits, NH, AM_DLOGITS, p->heads_w, Hd, AM_WHEADS, nullptr, Hd, nullptr, &nslab));
+    if (k.hb())
+      TRY(vae_gemm_bf16io(VAE_NN, VAE_IO_A_BF16, B, Hd, NH, logits, NH, p->heads_w, Hd, nullptr, Hd, nullptr, ws + lo.scratch,
+                          lo.scratch_floats * 4, &nslab, nullptr, stream));
+    else
+      TRY(k.big(VAE_NN, B, Hd, NH, logits, NH, AM_DLOGITS, p->heads_w, Hd, AM_WHEADS, nullptr, Hd, nullptr, &nslab));
     TRY(vae_mid_backward(c, p, g, ws + lo.scratch, nslab, eps_z, eps_l, use_dz_extra ? ws + lo.dz_extra : nullptr, g_kl,
                          ws + lo.dec_pre[0], ws + lo.ln_md[0], ws + lo.ln_rd[0], ws + lo.heads_z, ws + lo.heads_l,
                          ws + lo.qz_v, ws + lo.ql_v, ws + lo.dlibrary, ws + lo.pre_enc0, ws + lo.ln_mz[0], ws + lo.ln_rz[0],
@@ -392,7 +441,11 @@ extern "C" int vae_elbo_step_backward_events(const vae_step_config* cfg, const v
     }
     TRY(zero(g->encl_ln_g, Hl)); TRY(zero(g->encl_ln_b, Hl)); TRY(zero(g->enc_b0, HE));
     TRY(zero(g->hz_b, L + 1)); TRY(zero(g->hl_b, 2));
-    TRY(k.big(VAE_NN, B, Hd, NH, logits, NH, AM_DLOGITS, p->heads_w, Hd, AM_WHEADS, ws + lo.dpx, Hd, nullptr, nullptr));
+    if (k.hb())
+      TRY(vae_gemm_bf16io(VAE_NN, VAE_IO_A_BF16, B, Hd, NH, logits, NH, p->heads_w, Hd, ws + lo.dpx, Hd, nullptr, ws + lo.scratch,
+                          lo.scratch_floats * 4, nullptr, nullptr, stream));
+    else
+      TRY(k.big(VAE_NN, B, Hd, NH, logits, NH, AM_DLOGITS, p->heads_w, Hd, AM_WHEADS, ws + lo.dpx, Hd, nullptr, nullptr));
 
     // decoder hidden layers
     float* dcur = ws + lo.dpx;
@@ -455,11 +508,10 @@ extern "C" int vae_elbo_step_backward_events(const vae_step_config* cfg, const v
       return vae_set_error(VAE_ERR_LAUNCH, "vae_elbo_step_backward: hipEventRecord failed");
   }
   if (c.input_dropout_rate > 0.f) {  // GeneDropout: each encoder's weight gradient over its own input
-    TRY(k.big(VAE_TN, H, G, B, ws + lo.dpre_enc0, HE, AM_DPRE, ws + lo.xn_z, lo.ld_xn, AM_XNZ, g->enc_w0, G, nullptr, nullptr));
-    TRY(k.big(VAE_TN, Hl, G, B, ws + lo.dpre_enc0 + H, HE, AM_DPRE, ws + lo.xn, lo.ld_xn, AM_XN, g->enc_w0 + H * G, G, nullptr,
-              nullptr));
+    TRY(k.enc_wgrad(H, ws + lo.dpre_enc0, HE, ws + lo.xn_z, AM_XNZ, g->enc_w0));
+    TRY(k.enc_wgrad(Hl, ws + lo.dpre_enc0 + H, HE, ws + lo.xn, AM_XN, g->enc_w0 + H * G));
   } else {
-    TRY(k.big(VAE_TN, HE, G, B, ws + lo.dpre_enc0, HE, AM_DPRE, ws + lo.xn, lo.ld_xn, AM_XN, g->enc_w0, G, nullptr, nullptr));
+    TRY(k.enc_wgrad(HE, ws + lo.dpre_enc0, HE, ws + lo.xn, AM_XN, g->enc_w0));
   }
   return VAE_OK;
 }

@@ -150,6 +150,46 @@ def gemm_scaled(layout: int, a: torch.Tensor, b: torch.Tensor, scale_a: Optional
     return out
 
 
+IO_A_BF16, IO_B_BF16, IO_C_BF16 = 1, 2, 4
+
+
+def gemm_bf16_storage(layout: int, a: torch.Tensor, b: torch.Tensor, io: int, *, out: Optional[torch.Tensor] = None,
+                      bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``gemm(precision=BF16)`` with one matrix held as bfloat16 in HBM (include/vae_amd.h, vae_gemm_bf16_storage):
+    ``io`` = IO_A_BF16 (a is a bfloat16 tensor), IO_B_BF16 (b is; TN only) or IO_C_BF16 (the result is; NT only)."""
+    lib = _lib.load()
+    want = {IO_A_BF16: (torch.bfloat16, torch.float32, torch.float32), IO_B_BF16: (torch.float32, torch.bfloat16, torch.float32),
+            IO_C_BF16: (torch.float32, torch.float32, torch.bfloat16)}.get(io)
+    if want is None:
+        raise ValueError("io must be exactly one of IO_A_BF16, IO_B_BF16, IO_C_BF16")
+    for t, dt, name in ((a, want[0], "a"), (b, want[1], "b")):
+        if not t.is_cuda or t.dtype != dt or t.dim() != 2 or t.stride(1) != 1:
+            raise TypeError(f"vae_amd.ops.gemm_bf16_storage: {name} must be a 2-D {dt} GPU tensor with a contiguous last dim")
+    if layout == NT:
+        (M, K), (N, K2) = a.shape, b.shape
+    elif layout == NN:
+        (M, K), (K2, N) = a.shape, b.shape
+    elif layout == TN:
+        (K, M), (K2, N) = a.shape, b.shape
+    else:
+        raise ValueError("layout must be NT, NN or TN")
+    if K != K2:
+        raise ValueError(f"vae_amd.ops.gemm_bf16_storage: inner dimensions differ ({K} vs {K2})")
+    if not lib.vae_gemm_bf16_storage_ok(layout, io, M, N, K):
+        raise ValueError(f"vae_amd.ops.gemm_bf16_storage: shape {(M, N, K)} / layout {layout} / io {io} is outside the bf16-storage pipeline")
+    if out is None:
+        out = torch.empty(M, N, dtype=want[2], device=a.device)
+    if out.dtype != want[2] or tuple(out.shape) != (M, N) or out.stride(1) != 1 or not out.is_cuda:
+        raise TypeError(f"vae_amd.ops.gemm_bf16_storage: out must be a {(M, N)} {want[2]} GPU tensor")
+    _chk1d(bias, N, "bias")
+    nbytes = lib.vae_gemm_workspace_bytes(M, N, K)
+    ws = workspace(nbytes, a.device) if nbytes else None
+    rc = lib.vae_gemm_bf16_storage(layout, io, M, N, K, _p(a), _ld(a), _p(b), _ld(b), _p(out), _ld(out), _p(bias), _p(ws), nbytes,
+                                   _stream())
+    _lib.check(rc, "gemm_bf16_storage")
+    return out
+
+
 def gemm_slabs(layout: int, a: torch.Tensor, b: torch.Tensor, precision: int = FP32) -> torch.Tensor:
     """The product of ``gemm`` left as split-K partial sums: -> (n_slabs, M, N), whose sum over dim 0 is
     the result (no bias).  What the fused encoder-tail / decoder-head kernels consume."""

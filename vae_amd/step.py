@@ -141,6 +141,11 @@ class ElboStep:
             raise ValueError("ElboStep.use_weight_maxima: need a contiguous (2, P) float32 GPU tensor, P a multiple of 4")
         self.weight_maxima = t
 
+    def bf16_activations(self, B: int, train: bool = False) -> bool:
+        """Whether a step of batch size B keeps the logits / logit gradients as bf16 (include/vae_amd.h,
+        vae_elbo_step_bf16_activations): the bf16 oracle is then the one with ``logits_bf16=True``."""
+        return bool(self.lib.vae_elbo_step_bf16_activations(C.byref(self._plan(B, 1.0, train)[0])))
+
     def _plan(self, B: int, loss_scale: float, train: bool = False):
         """Config struct, workspace and named views for batch size B (cached).  GeneDropout changes the
         workspace layout, so training-mode plans with it are kept apart."""
