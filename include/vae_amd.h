@@ -95,14 +95,15 @@ int vae_gemm_scaled_slabs(int layout, int64_t M, int64_t N, int64_t K, const flo
                           const float* B, int64_t ldb, const float* scale_b, float* workspace, int64_t workspace_bytes,
                           int* n_slabs, void* stream);
 
-/* VAE_BF16 products with ONE operand, or the output, stored as bf16 in HBM (io = exactly one VAE_IO_* bit; the other
- * matrices fp32).  This is the reference's autocast(bfloat16) storage (config.py:87: nn.Linear outputs are bf16 tensors,
+/* VAE_BF16 products with operands and / or the output stored as bf16 in HBM (io = VAE_IO_* bits; the other matrices
+ * fp32).  This is the reference's autocast(bfloat16) storage (config.py:87: nn.Linear outputs are bf16 tensors,
  * and what autograd saves / hands to the wgrad and dgrad products is bf16): the bytes of the three gene-sized
  * activations (normalised counts, logits, logit gradients) halve.  Rounding an operand to bf16 when it is WRITTEN is
  * bit-identical to rounding it when the product reads it (vae_gemm(VAE_BF16)); a bf16 OUTPUT is the fp32 accumulator + bias
  * rounded to nearest even.  Leading dimensions count elements of the matrix's own type; bf16 matrices need 8-byte
  * aligned rows (the output: 16-byte, ldc % 8 == 0).  Shapes: vae_gemm_bf16_storage_ok() != 0 (the 128-wide tile pipeline:
- * no dimension <= 64, K % 4 == 0, 16-byte rows); layouts: A bf16 in any, B bf16 in VAE_TN, C bf16 in VAE_NT. */
+ * no dimension <= 64, K % 4 == 0, 16-byte rows); combinations: VAE_NT {A, A|B, C, A|B|C}, VAE_NN {A, A|B}, VAE_TN {A, B, A|B}
+ * -- what a bf16-mode training step uses (it keeps bf16 images of the gene-sized weights and of the small activations). */
 enum { VAE_IO_A_BF16 = 1, VAE_IO_B_BF16 = 2, VAE_IO_C_BF16 = 4 };
 int vae_gemm_bf16_storage_ok(int layout, int io, int64_t M, int64_t N, int64_t K);
 int vae_gemm_bf16_storage(int layout, int io, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B,

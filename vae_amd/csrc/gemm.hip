@@ -27,6 +27,7 @@
 #include <mutex>
 #include <type_traits>
 
+extern "C" int vae_gemm_bf16_storage_ok(int layout, int io, int64_t M, int64_t N, int64_t K);
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
@@ -640,6 +641,162 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
 
+// Output stage shared by the split-precision kernel and the bf16 LDS-DMA kernel below: accumulators (+ bias, scaled back)
+// -> C or the split-K slab, as fp32 or bf16, with the softmax statistics of the rows when asked for.  `smem` is the kernel's
+// LDS (operand storage, dead by now; at least 4 * 32 * 40 floats when PATCHED); every thread of the workgroup calls it.
+template <int LAYOUT, int BM, int BN, int WAVES_M, int NP, bool CBF, bool PATCHED>
+__device__ __forceinline__ void x3_epilogue(const GemmArgs& g, f32x16 (&acc)[BM / (32 * WAVES_M)][BN / (32 * (4 / WAVES_M))],
+                                            void* smem, int m0, int n0, int tn, int s, float scA, float scB) {
+  constexpr int WAVES_N = 4 / WAVES_M;
+  constexpr int TM = BM / (32 * WAVES_M), TNN = BN / (32 * WAVES_N);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  const int l31 = lane & 31, h = lane >> 5;
+  const float inv_sc = 1.f / (scA * scB);   // powers of two: exact
+  float* out = g.C;
+  int64_t ldc = g.ldc;
+  if (g.split > 1) {
+    out = g.C + (int64_t)s * g.M * g.N;
+    ldc = g.N;
+  }
+  // 16-byte stores: every 32 x 32 accumulator block goes through a private 32 x 40-float LDS patch of its wave (the
+  // operand planes are dead by now) and leaves as 4 instructions of 8 rows x 128 B instead of 16 of 2 rows x 128 B --
+  // a quarter of the vector-memory instructions against the 63-deep in-order queue of the wave.
+  const bool vec_out = PATCHED && g.vecC && !(g.split == 1 && g.accumulate);
+  float* patch = reinterpret_cast<float*>(smem) + wave * (32 * 40);
+  if (vec_out) __syncthreads();   // every wave is done with the operand planes
+  // running softmax statistics of this wave's rows over its column span: lane (8 r' + c) holds rows r' + 8 i, i < 4
+  constexpr bool STAT_OK = LAYOUT == NT && TM <= 2;         // tile shapes whose epilogue carries the statistics registers
+  const bool stats = STAT_OK && g.stat_m != nullptr;        // the host enables it only when every block takes the path below
+  float rmax[STAT_OK ? TM : 1][4], rsum[STAT_OK ? TM : 1][4];
+#pragma unroll
+  for (int mi = 0; mi < (STAT_OK ? TM : 1); ++mi)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { rmax[mi][i] = -INFINITY; rsum[mi][i] = 0.f; }
+#pragma unroll
+  for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < TNN; ++ni) {
+      const int nb = n0 + wn * (32 * TNN) + ni * 32;
+      const int n = nb + l31;
+      const float bv = (g.split == 1 && g.bias && n < g.N) ? g.bias[n] : 0.f;
+      if (CBF && vec_out && nb + 32 <= g.N) {
+        // bf16 output: the 32 x 32 block leaves as 2 instructions of 16 rows x 64 B (8 bf16 per lane)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * h) * 40 + l31] = acc[mi][ni][r] + bv;
+        uint16_t* out16 = reinterpret_cast<uint16_t*>(out);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int row = (lane >> 2) + 16 * i;
+          const int m = m0 + wm * (32 * TM) + mi * 32 + row;
+          const float4 v0 = *reinterpret_cast<const float4*>(patch + row * 40 + 8 * (lane & 3));
+          const float4 v1 = *reinterpret_cast<const float4*>(patch + row * 40 + 8 * (lane & 3) + 4);
+          bf16x8 o;
+          o[0] = (__bf16)v0.x; o[1] = (__bf16)v0.y; o[2] = (__bf16)v0.z; o[3] = (__bf16)v0.w;
+          o[4] = (__bf16)v1.x; o[5] = (__bf16)v1.y; o[6] = (__bf16)v1.z; o[7] = (__bf16)v1.w;
+          if (m < g.M) *reinterpret_cast<bf16x8*>(out16 + (int64_t)m * ldc + nb + 8 * (lane & 3)) = o;
+          if (STAT_OK && stats && nb < g.stat_cols) {   // as below, over the 8 ROUNDED values this lane stores
+            constexpr int MI = STAT_OK ? 1 : 0;
+            constexpr float L2E = 1.44269504088896341f;
+            const int c0 = nb + 8 * (lane & 3);
+            float a[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a[j] = c0 + j < g.stat_cols ? (float)o[j] : -INFINITY;
+            const float om = rmax[mi * MI][i];
+            const float nm = fmaxf(fmaxf(fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3])), fmaxf(fmaxf(a[4], a[5]), fmaxf(a[6], a[7]))), om);
+            const float nb2 = -nm * L2E;
+            if (nm > -INFINITY) {
+              float e = 0.f;
+#pragma unroll
+              for (int j = 0; j < 8; ++j) e += __builtin_amdgcn_exp2f(fmaf(a[j], L2E, nb2));
+              const float rescale = om == nm ? 1.f : __builtin_amdgcn_exp2f(fmaxf(fmaf(om, L2E, nb2), -126.f));
+              rsum[mi * MI][i] = fmaf(rsum[mi * MI][i], rescale, e);
+              rmax[mi * MI][i] = nm;
+            }
+          }
+        }
+        continue;
+      }
+      if (CBF) {   // ragged edge block of a bf16 output: element stores
+        if (n >= g.N) continue;
+        uint16_t* out16 = reinterpret_cast<uint16_t*>(out);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = m0 + wm * (32 * TM) + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          if (m < g.M) out16[(int64_t)m * ldc + n] = __builtin_bit_cast(uint16_t, (__bf16)(acc[mi][ni][r] + bv));
+        }
+        continue;
+      }
+      if (vec_out && nb + 32 <= g.N) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          patch[((r & 3) + 8 * (r >> 2) + 4 * h) * 40 + l31] = (NP == 2 ? acc[mi][ni][r] * inv_sc : acc[mi][ni][r]) + bv;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int row = (lane >> 3) + 8 * i;
+          const int m = m0 + wm * (32 * TM) + mi * 32 + row;
+          const float4 v = *reinterpret_cast<const float4*>(patch + row * 40 + 4 * (lane & 7));
+          if (m < g.M) *reinterpret_cast<float4*>(out + (int64_t)m * ldc + nb + 4 * (lane & 7)) = v;
+          if (STAT_OK && stats && nb < g.stat_cols) {
+            // lane-local running (max, sum of exp) over the columns THIS lane stores: no cross-lane traffic in the loop.
+            // Plain exp2 (no compensation): the terms that matter sit within a few units of the maximum, where the
+            // argument rounding is < 1e-7 relative; the softmax WEIGHTS downstream keep the compensated form.
+            constexpr int MI = STAT_OK ? 1 : 0;   // (index 0 when the registers are not carried)
+            constexpr float L2E = 1.44269504088896341f;
+            const int c0 = nb + 4 * (lane & 7);
+            const float a0 = c0 < g.stat_cols ? v.x : -INFINITY, a1 = c0 + 1 < g.stat_cols ? v.y : -INFINITY;
+            const float a2 = c0 + 2 < g.stat_cols ? v.z : -INFINITY, a3 = c0 + 3 < g.stat_cols ? v.w : -INFINITY;
+            const float om = rmax[mi * MI][i];
+            const float nm = fmaxf(fmaxf(fmaxf(a0, a1), fmaxf(a2, a3)), om);
+            const float nb2 = -nm * L2E;   // nm is finite unless every column so far was masked (then the terms are exp2(nan)?)
+            if (nm > -INFINITY) {
+              const float e = (__builtin_amdgcn_exp2f(fmaf(a0, L2E, nb2)) + __builtin_amdgcn_exp2f(fmaf(a1, L2E, nb2))) +
+                              (__builtin_amdgcn_exp2f(fmaf(a2, L2E, nb2)) + __builtin_amdgcn_exp2f(fmaf(a3, L2E, nb2)));
+              const float rescale = om == nm ? 1.f : __builtin_amdgcn_exp2f(fmaxf(fmaf(om, L2E, nb2), -126.f));
+              rsum[mi * MI][i] = fmaf(rsum[mi * MI][i], rescale, e);
+              rmax[mi * MI][i] = nm;
+            }
+          }
+        }
+        continue;
+      }
+      if (n >= g.N) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * (32 * TM) + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (m < g.M) {
+          float* p = out + (int64_t)m * ldc + n;
+          float v = (NP == 2 ? acc[mi][ni][r] * inv_sc : acc[mi][ni][r]) + bv;
+          if (g.split == 1 && g.accumulate) v += *p;
+          *p = v;
+        }
+      }
+    }
+  if (STAT_OK && stats && n0 + wn * (32 * TNN) < g.stat_cols) {   // (uniform per wave: every lane takes part in the shuffles)
+    const int slot = tn * WAVES_N + wn;
+#pragma unroll
+    for (int mi = 0; mi < (STAT_OK ? TM : 1); ++mi)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        // merge the 8 (bf16 output: 4) lanes that share this row: max, rescale, sum
+        if (CBF && i >= 2) continue;
+        float M = rmax[mi][i];
+        M = fmaxf(M, __shfl_xor(M, 1, 64));
+        M = fmaxf(M, __shfl_xor(M, 2, 64));
+        if (!CBF) M = fmaxf(M, __shfl_xor(M, 4, 64));
+        float sv = rmax[mi][i] > -INFINITY ? rsum[mi][i] * vae_exp_acc(rmax[mi][i] - M) : 0.f;
+        sv += __shfl_xor(sv, 1, 64);
+        sv += __shfl_xor(sv, 2, 64);
+        if (!CBF) sv += __shfl_xor(sv, 4, 64);
+        const int m = m0 + wm * (32 * TM) + mi * 32 + (CBF ? (lane >> 2) + 16 * i : (lane >> 3) + 8 * i);
+        if ((lane & (CBF ? 3 : 7)) == 0 && m < g.M) {
+          g.stat_m[(int64_t)slot * g.M + m] = M;
+          g.stat_s[(int64_t)slot * g.M + m] = sv;
+        }
+      }
+  }
+}
+
 // IO (NP == 1 only): storage type of the operands / the output in HBM.  bit 0: A holds bf16, bit 1: B holds bf16 (staged
 // by 8-byte loads straight into the operand plane -- no conversion, half the bytes), bit 2: C is written as bf16 (rounded
 // to nearest even; the softmax statistics are then taken from the ROUNDED values, the ones the consumer will read).
@@ -933,151 +1090,185 @@ __global__ __launch_bounds__(256, (NP <= 2 ? 3 : 2)) void gemm_x3_kernel(GemmArg
   }
   GSTAMP();
 
-  const float inv_sc = 1.f / (scA * scB);   // powers of two: exact
-  float* out = g.C;
-  int64_t ldc = g.ldc;
-  if (g.split > 1) {
-    out = g.C + (int64_t)s * g.M * g.N;
-    ldc = g.N;
+  x3_epilogue<LAYOUT, BM, BN, WAVES_M, NP, CBF, (NP * (PLA + PLB) * 2 >= 4 * 32 * 40 * 4)>(g, acc, smem, m0, n0, tn, s, scA, scB);
+  GSTAMP();
+}
+
+// ---------------------------------------------------------------------------------------
+// bf16 product with BOTH operands stored as bf16 in HBM (a bf16-mode step: bf16 activations and bf16 images of the
+// weights): nothing to convert, so the operands go HBM -> LDS by LDS-DMA (global_load_lds_dwordx4), two stages, one
+// barrier per 64-deep K-tile, no staging registers -- the structure of gemm32_dma_kernel with half-size elements:
+//   KC operand image: [rows][64 k] bf16 = 128-byte rows of 8 x 16 B; slot = chunk ^ ((row >> 1) & 7), applied to the
+//     SOURCE address (the DMA destination is lane-linear) and again on the read; fragments by ds_read_b128.
+//   RC operand image: [64 k][BM or BN] bf16, fragments by the transposing ds_read_b64_tr_b16; 128-wide images swizzle
+//     the 16-byte chunk with 2 (k & 3) so that the four k rows a 16-lane group reads fall into different banks
+//     (160-wide rows are 320 B apart and need none).
+// The register-staged split kernel spends a K-tile as: wait for the global loads, write LDS, two barriers, then the
+// MFMAs -- at B = 4096 a workgroup's 32-deep K step takes ~4300 cycles for 320 cycles of matrix work per wave
+// (tools/micro/gemm_probe.hip).  Here a K-tile's loads are issued a whole tile of MFMAs ahead and land by themselves.
+// K tail (K % 64 != 0, K % 8 == 0): chunks past the end read a zero page.  Output stage: x3_epilogue.
+// ---------------------------------------------------------------------------------------
+__device__ __attribute__((aligned(16))) const uint32_t g_zero16[4] = {0u, 0u, 0u, 0u};
+__device__ __forceinline__ void dma16h(const uint16_t* src, uint32_t lds_wave_base) {
+  dma16(reinterpret_cast<const float*>(src), lds_wave_base);
+}
+
+template <int LAYOUT, int BM, int BN, int WAVES_M, bool CBF>
+__global__ __launch_bounds__(256, 2) void gemm16_dma_kernel(GemmArgs g) {
+  constexpr bool A_KC = (LAYOUT != TN);
+  constexpr bool B_KC = (LAYOUT == NT);
+  constexpr int WAVES_N = 4 / WAVES_M;
+  constexpr int TM = BM / (32 * WAVES_M), TNN = BN / (32 * WAVES_N);
+  constexpr int KT = 64;
+  constexpr int PA = BM / 32, PB = BN / 32;          // 1 KB DMA pieces per wave and operand
+  constexpr int OPA = KT * BM, OPB = KT * BN;        // bf16 elements per operand per stage
+  constexpr int STAGE = OPA + OPB;
+  constexpr bool SWZ_A = !A_KC && (BM % 64 == 0), SWZ_B = !B_KC && (BN % 64 == 0);
+  __shared__ __attribute__((aligned(16))) uint16_t smem[2 * STAGE];   // 64-72 KB: two workgroups per CU
+
+  const int nwg = gridDim.x;
+  const int xcd = blockIdx.x & 7, q8 = nwg >> 3, r8 = nwg & 7;
+  const int id = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3);
+  const int tiles_m = g.tiles_m, tiles_n = g.tiles_n;
+  const int per_split = tiles_m * tiles_n;
+  const int s = id / per_split, t = id - s * per_split;
+  int tm, tn;
+  if (g.group_m > 0) {   // as gemm_x3_kernel
+    const int gsz = g.group_m * tiles_n;
+    const int grp = t / gsz, r = t - grp * gsz;
+    const int rows = min(g.group_m, tiles_m - grp * g.group_m);
+    tm = grp * g.group_m + r % rows;
+    tn = r / rows;
+  } else if (tiles_m <= tiles_n) { tm = t % tiles_m; tn = t / tiles_m; }
+  else                           { tn = t % tiles_n; tm = t / tiles_n; }
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int kbeg = s * g.k_per_split;
+  const int kend = min(g.K, kbeg + g.k_per_split);
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  const int l31 = lane & 31, h = lane >> 5;
+
+  // ---- per-lane DMA sources: one 1 KB piece per wave-instruction; ka / kb = the k offset of the lane's chunk in a tile ----
+  const uint16_t* gA = reinterpret_cast<const uint16_t*>(g.A);
+  const uint16_t* gB = reinterpret_cast<const uint16_t*>(g.B);
+  const uint16_t* zero = reinterpret_cast<const uint16_t*>(g_zero16);
+  const uint16_t* pa[PA];
+  const uint16_t* pb[PB];
+  int ka[PA], kb[PB];
+#pragma unroll
+  for (int i = 0; i < PA; ++i) {
+    const int piece = wave * PA + i;
+    if (A_KC) {
+      const int row = piece * 8 + (lane >> 3);
+      const int c8 = (lane & 7) ^ ((row >> 1) & 7);
+      ka[i] = 8 * c8;
+      pa[i] = gA + (int64_t)min(m0 + row, g.M - 1) * g.lda + kbeg + 8 * c8;
+    } else {
+      const int c = piece * 64 + lane, k = c / (BM / 8), ch = c % (BM / 8);
+      const int sc = SWZ_A ? (ch ^ (2 * (k & 3))) : ch;
+      ka[i] = k;
+      pa[i] = gA + (int64_t)(kbeg + k) * g.lda + min(m0 + 8 * sc, g.M - 8);
+    }
   }
-  // 16-byte stores: every 32 x 32 accumulator block goes through a private 32 x 40-float LDS patch of its wave (the
-  // operand planes are dead by now) and leaves as 4 instructions of 8 rows x 128 B instead of 16 of 2 rows x 128 B --
-  // a quarter of the vector-memory instructions against the 63-deep in-order queue of the wave.
-  constexpr bool PATCHED = (NP * (PLA + PLB) * 2 >= 4 * 32 * 40 * 4);
-  const bool vec_out = PATCHED && g.vecC && !(g.split == 1 && g.accumulate);
-  float* patch = reinterpret_cast<float*>(smem) + wave * (32 * 40);
-  if (vec_out) __syncthreads();   // every wave is done with the operand planes
-  // running softmax statistics of this wave's rows over its column span: lane (8 r' + c) holds rows r' + 8 i, i < 4
-  constexpr bool STAT_OK = LAYOUT == NT && TM <= 2;         // tile shapes whose epilogue carries the statistics registers
-  const bool stats = STAT_OK && g.stat_m != nullptr;        // the host enables it only when every block takes the path below
-  float rmax[STAT_OK ? TM : 1][4], rsum[STAT_OK ? TM : 1][4];
 #pragma unroll
-  for (int mi = 0; mi < (STAT_OK ? TM : 1); ++mi)
+  for (int i = 0; i < PB; ++i) {
+    const int piece = wave * PB + i;
+    if (B_KC) {
+      const int row = piece * 8 + (lane >> 3);
+      const int c8 = (lane & 7) ^ ((row >> 1) & 7);
+      kb[i] = 8 * c8;
+      pb[i] = gB + (int64_t)min(n0 + row, g.N - 1) * g.ldb + kbeg + 8 * c8;
+    } else {
+      const int c = piece * 64 + lane, k = c / (BN / 8), ch = c % (BN / 8);
+      const int sc = SWZ_B ? (ch ^ (2 * (k & 3))) : ch;
+      kb[i] = k;
+      pb[i] = gB + (int64_t)(kbeg + k) * g.ldb + min(n0 + 8 * sc, g.N - 8);
+    }
+  }
+  const int64_t step_a = A_KC ? KT : (int64_t)KT * g.lda;
+  const int64_t step_b = B_KC ? KT : (int64_t)KT * g.ldb;
+
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void_ptr)smem;
+  // left = k extent still ahead of this tile's first row (>= KT except for the last tile of a ragged K)
+  auto issue = [&](int stage, int left) {
+    const uint32_t base_a = lds0 + (uint32_t)stage * (STAGE * 2u) + (uint32_t)wave * (PA * 1024u);
+    const uint32_t base_b = lds0 + (uint32_t)stage * (STAGE * 2u) + OPA * 2u + (uint32_t)wave * (PB * 1024u);
+    const bool full = left >= KT;   // wave-uniform
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { rmax[mi][i] = -INFINITY; rsum[mi][i] = 0.f; }
+    for (int i = 0; i < PA; ++i) {
+      dma16h((full || ka[i] + (A_KC ? 8 : 1) <= left) ? pa[i] : zero, base_a + i * 1024u);
+      pa[i] += step_a;
+    }
 #pragma unroll
-  for (int mi = 0; mi < TM; ++mi)
+    for (int i = 0; i < PB; ++i) {
+      dma16h((full || kb[i] + (B_KC ? 8 : 1) <= left) ? pb[i] : zero, base_b + i * 1024u);
+      pb[i] += step_b;
+    }
+  };
+
+  // ---- fragment addressing (bf16 element offsets inside an operand image) ----
+  // KC: lane (row l31, k half h) reads chunk (2 ks + h) ^ ((row >> 1) & 7) of its row
+  // RC: 16-lane group j: rows 16 (j & 1) .. +15 of the 32-row block, k group j >> 1; lane 4q + p of the group points at
+  //     [k = 8 (j >> 1) + q (+ 4)][row0 + 4p]
+  const int la = lane & 15, lq = la >> 2, lp = la & 3, lj = lane >> 4;
+  const int ea = (l31 >> 1) & 7;
+  const int kc_a = (wm * (32 * TM) + l31) * KT, kc_b = (wn * (32 * TNN) + l31) * KT;
+  const int rc_ka = 8 * (lj >> 1) + lq;                         // k row inside a 16-deep step (+4 for the second half)
+  const int rc_ea = wm * (32 * TM) + 16 * (lj & 1) + 4 * lp;    // element column before the 32 tt offset
+  const int rc_eb = wn * (32 * TNN) + 16 * (lj & 1) + 4 * lp;
+
+  f32x16 acc[TM][TNN];
 #pragma unroll
-    for (int ni = 0; ni < TNN; ++ni) {
-      const int nb = n0 + wn * (32 * TNN) + ni * 32;
-      const int n = nb + l31;
-      const float bv = (g.split == 1 && g.bias && n < g.N) ? g.bias[n] : 0.f;
-      if (CBF && vec_out && nb + 32 <= g.N) {
-        // bf16 output: the 32 x 32 block leaves as 2 instructions of 16 rows x 64 B (8 bf16 per lane)
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * h) * 40 + l31] = acc[mi][ni][r] + bv;
-        uint16_t* out16 = reinterpret_cast<uint16_t*>(out);
+    for (int j = 0; j < TNN; ++j)
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          const int row = (lane >> 2) + 16 * i;
-          const int m = m0 + wm * (32 * TM) + mi * 32 + row;
-          const float4 v0 = *reinterpret_cast<const float4*>(patch + row * 40 + 8 * (lane & 3));
-          const float4 v1 = *reinterpret_cast<const float4*>(patch + row * 40 + 8 * (lane & 3) + 4);
-          bf16x8 o;
-          o[0] = (__bf16)v0.x; o[1] = (__bf16)v0.y; o[2] = (__bf16)v0.z; o[3] = (__bf16)v0.w;
-          o[4] = (__bf16)v1.x; o[5] = (__bf16)v1.y; o[6] = (__bf16)v1.z; o[7] = (__bf16)v1.w;
-          if (m < g.M) *reinterpret_cast<bf16x8*>(out16 + (int64_t)m * ldc + nb + 8 * (lane & 3)) = o;
-          if (STAT_OK && stats && nb < g.stat_cols) {   // as below, over the 8 ROUNDED values this lane stores
-            constexpr int MI = STAT_OK ? 1 : 0;
-            constexpr float L2E = 1.44269504088896341f;
-            const int c0 = nb + 8 * (lane & 3);
-            float a[8];
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  auto frag_kc = [&](const uint16_t* img, int base, int tt, int ks) -> bf16x8 {
+    return *reinterpret_cast<const bf16x8*>(img + base + tt * 32 * KT + (((2 * ks + h) ^ ea) << 3));
+  };
+  auto frag_rc = [&](const uint16_t* img, int W, bool swz, int e_base, int tt, int ks) -> bf16x8 {
+    const int e0 = e_base + tt * 32;
+    const int col = swz ? ((((e0 >> 3) ^ (2 * lq)) << 3) | (e0 & 7)) : e0;
+    const uint16_t* p = img + (ks * 16 + rc_ka) * W + col;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)p);
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(p + 4 * W));
+    union { s16x4 s2[2]; bf16x8 v; } u;
+    u.s2[0] = lo;
+    u.s2[1] = hi;
+    return u.v;
+  };
+  auto multiply = [&](const uint16_t* stage) {
+    const uint16_t* sa = stage;
+    const uint16_t* sb = stage + OPA;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) a[j] = c0 + j < g.stat_cols ? (float)o[j] : -INFINITY;
-            const float om = rmax[mi * MI][i];
-            const float nm = fmaxf(fmaxf(fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3])), fmaxf(fmaxf(a[4], a[5]), fmaxf(a[6], a[7]))), om);
-            const float nb2 = -nm * L2E;
-            if (nm > -INFINITY) {
-              float e = 0.f;
+    for (int ks = 0; ks < KT / 16; ++ks) {
+      bf16x8 a[TM];
 #pragma unroll
-              for (int j = 0; j < 8; ++j) e += __builtin_amdgcn_exp2f(fmaf(a[j], L2E, nb2));
-              const float rescale = om == nm ? 1.f : __builtin_amdgcn_exp2f(fmaxf(fmaf(om, L2E, nb2), -126.f));
-              rsum[mi * MI][i] = fmaf(rsum[mi * MI][i], rescale, e);
-              rmax[mi * MI][i] = nm;
-            }
-          }
-        }
-        continue;
-      }
-      if (CBF) {   // ragged edge block of a bf16 output: element stores
-        if (n >= g.N) continue;
-        uint16_t* out16 = reinterpret_cast<uint16_t*>(out);
+      for (int ti = 0; ti < TM; ++ti) a[ti] = A_KC ? frag_kc(sa, kc_a, ti, ks) : frag_rc(sa, BM, SWZ_A, rc_ea, ti, ks);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = m0 + wm * (32 * TM) + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-          if (m < g.M) out16[(int64_t)m * ldc + n] = __builtin_bit_cast(uint16_t, (__bf16)(acc[mi][ni][r] + bv));
-        }
-        continue;
-      }
-      if (vec_out && nb + 32 <= g.N) {
+      for (int tj = 0; tj < TNN; ++tj) {
+        const bf16x8 b = B_KC ? frag_kc(sb, kc_b, tj, ks) : frag_rc(sb, BN, SWZ_B, rc_eb, tj, ks);
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-          patch[((r & 3) + 8 * (r >> 2) + 4 * h) * 40 + l31] = (NP == 2 ? acc[mi][ni][r] * inv_sc : acc[mi][ni][r]) + bv;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int row = (lane >> 3) + 8 * i;
-          const int m = m0 + wm * (32 * TM) + mi * 32 + row;
-          const float4 v = *reinterpret_cast<const float4*>(patch + row * 40 + 4 * (lane & 7));
-          if (m < g.M) *reinterpret_cast<float4*>(out + (int64_t)m * ldc + nb + 4 * (lane & 7)) = v;
-          if (STAT_OK && stats && nb < g.stat_cols) {
-            // lane-local running (max, sum of exp) over the columns THIS lane stores: no cross-lane traffic in the loop.
-            // Plain exp2 (no compensation): the terms that matter sit within a few units of the maximum, where the
-            // argument rounding is < 1e-7 relative; the softmax WEIGHTS downstream keep the compensated form.
-            constexpr int MI = STAT_OK ? 1 : 0;   // (index 0 when the registers are not carried)
-            constexpr float L2E = 1.44269504088896341f;
-            const int c0 = nb + 4 * (lane & 7);
-            const float a0 = c0 < g.stat_cols ? v.x : -INFINITY, a1 = c0 + 1 < g.stat_cols ? v.y : -INFINITY;
-            const float a2 = c0 + 2 < g.stat_cols ? v.z : -INFINITY, a3 = c0 + 3 < g.stat_cols ? v.w : -INFINITY;
-            const float om = rmax[mi * MI][i];
-            const float nm = fmaxf(fmaxf(fmaxf(a0, a1), fmaxf(a2, a3)), om);
-            const float nb2 = -nm * L2E;   // nm is finite unless every column so far was masked (then the terms are exp2(nan)?)
-            if (nm > -INFINITY) {
-              const float e = (__builtin_amdgcn_exp2f(fmaf(a0, L2E, nb2)) + __builtin_amdgcn_exp2f(fmaf(a1, L2E, nb2))) +
-                              (__builtin_amdgcn_exp2f(fmaf(a2, L2E, nb2)) + __builtin_amdgcn_exp2f(fmaf(a3, L2E, nb2)));
-              const float rescale = om == nm ? 1.f : __builtin_amdgcn_exp2f(fmaxf(fmaf(om, L2E, nb2), -126.f));
-              rsum[mi * MI][i] = fmaf(rsum[mi * MI][i], rescale, e);
-              rmax[mi * MI][i] = nm;
-            }
-          }
-        }
-        continue;
-      }
-      if (n >= g.N) continue;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm * (32 * TM) + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (m < g.M) {
-          float* p = out + (int64_t)m * ldc + n;
-          float v = (NP == 2 ? acc[mi][ni][r] * inv_sc : acc[mi][ni][r]) + bv;
-          if (g.split == 1 && g.accumulate) v += *p;
-          *p = v;
-        }
+        for (int ti = 0; ti < TM; ++ti) acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ti], b, acc[ti][tj], 0, 0, 0);
       }
     }
-  if (STAT_OK && stats && n0 + wn * (32 * TNN) < g.stat_cols) {   // (uniform per wave: every lane takes part in the shuffles)
-    const int slot = tn * WAVES_N + wn;
-#pragma unroll
-    for (int mi = 0; mi < (STAT_OK ? TM : 1); ++mi)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        // merge the 8 (bf16 output: 4) lanes that share this row: max, rescale, sum
-        if (CBF && i >= 2) continue;
-        float M = rmax[mi][i];
-        M = fmaxf(M, __shfl_xor(M, 1, 64));
-        M = fmaxf(M, __shfl_xor(M, 2, 64));
-        if (!CBF) M = fmaxf(M, __shfl_xor(M, 4, 64));
-        float sv = rmax[mi][i] > -INFINITY ? rsum[mi][i] * vae_exp_acc(rmax[mi][i] - M) : 0.f;
-        sv += __shfl_xor(sv, 1, 64);
-        sv += __shfl_xor(sv, 2, 64);
-        if (!CBF) sv += __shfl_xor(sv, 4, 64);
-        const int m = m0 + wm * (32 * TM) + mi * 32 + (CBF ? (lane >> 2) + 16 * i : (lane >> 3) + 8 * i);
-        if ((lane & (CBF ? 3 : 7)) == 0 && m < g.M) {
-          g.stat_m[(int64_t)slot * g.M + m] = M;
-          g.stat_s[(int64_t)slot * g.M + m] = sv;
-        }
-      }
+  };
+
+  const int ntile = kend > kbeg ? (kend - kbeg + KT - 1) / KT : 0;
+  if (ntile > 0) issue(0, kend - kbeg);
+  dma_wait();
+  __syncthreads();  // stage 0 published
+  for (int i = 0; i < ntile; ++i) {
+    if (i + 1 < ntile) issue((i + 1) & 1, kend - kbeg - (i + 1) * KT);  // lands during the MFMAs below
+    multiply(smem + (i & 1) * STAGE);
+    dma_wait();
+    __syncthreads();  // next stage published; every wave is done reading this one
   }
-  GSTAMP();
+  x3_epilogue<LAYOUT, BM, BN, WAVES_M, 1, CBF, true>(g, acc, smem, m0, n0, tn, s, 1.f, 1.f);
 }
 
 // Sums the split-K slabs in slab order, adds the bias, writes (or accumulates into) C.
@@ -1267,14 +1458,21 @@ int gemm_impl(int layout, int precision, int64_t M, int64_t N, int64_t K, const 
     if (io & 4) split = 1;   // a bf16 output is written by the product kernel itself
   }
   // bf16 storage exists in the one-plane split kernel only: the caller (step.hip) checks the shapes with vae_gemm_bf16io_ok
-  VAE_REQUIRE(io == 0 || (precision == 1 && dma_ok && (io == 1 || io == 2 || io == 4) && !(io == 2 && layout != TN) &&
-                          !(io == 4 && (layout != NT || slabs_out || accumulate || ldc % 8 != 0 || !vae_aligned16(C)))),
+  VAE_REQUIRE(io == 0 || (precision == 1 && dma_ok && io > 0 && io <= 7 && vae_gemm_bf16_storage_ok(layout, io, M, N, K) &&
+                          !((io & 4) && (slabs_out || accumulate || ldc % 8 != 0 || !vae_aligned16(C)))),
               "vae_gemm: bf16 operand / output storage is not available for this shape, layout or alignment");
   const int tiles_m = (g.M + bm - 1) / bm;
   g.tiles_m = tiles_m;
   g.tiles_n = (g.N + bn - 1) / bn;
   const int ktiles = (g.K + BK - 1) / BK;
-  const int tiles_per_split = (ktiles + split - 1) / split;
+  // both operands bf16 in HBM: the LDS-DMA kernel (64-deep K tiles, 16-byte chunks of 8 elements)
+  static const int no_dma16 = getenv("VAE_GEMM_NO_DMA16") ? atoi(getenv("VAE_GEMM_NO_DMA16")) : 0;  // A/B knob
+  // (short contractions -- the decoder heads, K = 256: four K tiles, then a long output stage -- stay on the split kernel,
+  // whose three workgroups per CU overlap each other's output stage better than two: 220 vs 255 us at B = 4096)
+  const bool dma16k = (io & 3) == 3 && dma_ok && !no_dma16 && K >= 1024 && K % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && vae_aligned16(A) &&
+                      vae_aligned16(B) && (!a_rc || M % 8 == 0) && (!b_rc || N % 8 == 0) && M >= 8 && N >= 8;
+  int tiles_per_split = (ktiles + split - 1) / split;
+  if (dma16k) tiles_per_split = (tiles_per_split + 1) & ~1;   // slabs of whole 64-deep tiles
   g.k_per_split = tiles_per_split * BK;
   split = (ktiles + tiles_per_split - 1) / tiles_per_split;  // drop empty slabs
   g.split = split;
@@ -1332,12 +1530,27 @@ int gemm_impl(int layout, int precision, int64_t M, int64_t N, int64_t K, const 
       else if (bn == 160)         hipLaunchKernelGGL((gemm_x3_kernel<LAY, 128, 160, 4, 1, IOF>), grid1, dim3(256), 0, st, g); \
       else                        hipLaunchKernelGGL((gemm_x3_kernel<LAY, 160, 128, 1, 1, IOF>), grid1, dim3(256), 0, st, g); \
     } while (0)
-    if (io) {   // bf16 storage of one operand or of the output (combinations the step uses)
+#define VAE_DMA16_LAUNCH(LAY, CB)                                                                           \
+    do {                                                                                                   \
+      if (bm == 128 && bn == 128) hipLaunchKernelGGL((gemm16_dma_kernel<LAY, 128, 128, 2, CB>), grid1, dim3(256), 0, st, g); \
+      else if (bn == 160)         hipLaunchKernelGGL((gemm16_dma_kernel<LAY, 128, 160, 4, CB>), grid1, dim3(256), 0, st, g); \
+      else                        hipLaunchKernelGGL((gemm16_dma_kernel<LAY, 160, 128, 1, CB>), grid1, dim3(256), 0, st, g); \
+    } while (0)
+    if (dma16k) {
+      if (layout == NT && (io & 4)) VAE_DMA16_LAUNCH(NT, true);
+      else if (layout == NT) VAE_DMA16_LAUNCH(NT, false);
+      else if (layout == NN) VAE_DMA16_LAUNCH(NN, false);
+      else VAE_DMA16_LAUNCH(TN, false);
+    } else if (io) {   // bf16 storage of operands / of the output (vae_gemm_bf16_storage_ok lists the combinations)
       if (layout == NT && io == 1) VAE_X3_LAUNCH_IO(NT, 1);
-      else if (layout == NT) VAE_X3_LAUNCH_IO(NT, 4);
-      else if (layout == NN) VAE_X3_LAUNCH_IO(NN, 1);
+      else if (layout == NT && io == 3) VAE_X3_LAUNCH_IO(NT, 3);
+      else if (layout == NT && io == 4) VAE_X3_LAUNCH_IO(NT, 4);
+      else if (layout == NT) VAE_X3_LAUNCH_IO(NT, 7);
+      else if (layout == NN && io == 1) VAE_X3_LAUNCH_IO(NN, 1);
+      else if (layout == NN) VAE_X3_LAUNCH_IO(NN, 3);
       else if (io == 1) VAE_X3_LAUNCH_IO(TN, 1);
-      else VAE_X3_LAUNCH_IO(TN, 2);
+      else if (io == 2) VAE_X3_LAUNCH_IO(TN, 2);
+      else VAE_X3_LAUNCH_IO(TN, 3);
     } else if (precision == 1) {
       if (layout == NT) VAE_X3_LAUNCH(NT, 1);
       else if (layout == NN) VAE_X3_LAUNCH(NN, 1);
@@ -1356,6 +1569,7 @@ int gemm_impl(int layout, int precision, int64_t M, int64_t N, int64_t K, const 
 #undef VAE_DMA_LAUNCH
 #undef VAE_X3_LAUNCH
 #undef VAE_X3_LAUNCH_IO
+#undef VAE_DMA16_LAUNCH
   } else if (precision == 0) {
     if (layout == NT) launch_t<NT, 0>(g, norm, grid, st, plan.tile);
     else if (layout == NN) launch_t<NN, 0>(g, false, grid, st, plan.tile);
@@ -1478,12 +1692,48 @@ int vae_gemm_bf16io(int layout, int io, int64_t M, int64_t N, int64_t K, const v
                    n_slabs ? nullptr : bias, nullptr, 0, workspace, workspace_bytes, stream, n_slabs, nullptr, nullptr, 0, 0, stats,
                    io);
 }
+namespace {
+// fp32 -> bf16 (nearest even) of up to two dense arrays in one launch: the bf16 images of the gene-sized weight matrices
+// (and of small activations) that a bf16-mode step's products stream instead of the fp32 originals -- half the L2 -> LDS
+// bytes of a product whose tiles are re-read by many workgroups.  n0, n1 multiples of 4; blocks [0, split) take array 0.
+__global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ s0, uint16_t* __restrict__ d0, int64_t n0,
+                                                        const float* __restrict__ s1, uint16_t* __restrict__ d1, int64_t n1,
+                                                        int split) {
+  const bool first = (int)blockIdx.x < split;
+  const float* s = first ? s0 : s1;
+  uint16_t* d = first ? d0 : d1;
+  const int64_t n4 = (first ? n0 : n1) >> 2;
+  const int nb = first ? split : (int)gridDim.x - split, bi = first ? (int)blockIdx.x : (int)blockIdx.x - split;
+  for (int64_t i = (int64_t)bi * 256 + threadIdx.x; i < n4; i += (int64_t)nb * 256) {
+    const float4 v = reinterpret_cast<const float4*>(s)[i];
+    bf16x4 o;
+    o[0] = (__bf16)v.x; o[1] = (__bf16)v.y; o[2] = (__bf16)v.z; o[3] = (__bf16)v.w;
+    reinterpret_cast<bf16x4*>(d)[i] = o;
+  }
+}
+}  // namespace
+// d0[i] = bf16(s0[i]), i < n0, and (s1 != null) d1[i] = bf16(s1[i]), i < n1: dense, 16-byte aligned, n % 4 == 0
+int vae_cast_bf16(const float* s0, void* d0, int64_t n0, const float* s1, void* d1, int64_t n1, void* stream) {
+  VAE_REQUIRE(s0 && d0 && n0 > 0 && n0 % 4 == 0 && vae_aligned16(s0) && (reinterpret_cast<uintptr_t>(d0) & 7u) == 0,
+              "vae_cast_bf16: bad first array");
+  const bool two = s1 != nullptr;
+  VAE_REQUIRE(!two || (d1 && n1 > 0 && n1 % 4 == 0 && vae_aligned16(s1) && (reinterpret_cast<uintptr_t>(d1) & 7u) == 0),
+              "vae_cast_bf16: bad second array");
+  auto blocks = [](int64_t n) { int64_t b = (n / 4 + 255) / 256 / 4; return (int)(b < 1 ? 1 : (b > 1024 ? 1024 : b)); };
+  const int b0 = blocks(n0), b1 = two ? blocks(n1) : 0;
+  hipLaunchKernelGGL(cast_bf16_kernel, dim3(b0 + b1), dim3(256), 0, (hipStream_t)stream, s0, (uint16_t*)d0, n0, s1, (uint16_t*)d1,
+                     two ? n1 : 0, b0);
+  VAE_CHECK_LAUNCH("vae_cast_bf16");
+  return VAE_OK;
+}
 extern "C" int vae_gemm_bf16_storage_ok(int layout, int io, int64_t M, int64_t N, int64_t K) {
   if (layout < 0 || layout > 2 || M < 4 || N < 4 || K < 4 || M >= (1 << 30) || N >= (1 << 30) || K >= (1 << 30)) return 0;
-  if (!(io == 1 || io == 2 || io == 4) || (io == 2 && layout != TN) || (io == 4 && layout != NT)) return 0;
+  // combinations with a kernel behind them: NT {A, A+B, C, A+B+C}, NN {A, A+B}, TN {A, B, A+B}
+  const bool combo = layout == NT ? (io == 1 || io == 3 || io == 4 || io == 7) : layout == NN ? (io == 1 || io == 3) : (io >= 1 && io <= 3);
+  if (!combo) return 0;
   if (make_plan((int)M, (int)N, (int)K).tile != 128 || K % 4 != 0) return 0;
   if ((layout == TN && M % 4 != 0) || (layout != NT && N % 4 != 0)) return 0;
-  if (io == 4 && N % 8 != 0) return 0;
+  if ((io & 4) && N % 8 != 0) return 0;
   return 1;
 }
 extern "C" int vae_gemm_bf16_storage(int layout, int io, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B,

@@ -40,6 +40,8 @@ int vae_gemm_rowstats(int layout, int precision, int64_t M, int64_t N, int64_t K
 int vae_gemm_bf16io(int layout, int io, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B, int64_t ldb,
                     void* C, int64_t ldc, const float* bias, float* workspace, int64_t workspace_bytes, int* n_slabs,
                     VaeGemmRowStats* stats, void* stream);
+// bf16 images of up to two dense fp32 arrays (s1 nullable), one launch (gemm.hip)
+int vae_cast_bf16(const float* s0, void* d0, int64_t n0, const float* s1, void* d1, int64_t n1, void* stream);
 // rowmax[b] / rowsum[b] from the `slots` per-slot statistics a GEMM left (epilogue.hip)
 int vae_softmax_stats_merge(const float* stat_m, const float* stat_s, int slots, int64_t B, float* rowmax, float* rowsum,
                             void* stream);

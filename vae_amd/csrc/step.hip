@@ -29,6 +29,7 @@ struct Layout {
   int64_t xn_z, mean_z, gene_thr, gene_counts;  // GeneDropout: the z-encoder's own normalised counts (-1: off)
   int64_t amax[8]; int amax_n[8];  // partial maxima of the operands of the two-f16-term GEMMs (AM_*): offset, entries
   int64_t stat_m, stat_s, stat_cap;   // per-slot softmax statistics the decoder-head GEMM leaves (internal.h)
+  int64_t w_enc16, w_heads16, px16, dpre16;   // bf16 images (bf16_storage): the two gene-sized weight matrices, px, dpre_enc0
   int64_t fwd_part;       // per-strip partials of ll[b] / S_b of the streaming likelihood pass
   int64_t bwd_slabs;      // column-sum slabs of the epilogue backward (kept until the last launch of the backward)
   int64_t scratch;        // split-K slabs (shared, used by one launch at a time)
@@ -50,12 +51,11 @@ bool bf16_storage(const vae_step_config& c) {
   if (off || c.precision != VAE_BF16 || c.G % 8 != 0 || c.Hd % 4 != 0 || c.H % 4 != 0 || c.Hl % 4 != 0) return false;
   const int64_t NH = c.zinb ? 2 * (int64_t)c.G : c.G, HE = c.H + c.Hl;
   auto ok = vae_gemm_bf16_storage_ok;
-  if (!(ok(VAE_NT, VAE_IO_C_BF16, c.B, NH, c.Hd) && ok(VAE_TN, VAE_IO_A_BF16, NH, c.Hd, c.B) && ok(VAE_NN, VAE_IO_A_BF16, c.B, c.Hd, NH)))
-    return false;
+  if (c.B % 4 != 0 || (c.B * (int64_t)c.Hd) % 4 != 0) return false;
+  if (!(ok(VAE_NT, 7, c.B, NH, c.Hd) && ok(VAE_TN, 3, NH, c.Hd, c.B) && ok(VAE_NN, 3, c.B, c.Hd, NH))) return false;
   if (c.input_dropout_rate > 0.f)   // GeneDropout: one product per encoder
-    return ok(VAE_NT, VAE_IO_A_BF16, c.B, c.H, c.G) && ok(VAE_NT, VAE_IO_A_BF16, c.B, c.Hl, c.G) &&
-           ok(VAE_TN, VAE_IO_B_BF16, c.H, c.G, c.B) && ok(VAE_TN, VAE_IO_B_BF16, c.Hl, c.G, c.B);
-  return ok(VAE_NT, VAE_IO_A_BF16, c.B, HE, c.G) && ok(VAE_TN, VAE_IO_B_BF16, HE, c.G, c.B);
+    return ok(VAE_NT, 3, c.B, c.H, c.G) && ok(VAE_NT, 3, c.B, c.Hl, c.G) && ok(VAE_TN, 3, c.H, c.G, c.B) && ok(VAE_TN, 3, c.Hl, c.G, c.B);
+  return ok(VAE_NT, 3, c.B, HE, c.G) && ok(VAE_TN, 3, HE, c.G, c.B);
 }
 inline int64_t maxi(int64_t a, int64_t b) { return a > b ? a : b; }
 
@@ -95,6 +95,13 @@ bool make_layout(const vae_step_config& c, Layout* lo) {
                                  vae_nbzinb_bwd_workgroups(B, G), mid ? B * VAE_MID_WAVES : VAE_ABSMAX_PARTIALS,
                                  VAE_ABSMAX_W_SPLIT, VAE_ABSMAX_PARTIALS - VAE_ABSMAX_W_SPLIT};
     for (int i = 0; i < AM_COUNT; ++i) { lo->amax[i] = take(n[i]); lo->amax_n[i] = (int)n[i]; }
+  }
+  lo->w_enc16 = lo->w_heads16 = lo->px16 = lo->dpre16 = -1;
+  if (hb) {
+    lo->w_enc16 = take((H + Hl) * G / 2 + 4);
+    lo->w_heads16 = take(NH * Hd / 2 + 4);
+    lo->px16 = take(B * Hd / 2 + 4);
+    lo->dpre16 = take(B * (H + Hl) / 2 + 4);
   }
   lo->xn_z = lo->mean_z = lo->gene_thr = lo->gene_counts = -1;
   if (c.input_dropout_rate > 0.f) {
@@ -138,6 +145,8 @@ struct Ctx {
   float* ws;
   Layout lo;
   void* st;
+  const vae_step_tensors* par;   // the parameters (for offsets into their bf16 images)
+  uint16_t* h16(int64_t off) const { return reinterpret_cast<uint16_t*>(ws + off); }
   // the two-f16-term pipeline needs 16-byte rows everywhere; ragged shapes run as VAE_FP32
   bool hb() const { return bf16_storage(c); }   // logits / logit gradients held as bf16
   int ldt() const { return hb() ? VAE_L_BF16 : VAE_L_F32; }
@@ -168,15 +177,15 @@ struct Ctx {
   }
   // the two products over the normalised counts (xn: fp32, or bf16 when hb()): forward NT (xn = A), weight gradient TN (xn = B)
   int enc_fwd(int64_t N, const float* xn, int slot_x, const float* W, float* C, int64_t ldc, const float* bias, int* slabs_out) const {
-    if (hb())
-      return vae_gemm_bf16io(VAE_NT, VAE_IO_A_BF16, c.B, N, c.G, xn, lo.ld_xn, W, c.G, C, ldc, bias, ws + lo.scratch, lo.scratch_floats * 4,
-                             slabs_out, nullptr, st);
+    if (hb())   // bf16 xn x the bf16 image of the weight rows
+      return vae_gemm_bf16io(VAE_NT, VAE_IO_A_BF16 | VAE_IO_B_BF16, c.B, N, c.G, xn, lo.ld_xn, h16(lo.w_enc16) + (W - par->enc_w0), c.G, C,
+                             ldc, bias, ws + lo.scratch, lo.scratch_floats * 4, slabs_out, nullptr, st);
     return big(VAE_NT, c.B, N, c.G, xn, lo.ld_xn, slot_x, W, c.G, AM_WENC, C, ldc, bias, slabs_out);
   }
   int enc_wgrad(int64_t M, const float* dpre, int64_t ld_dpre, const float* xn, int slot_x, float* dW) const {
-    if (hb())
-      return vae_gemm_bf16io(VAE_TN, VAE_IO_B_BF16, M, c.G, c.B, dpre, ld_dpre, xn, lo.ld_xn, dW, c.G, nullptr, ws + lo.scratch,
-                             lo.scratch_floats * 4, nullptr, nullptr, st);
+    if (hb())   // the bf16 image of dpre (cast by the caller) x bf16 xn
+      return vae_gemm_bf16io(VAE_TN, VAE_IO_A_BF16 | VAE_IO_B_BF16, M, c.G, c.B, h16(lo.dpre16) + (dpre - (ws + lo.dpre_enc0)), ld_dpre, xn,
+                             lo.ld_xn, dW, c.G, nullptr, ws + lo.scratch, lo.scratch_floats * 4, nullptr, nullptr, st);
     return big(VAE_TN, M, c.G, c.B, dpre, ld_dpre, AM_DPRE, xn, lo.ld_xn, slot_x, dW, c.G, nullptr, nullptr);
   }
   // nn.Dropout after a hidden LayerNorm (forward: the activation; backward: the gradient arriving there)
@@ -252,7 +261,7 @@ extern "C" int vae_elbo_step_forward(const vae_step_config* cfg, const vae_step_
   Layout lo;
   TRY(check_common(cfg, p, p, xv, ldx, eps_z, eps_l, ws, ws_bytes, &lo, "vae_elbo_step_forward"));
   const vae_step_config& c = *cfg;
-  const Ctx k{c, ws, lo, stream};
+  const Ctx k{c, ws, lo, stream, p};
   const int64_t B = c.B, G = c.G, H = c.H, Hl = c.Hl, L = c.L, Hd = c.Hd, HE = c.H + c.Hl;
   const int64_t NH = c.zinb ? 2 * G : G;
 
@@ -263,6 +272,8 @@ extern "C" int vae_elbo_step_forward(const vae_step_config* cfg, const vae_step_
   } else if (k.fx())  // weight maxima of the two-f16-term products and the gene table, one launch
     TRY(vae_step_prologue(p->enc_w0, HE * G, p->heads_w, NH * Hd, k.am(AM_WENC), k.am(AM_WHEADS), p->px_r, G, ws + lo.table,
                           stream));
+  if (k.hb())   // bf16 images of the two gene-sized weight matrices: every product of this step streams those
+    TRY(vae_cast_bf16(p->enc_w0, k.h16(lo.w_enc16), HE * G, p->heads_w, k.h16(lo.w_heads16), NH * Hd, stream));
   // encoders: x/mean-1 -> Linear(G, H+Hl) -> GELU -> LayerNorm (z and library halves)
   TRY(vae_normalize_rows_ex(xv, c.x_dtype, ldx, B, G, ws + lo.mean, ws + lo.xn, k.hb(), lo.ld_xn, k.am(AM_XN), stream));
   // GeneDropout (training): the z-encoder reads its own masked + normalised counts, the library encoder xn
@@ -335,9 +346,12 @@ extern "C" int vae_elbo_step_forward(const vae_step_config* cfg, const vae_step_
   // runs the split kernel; a tiny launch merges them.  Otherwise the likelihood pass computes them itself.
   VaeGemmRowStats rs{ws + lo.stat_m, ws + lo.stat_s, (int)G, lo.stat_cap, 0};
   static const bool no_gemm_stats = getenv("VAE_NO_GEMM_STATS") != nullptr;   // A/B knob
-  if (k.hb())
-    TRY(vae_gemm_bf16io(VAE_NT, VAE_IO_C_BF16, B, NH, Hd, px, Hd, p->heads_w, Hd, ws + lo.logits, NH, p->heads_b, ws + lo.scratch,
-                        lo.scratch_floats * 4, nullptr, no_gemm_stats ? nullptr : &rs, stream));
+  if (k.hb()) {
+    TRY(vae_cast_bf16(px, k.h16(lo.px16), B * Hd, nullptr, nullptr, 0, stream));
+    TRY(vae_gemm_bf16io(VAE_NT, VAE_IO_A_BF16 | VAE_IO_B_BF16 | VAE_IO_C_BF16, B, NH, Hd, k.h16(lo.px16), Hd, k.h16(lo.w_heads16), Hd,
+                        ws + lo.logits, NH, p->heads_b, ws + lo.scratch, lo.scratch_floats * 4, nullptr, no_gemm_stats ? nullptr : &rs,
+                        stream));
+  }
   else
     TRY(k.big(VAE_NT, B, NH, Hd, px, Hd, AM_PX, p->heads_w, Hd, AM_WHEADS, ws + lo.logits, NH, p->heads_b, nullptr,
               no_gemm_stats ? nullptr : &rs));
@@ -383,7 +397,7 @@ extern "C" int vae_elbo_step_backward_events(const vae_step_config* cfg, const v
   Layout lo;
   TRY(check_common(cfg, p, g, xv, ldx, eps_z, eps_l, ws, ws_bytes, &lo, "vae_elbo_step_backward"));
   const vae_step_config& c = *cfg;
-  const Ctx k{c, ws, lo, stream};
+  const Ctx k{c, ws, lo, stream, p};
   const int64_t B = c.B, G = c.G, H = c.H, Hl = c.Hl, L = c.L, Hd = c.Hd, HE = c.H + c.Hl;
   const int64_t NH = c.zinb ? 2 * G : G;
   // d loss / d ll[b] = -coeff/B ; d loss / d kl[b] = coeff*kl_weight/B   (task.py:202,489)
@@ -406,9 +420,9 @@ extern "C" int vae_elbo_step_backward_events(const vae_step_config* cfg, const v
   // whole operand (the two-f16-term scheme) would leave the weight-gradient ROWS of quiet genes with few correct bits --
   // invisible in a tensor-wide norm, but AdamW normalises per element (tests/test_configs_gpu.py, row accuracy).  The
   // dgrad below sums over genes, where the quiet ones do not matter, and every other operand of the step is uniform.
-  if (k.hb())
-    TRY(vae_gemm_bf16io(VAE_TN, VAE_IO_A_BF16, NH, Hd, B, logits, NH, px, Hd, g->heads_w, Hd, nullptr, ws + lo.scratch,
-                        lo.scratch_floats * 4, nullptr, nullptr, stream));
+  if (k.hb())   // px16: the bf16 image the forward made
+    TRY(vae_gemm_bf16io(VAE_TN, VAE_IO_A_BF16 | VAE_IO_B_BF16, NH, Hd, B, logits, NH, k.h16(lo.px16), Hd, g->heads_w, Hd, nullptr,
+                        ws + lo.scratch, lo.scratch_floats * 4, nullptr, nullptr, stream));
   else
     TRY(k.gemm(VAE_TN, NH, Hd, B, logits, NH, px, Hd, g->heads_w, Hd, nullptr, nullptr, 0));
   if (event_heads_ready) {
@@ -418,8 +432,8 @@ extern "C" int vae_elbo_step_backward_events(const vae_step_config* cfg, const v
   if (vae_mid_supported(c)) {
     int nslab = 0;
     if (k.hb())
-      TRY(vae_gemm_bf16io(VAE_NN, VAE_IO_A_BF16, B, Hd, NH, logits, NH, p->heads_w, Hd, nullptr, Hd, nullptr, ws + lo.scratch,
-                          lo.scratch_floats * 4, &nslab, nullptr, stream));
+      TRY(vae_gemm_bf16io(VAE_NN, VAE_IO_A_BF16 | VAE_IO_B_BF16, B, Hd, NH, logits, NH, k.h16(lo.w_heads16), Hd, nullptr, Hd, nullptr,
+                          ws + lo.scratch, lo.scratch_floats * 4, &nslab, nullptr, stream));
     else
       TRY(k.big(VAE_NN, B, Hd, NH, logits, NH, AM_DLOGITS, p->heads_w, Hd, AM_WHEADS, nullptr, Hd, nullptr, &nslab));
     TRY(vae_mid_backward(c, p, g, ws + lo.scratch, nslab, eps_z, eps_l, use_dz_extra ? ws + lo.dz_extra : nullptr, g_kl,
@@ -442,8 +456,8 @@ extern "C" int vae_elbo_step_backward_events(const vae_step_config* cfg, const v
     TRY(zero(g->encl_ln_g, Hl)); TRY(zero(g->encl_ln_b, Hl)); TRY(zero(g->enc_b0, HE));
     TRY(zero(g->hz_b, L + 1)); TRY(zero(g->hl_b, 2));
     if (k.hb())
-      TRY(vae_gemm_bf16io(VAE_NN, VAE_IO_A_BF16, B, Hd, NH, logits, NH, p->heads_w, Hd, ws + lo.dpx, Hd, nullptr, ws + lo.scratch,
-                          lo.scratch_floats * 4, nullptr, nullptr, stream));
+      TRY(vae_gemm_bf16io(VAE_NN, VAE_IO_A_BF16 | VAE_IO_B_BF16, B, Hd, NH, logits, NH, k.h16(lo.w_heads16), Hd, ws + lo.dpx, Hd, nullptr,
+                          ws + lo.scratch, lo.scratch_floats * 4, nullptr, nullptr, stream));
     else
       TRY(k.big(VAE_NN, B, Hd, NH, logits, NH, AM_DLOGITS, p->heads_w, Hd, AM_WHEADS, ws + lo.dpx, Hd, nullptr, nullptr));
 
@@ -507,6 +521,7 @@ extern "C" int vae_elbo_step_backward_events(const vae_step_config* cfg, const v
     if (hipEventRecord((hipEvent_t)event_small_ready, (hipStream_t)stream) != hipSuccess)
       return vae_set_error(VAE_ERR_LAUNCH, "vae_elbo_step_backward: hipEventRecord failed");
   }
+  if (k.hb()) TRY(vae_cast_bf16(ws + lo.dpre_enc0, k.h16(lo.dpre16), B * HE, nullptr, nullptr, 0, stream));
   if (c.input_dropout_rate > 0.f) {  // GeneDropout: each encoder's weight gradient over its own input
     TRY(k.enc_wgrad(H, ws + lo.dpre_enc0, HE, ws + lo.xn_z, AM_XNZ, g->enc_w0));
     TRY(k.enc_wgrad(Hl, ws + lo.dpre_enc0 + H, HE, ws + lo.xn, AM_XN, g->enc_w0 + H * G));

@@ -156,12 +156,12 @@ IO_A_BF16, IO_B_BF16, IO_C_BF16 = 1, 2, 4
 def gemm_bf16_storage(layout: int, a: torch.Tensor, b: torch.Tensor, io: int, *, out: Optional[torch.Tensor] = None,
                       bias: Optional[torch.Tensor] = None) -> torch.Tensor:
     """``gemm(precision=BF16)`` with one matrix held as bfloat16 in HBM (include/vae_amd.h, vae_gemm_bf16_storage):
-    ``io`` = IO_A_BF16 (a is a bfloat16 tensor), IO_B_BF16 (b is; TN only) or IO_C_BF16 (the result is; NT only)."""
+    ``io`` = IO_A_BF16 (a is a bfloat16 tensor) | IO_B_BF16 (b is) | IO_C_BF16 (the result is; NT only) -- the combinations
+    ``vae_gemm_bf16_storage_ok`` accepts."""
     lib = _lib.load()
-    want = {IO_A_BF16: (torch.bfloat16, torch.float32, torch.float32), IO_B_BF16: (torch.float32, torch.bfloat16, torch.float32),
-            IO_C_BF16: (torch.float32, torch.float32, torch.bfloat16)}.get(io)
-    if want is None:
-        raise ValueError("io must be exactly one of IO_A_BF16, IO_B_BF16, IO_C_BF16")
+    if not 0 < io < 8:
+        raise ValueError("io must be a combination of IO_A_BF16, IO_B_BF16, IO_C_BF16")
+    want = tuple(torch.bfloat16 if io & bit else torch.float32 for bit in (IO_A_BF16, IO_B_BF16, IO_C_BF16))
     for t, dt, name in ((a, want[0], "a"), (b, want[1], "b")):
         if not t.is_cuda or t.dtype != dt or t.dim() != 2 or t.stride(1) != 1:
             raise TypeError(f"vae_amd.ops.gemm_bf16_storage: {name} must be a 2-D {dt} GPU tensor with a contiguous last dim")
