@@ -295,6 +295,64 @@ def test_midsize_against_oracle(likelihood, precision):
         assert rel_err(v.cpu().numpy(), o_grads[k].numpy()) < TOL_GRAD, k
 
 
+@pytest.mark.parametrize("widths", [(256, 128, 256, 30), (192, 64, 320, 17), (512, 256, 576, 32), (128, 128, 128, 10)],
+                         ids=["cfg2_widths", "ragged_lanes", "wide", "narrow"])
+@pytest.mark.parametrize("precision", [0, 3, 1], ids=["bf16x3", "f16x2", "bf16"])
+def test_wave_per_cell_middle_against_oracle(widths, precision):
+    """From 768 cells on, a 1-layer step runs the wave-per-cell middle kernels (middle.hip: one wave owns a cell, weights
+    staged once per workgroup, DPP reductions); the workgroup-per-cell kernels serve smaller batches and are what the
+    other step tests see.  B = 1024 with hidden dropout and a gradient arriving from cell heads (dz_extra), every
+    instantiated (elements per lane) class, vs the oracle fed the host-regenerated masks."""
+    from oracle import vae_oracle as O
+    from vae_amd.arena import ParamArena
+    from vae_amd.step import ElboStep
+    from helpers import dropout_multiplier
+    H, Hl, Hd, L = widths
+    B, G = 1024, 1600
+    p_drop, seed, rng_step = 0.25, 424242, 3
+    props = {"Dx": {"discrete": True, "values": [0, 1, 2], "stop_grad": False}}
+    p = O.init_params(G, H, Hd, Hl, L, 1, seed=15, cell_properties=props)
+    x = O.synthetic_counts(B, G, seed=15, zero_inflate=0.3)
+    g = torch.Generator().manual_seed(16)
+    eps_z, eps_l = torch.randn(B, L, generator=g), torch.randn(B, 1, generator=g)
+    targets = torch.randint(0, 3, (B, 1), generator=g).float()
+    mask = (torch.rand(B, 1, generator=g) > 0.2).float()
+    lm, lv = O.library_prior(x)
+    masks = {"z_encoder": [torch.from_numpy(dropout_multiplier(p_drop, seed, rng_step, 0, B, H))],
+             "decoder": [torch.from_numpy(dropout_multiplier(p_drop, seed, rng_step, 2, B, Hd))]}
+    bf16 = precision == 1
+    cast = (lambda t: t.float()) if bf16 else (lambda t: t.double())
+    arena = ParamArena(p, 1, "zinb", "cuda")
+    step = ElboStep(arena, l_mean=lm, l_var=lv, precision=precision, dropout_rate=p_drop, seed=seed)
+    kw = dict(n_layers=1, likelihood="zinb", l_mean=lm, l_var=lv, cell_properties=props, grad_reverse={}, cell_targets=cast(targets),
+              cell_mask=cast(mask), drop_masks={k: [cast(m) for m in v] for k, v in masks.items()})
+    if bf16:
+        kw.update(gemm_dtype=torch.bfloat16, logits_bf16=step.bf16_activations(B, train=True))
+    o_out, o_grads = O.training_step_with_grads({k: cast(v) for k, v in p.items()}, cast(x), cast(eps_z), cast(eps_l), **kw)
+    from vae_amd.modules import CellDecoder
+    from vae_amd.task import cell_loss
+    dec = CellDecoder(L, props, grad_reverse_dict={}, use_hidden_layer=False).cuda()
+    for leaf in ("weight", "bias"):
+        q = getattr(dec.cell_mlp["Dx"], leaf)
+        q.data, q.grad = arena.p(f"cell_decoder.cell_mlp.Dx.{leaf}"), arena.g(f"cell_decoder.cell_mlp.Dx.{leaf}")
+    t, m = targets.cuda(), mask.cuda()
+    out = step.run(x.cuda(), eps_z.cuda(), eps_l.cuda(), cell_head_fn=lambda z: cell_loss(dec(z), props, t, m), rng_step=rng_step)
+    torch.cuda.synchronize()
+    tc, tg = (2e-3, 3e-2) if bf16 else (TOL_CELL, TOL_GRAD)
+    for k in ("qz_m", "z", "library", "recon", "kl_z", "kl_l"):
+        ref = o_out[k].double().numpy()
+        kt = tc if not bf16 else (10 * tc if k in ("kl_z", "kl_l") else 3 * tc)   # bf16: latent entries near zero vs the max-norm
+        assert rel_err(out[k].cpu().numpy().reshape(ref.shape), ref) < kt, k
+    assert abs(float(out["loss"]) - float(o_out["loss"])) < tc * abs(float(o_out["loss"]))
+    n = 0
+    for k, v in arena.grads().items():
+        if v is None or o_grads[k] is None or k.startswith("cell_decoder"):
+            continue
+        assert rel_err(v.cpu().numpy(), o_grads[k].double().numpy()) < tg, k
+        n += 1
+    assert n >= 20
+
+
 # ------------------------------------------------------------------------------------------------
 # BASELINE.json configs[1] at FULL size (B=512, G=20000, hidden 256/128, latent 30, ZINB, fp32):
 # direct comparison with the fp64 oracle plus size-independent properties of the step.

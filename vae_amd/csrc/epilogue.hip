@@ -1036,7 +1036,7 @@ int vae_nbzinb_fwd_tiled_ex(int x_dtype, int l_dtype, int zinb, const void* logi
   const bool vec = (G % 4 == 0) && (ld_s % 4 == 0) && (ld_x % 4 == 0) && (!zinb || ld_p % 4 == 0) &&
                    logits_aligned(logit_scale, l_dtype) && x_ok && (!zinb || logits_aligned(logit_dropout, l_dtype)) &&
                    vae_aligned16(gene_table);
-  VAE_REQUIRE(!(u8 || l16) || vec, "vae_nbzinb_fwd_ws: uint8 counts / bf16 logits need G %% 4 == 0, leading dimensions %% 4 == 0 and aligned rows");
+  VAE_REQUIRE(!(u8 || l16) || vec, "vae_nbzinb_fwd_u8 / bf16 logits: need G %% 4 == 0, leading dimensions %% 4 == 0 and aligned rows");
   hipStream_t st = (hipStream_t)stream;
   if (!have_stats) {
     if (l16)      hipLaunchKernelGGL((softmax_stats_kernel<true, bf16_t>), dim3((unsigned)B), dim3(256), 0, st, (const bf16_t*)logit_scale, ld_s, (int)G, rowmax, rowsum);

@@ -85,12 +85,40 @@ __device__ __forceinline__ void slab_sum(const float* __restrict__ base, int nsl
   else slab_sum_ne<2>(base, nslab, stride, W, v);
 }
 
+// Wave-wide sum / max on the DPP path: quad butterfly, two rotations inside the 16-lane row, then the four row totals
+// through scalar registers -- ~12 short instructions, where __shfl_xor (ds_bpermute) costs an LDS round trip per step
+// (a 31-output head loop of shuffled reductions was 9 us of a cell's 28).  Every lane gets the result; fixed order.
+template <int CTRL>
+__device__ __forceinline__ float dpp_move(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float row_total(float v) {   // lanes 0, 16, 32, 48 hold their row's value
+  const int i = __float_as_int(v);
+  return (__int_as_float(__builtin_amdgcn_readlane(i, 0)) + __int_as_float(__builtin_amdgcn_readlane(i, 16))) +
+         (__int_as_float(__builtin_amdgcn_readlane(i, 32)) + __int_as_float(__builtin_amdgcn_readlane(i, 48)));
+}
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+  v += dpp_move<0xB1>(v);    // quad_perm [1, 0, 3, 2]
+  v += dpp_move<0x4E>(v);    // quad_perm [2, 3, 0, 1]
+  v += dpp_move<0x124>(v);   // row_ror:4
+  v += dpp_move<0x128>(v);   // row_ror:8
+  return row_total(v);
+}
+__device__ __forceinline__ float wave_max_dpp(float v) {
+  v = fmaxf(v, dpp_move<0xB1>(v));
+  v = fmaxf(v, dpp_move<0x4E>(v));
+  v = fmaxf(v, dpp_move<0x124>(v));
+  v = fmaxf(v, dpp_move<0x128>(v));
+  const int i = __float_as_int(v);
+  return fmaxf(fmaxf(__int_as_float(__builtin_amdgcn_readlane(i, 0)), __int_as_float(__builtin_amdgcn_readlane(i, 16))),
+               fmaxf(__int_as_float(__builtin_amdgcn_readlane(i, 32)), __int_as_float(__builtin_amdgcn_readlane(i, 48))));
+}
 // Sums N values over the workgroup's NWV waves (wave order); red holds >= NWV*N floats.  Every thread gets all sums.
 template <int N>
 __device__ __forceinline__ void block_sums(float (&v)[N], float* red) {
   const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
 #pragma unroll
-  for (int i = 0; i < N; ++i) v[i] = wave_sum(v[i]);
+  for (int i = 0; i < N; ++i) v[i] = wave_sum_dpp(v[i]);
   __syncthreads();
   if (l == 0) {
 #pragma unroll
@@ -166,7 +194,7 @@ __device__ __forceinline__ void reparam_wave(const float* hd, int L, float eps_l
     z_row[lane] = zz;
     if (z_lds) z_lds[lane] = zz;
   }
-  acc = wave_sum(acc);
+  acc = wave_sum_dpp(acc);
   if (lane == 0) {
     *qv_out = v;
     *kl_out = acc;
@@ -229,6 +257,12 @@ __global__ __launch_bounds__(T) void mid_fwd_kernel(MidFwd a) {
     const int n = o < L + 3 ? (zo ? H : Hl) : 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) hw[r][i] = lane + 64 * i < n ? w[lane + 64 * i] : 0.f;
+  }
+  float hbias[RH];   // bias of this wave's head outputs (first pass), requested with everything else
+#pragma unroll
+  for (int r = 0; r < RH; ++r) {
+    const int o = wave + NWV * r;
+    hbias[r] = o < L + 3 ? (o <= L ? a.hz_b[o] : a.hl_b[o - L - 1]) : 0.f;
   }
   float epsz = 0.f, epsl = 0.f;
   if (wave == 0 && lane < L) epsz = a.eps_z[(int64_t)b * L + lane];
@@ -303,8 +337,8 @@ __global__ __launch_bounds__(T) void mid_fwd_kernel(MidFwd a) {
 #pragma unroll
       for (int r = 0; r < RH; ++r) {
         const int o = base + NWV * r;
-        const float v = wave_sum(acc[r]);
-        if (lane == 0 && o < L + 3) hd[o] = v + (o <= L ? a.hz_b[o] : a.hl_b[o - L - 1]);
+        const float v = wave_sum_dpp(acc[r]);
+        if (lane == 0 && o < L + 3) hd[o] = v + (base == wave ? hbias[r] : (o <= L ? a.hz_b[o] : a.hl_b[o - L - 1]));
       }
     }
   }
@@ -385,7 +419,7 @@ __device__ __forceinline__ void reparam_bwd_wave(const float* dz_lds, const floa
     dq_lds[lane] = o;
     dv = d * eps_row[lane];
   }
-  dv = wave_sum(dv);
+  dv = wave_sum_dpp(dv);
   dv = dv * 0.5f / sq + gk * (float)L * 0.5f * (1.f / pv - 1.f / v);
   const float o = dv * softplus20_grad(hrow[L]);
   if (lane == 0) {
@@ -540,6 +574,508 @@ __global__ __launch_bounds__(T) void mid_bwd_kernel(MidBwd a) {
 }
 
 // ---------------------------------------------------------------------------------------
+// Wave-per-cell form of the two kernels above.  The workgroup-per-cell kernels are one latency chain per cell -- a dozen
+// workgroup barriers and three dependent global round trips, ~20 us whatever the batch -- and a CU holds three of them: at
+// B = 4096 the pair costs 260 us for a few MB and a few MFLOP per cell.  Here ONE WAVE owns a cell: lane l holds elements
+// l, l + 64, ... of every hidden vector, all reductions are wave shuffles (no barrier after the set-up), and the
+// weights every cell needs -- the first decoder Linear (Hd, L) and the latent heads (L + 1, H), (2, Hl) -- are staged
+// in LDS ONCE per workgroup, whose WPB waves then walk over cells b = first, first + stride, ...  Results are the same
+// expressions in a different summation order (lane-strided partial sums, then a butterfly).
+// ---------------------------------------------------------------------------------------
+template <int N>
+__device__ __forceinline__ void wave_sums(float (&v)[N]) {
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] = wave_sum_dpp(v[i]);
+}
+__device__ __forceinline__ float lane_bcast(float v, int src) {   // src wave-uniform
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
+}
+
+// LDS image shared by both directions: Wd[Hd][LP] (LP = L | 1: a lane's row reads are conflict-free), Wz[L + 1][H],
+// Wl[2][Hl]
+struct MidLds {
+  float *wd, *wz, *wl;
+  int LP;
+};
+__device__ __forceinline__ MidLds mid_stage_weights(float* dyn, const float* __restrict__ d_w, const float* __restrict__ hz_w,
+                                                    const float* __restrict__ hl_w, int H, int Hl, int L, int Hd, int nthreads) {
+  MidLds m;
+  m.LP = L | 1;
+  m.wd = dyn;
+  m.wz = dyn + ((Hd * m.LP + 3) & ~3);
+  m.wl = m.wz + (L + 1) * H;
+  const int t = threadIdx.x;
+  // every load of a batch is in flight before the first LDS store (a dependent round trip costs ~2 us here): the head
+  // weights as 16-byte copies (H % 4 == 0, 16-byte aligned: the host checks), 8 per thread and batch; the decoder weight
+  // element-wise into its odd-stride image (d_w is (Hd, L) with L odd or even: no vector alignment), 16 per batch
+  const int nz4 = ((L + 1) * H) >> 2;
+  for (int i0 = 0; i0 < nz4; i0 += nthreads * 8) {
+    float4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = i0 + t + nthreads * u;
+      v[u] = i < nz4 ? reinterpret_cast<const float4*>(hz_w)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = i0 + t + nthreads * u;
+      if (i < nz4) reinterpret_cast<float4*>(m.wz)[i] = v[u];
+    }
+  }
+  const int total = Hd * L;
+  const float invL = 1.f / (float)L;
+  for (int i0 = 0; i0 < total; i0 += nthreads * 16) {
+    float v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int i = i0 + t + nthreads * u;
+      v[u] = i < total ? d_w[i] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int i = i0 + t + nthreads * u;
+      int r = (int)((float)i * invL);        // i / L for i < 2^20: the float quotient is off by at most one
+      r += (r + 1) * L <= i ? 1 : 0;
+      r -= r * L > i ? 1 : 0;
+      if (i < total) m.wd[r * m.LP + (i - r * L)] = v[u];
+    }
+  }
+  for (int i = t; i < 2 * Hl; i += nthreads) m.wl[i] = hl_w[i];
+  return m;
+}
+
+// Sum of the nslab split-K partials of this lane's NE elements of row `base`, slab order, 16 slabs in flight.
+template <int NE, int WPB>
+__device__ __forceinline__ void slab_sum_wave(const float* __restrict__ base, int nslab, int64_t stride, int W, int lane,
+                                              float (&v)[NE]) {
+  constexpr int U = (WPB <= 4 ? 128 : 64) / NE;   // loads in flight per lane: workgroups of <= 4 waves have 256 registers
+#pragma unroll
+  for (int i = 0; i < NE; ++i) v[i] = 0.f;
+  for (int s = 0; s < nslab; s += U) {
+    float w[NE][U];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int i = 0; i < NE; ++i)
+        w[i][u] = (lane + 64 * i < W && s + u < nslab) ? base[(int64_t)(s + u) * stride + lane + 64 * i] : 0.f;
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int i = 0; i < NE; ++i) v[i] += w[i][u];
+  }
+}
+
+template <int NEE, int NED, int WPB>
+__global__ __launch_bounds__(64 * WPB) void mid_fwd_wave_kernel(MidFwd a) {
+  extern __shared__ __attribute__((aligned(16))) float dyn[];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int H = a.H, Hl = a.Hl, HE = a.H + a.Hl, L = a.L, Hd = a.Hd;
+  STAMP(0);
+  const MidLds w = mid_stage_weights(dyn, a.d_w, a.hz_w, a.hl_w, H, Hl, L, Hd, 64 * WPB);
+  const int LP = w.LP;
+  // per-lane parameters, kept for every cell of this wave
+  float eb[NEE], gam[NEE], bet[NEE], db[NED], dgam[NED], dbet[NED];
+#pragma unroll
+  for (int i = 0; i < NEE; ++i) {
+    const int e = lane + 64 * i;
+    const bool zh = e < H;
+    eb[i] = e < HE ? a.enc_b0[e] : 0.f;
+    gam[i] = e < HE ? (zh ? a.gz[e] : a.gl[e - H]) : 0.f;
+    bet[i] = e < HE ? (zh ? a.bz[e] : a.bl[e - H]) : 0.f;
+  }
+#pragma unroll
+  for (int i = 0; i < NED; ++i) {
+    const int n = lane + 64 * i;
+    db[i] = n < Hd ? a.d_b[n] : 0.f;
+    dgam[i] = n < Hd ? a.gd[n] : 0.f;
+    dbet[i] = n < Hd ? a.bd[n] : 0.f;
+  }
+  // head biases: lane j <= L holds the bias of z head j; lanes 0, 1 those of the library heads
+  const float hzb = lane <= L ? a.hz_b[lane] : 0.f;
+  const float hlb = lane < 2 ? a.hl_b[lane] : 0.f;
+  __syncthreads();   // the LDS images are complete; no barrier below
+  STAMP(1);
+
+  for (int b = blockIdx.x * WPB + wave; b < a.B; b += gridDim.x * WPB) {
+    const float epsz = lane < L ? a.eps_z[(int64_t)b * L + lane] : 0.f;
+    const float epsl = a.eps_l[b];
+    // 1. pre-activation of both first layers, GELU
+    float pre[NEE], g[NEE];
+    slab_sum_wave<NEE, WPB>(a.slabs + (int64_t)b * HE, a.nslab, a.slab_stride, HE, lane, pre);
+    float st[2] = {0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < NEE; ++i) {
+      const int e = lane + 64 * i;
+      if (e < HE) {
+        pre[i] += eb[i];
+        a.pre_enc0[(int64_t)b * HE + e] = pre[i];
+      }
+      g[i] = e < HE ? gelu_f(pre[i]) : 0.f;
+      st[e < H ? 0 : 1] += g[i];
+    }
+    STAMP(2);
+    // 2. LayerNorm of the two halves
+    wave_sums<2>(st);
+    const float mu0 = st[0] / (float)H, mu1 = st[1] / (float)Hl;
+    float q[2] = {0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < NEE; ++i) {
+      const int e = lane + 64 * i;
+      if (e < H) { const float d = g[i] - mu0; q[0] += d * d; }
+      else if (e < HE) { const float d = g[i] - mu1; q[1] += d * d; }
+    }
+    wave_sums<2>(q);
+    const float rs0 = 1.f / sqrtf(q[0] / (float)H + 1e-5f), rs1 = 1.f / sqrtf(q[1] / (float)Hl + 1e-5f);
+    float h[NEE];
+#pragma unroll
+    for (int i = 0; i < NEE; ++i) {
+      const int e = lane + 64 * i;
+      h[i] = 0.f;
+      if (e < HE) {
+        const bool zh = e < H;
+        float v = (g[i] - (zh ? mu0 : mu1)) * (zh ? rs0 : rs1) * gam[i] + bet[i];
+        if (zh && a.drop.on()) v *= a.drop.mult(VAE_SITE_ENC_Z(0), b, H, e);
+        h[i] = v;
+        a.h_enc0[(int64_t)b * HE + e] = v;
+      }
+    }
+    if (lane == 0) {
+      a.ln_mz[b] = mu0; a.ln_rz[b] = rs0;
+      a.ln_ml[b] = mu1; a.ln_rl[b] = rs1;
+    }
+    STAMP(3);
+    // 3. heads: lane j <= L ends up with z head j, lanes 0 / 1 of `hl` with the library heads.  Branch-free inner loops
+    //    (clamped LDS offsets, zeroed multipliers) so that the LDS reads of several outputs are in flight together.
+    float hz = 0.f, hl = 0.f;
+    float hzv[NEE], hlv[NEE];
+    int oz[NEE], ol[NEE];
+#pragma unroll
+    for (int i = 0; i < NEE; ++i) {
+      const int e = lane + 64 * i;
+      hzv[i] = e < H ? h[i] : 0.f;
+      hlv[i] = (e >= H && e < HE) ? h[i] : 0.f;
+      oz[i] = min(e, H - 1);
+      ol[i] = min(max(e - H, 0), Hl - 1);
+    }
+    for (int o0 = 0; o0 <= L; o0 += 4) {   // four outputs at a time: independent reduction chains
+      float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float* wr = w.wz + min(o0 + u, L) * H;
+#pragma unroll
+        for (int i = 0; i < NEE; ++i) acc[u] = fmaf(hzv[i], wr[oz[i]], acc[u]);
+      }
+      wave_sums<4>(acc);
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (lane == o0 + u) hz = acc[u];
+    }
+    {
+      float acc[2] = {0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < NEE; ++i) {
+        acc[0] = fmaf(hlv[i], w.wl[ol[i]], acc[0]);
+        acc[1] = fmaf(hlv[i], w.wl[Hl + ol[i]], acc[1]);
+      }
+      wave_sums<2>(acc);
+      hl = lane == 0 ? acc[0] : (lane == 1 ? acc[1] : 0.f);
+    }
+    hz += hzb;
+    hl += hlb;
+    if (lane <= L) a.heads_z[(int64_t)b * (L + 1) + lane] = hz;
+    if (lane < 2) a.heads_l[(int64_t)b * 2 + lane] = hl;
+    STAMP(4);
+    // 4. reparameterised samples + KL (reparam_wave above, with the heads in lanes instead of LDS)
+    float zj;
+    {
+      const float v = softplus20(lane_bcast(hz, L)) + 1e-4f;
+      const float sq = sqrtf(v);
+      const float r = sq * sq;     // prior N(0, 1): (sq / 1)^2 as reparam_wave forms it
+      const float lr = logf(r);
+      float acc = 0.f;
+      zj = 0.f;
+      if (lane < L) {
+        acc = 0.5f * (r + hz * hz - 1.f - lr);
+        zj = hz + epsz * sq;
+        a.z[(int64_t)b * L + lane] = zj;
+      }
+      acc = wave_sum_dpp(acc);
+      if (lane == 0) { a.qz_v[b] = v; a.kl_z[b] = acc; }
+    }
+    {
+      const float m = lane_bcast(hl, 0);
+      const float v = softplus20(lane_bcast(hl, 1)) + 1e-4f;
+      const float sq = sqrtf(v), sp = sqrtf(a.l_var);
+      const float r0 = sq / sp, r = r0 * r0;
+      const float tt = (m - a.l_mean) / sp;
+      if (lane == 0) {
+        a.ql_v[b] = v;
+        a.kl_l[b] = 0.5f * (r + tt * tt - 1.f - logf(r));
+        a.library[b] = m + epsl * sq;
+      }
+    }
+    STAMP(5);
+    // 5. first decoder layer: Linear(L -> Hd) + GELU + LayerNorm; z_j broadcast from lane j, weight rows from LDS
+    float pd[NED];
+    int od[NED];
+#pragma unroll
+    for (int i = 0; i < NED; ++i) { pd[i] = 0.f; od[i] = min(lane + 64 * i, Hd - 1) * LP; }
+#pragma unroll 6
+    for (int j = 0; j < L; ++j) {
+      const float z1 = lane_bcast(zj, j);
+#pragma unroll
+      for (int i = 0; i < NED; ++i) pd[i] = fmaf(z1, w.wd[od[i] + j], pd[i]);
+    }
+    STAMP(6);
+    float gd[NED];
+    float sd[1] = {0.f};
+#pragma unroll
+    for (int i = 0; i < NED; ++i) {
+      const int n = lane + 64 * i;
+      gd[i] = 0.f;
+      if (n < Hd) {
+        pd[i] += db[i];
+        a.dec_pre[(int64_t)b * Hd + n] = pd[i];
+        gd[i] = gelu_f(pd[i]);
+      }
+      sd[0] += gd[i];
+    }
+    wave_sums<1>(sd);
+    const float mud = sd[0] / (float)Hd;
+    float qd[1] = {0.f};
+#pragma unroll
+    for (int i = 0; i < NED; ++i)
+      if (lane + 64 * i < Hd) { const float d = gd[i] - mud; qd[0] += d * d; }
+    wave_sums<1>(qd);
+    const float rsd = 1.f / sqrtf(qd[0] / (float)Hd + 1e-5f);
+    float am = 0.f;
+#pragma unroll
+    for (int i = 0; i < NED; ++i) {
+      const int n = lane + 64 * i;
+      if (n < Hd) {
+        float v = (gd[i] - mud) * rsd * dgam[i] + dbet[i];
+        if (a.drop.on()) v *= a.drop.mult(VAE_SITE_DEC(0), b, Hd, n);
+        a.dec_h[(int64_t)b * Hd + n] = v;
+        am = fmaxf(am, fabsf(v));
+      }
+    }
+    if (lane == 0) { a.ln_md[b] = mud; a.ln_rd[b] = rsd; }
+    if (a.absmax_px) {   // the array has NWV entries per cell (the workgroup-per-cell kernel's waves): entry 0 = the maximum
+      am = wave_max_dpp(am);
+      if (lane < NWV) a.absmax_px[b * NWV + lane] = lane == 0 ? am : 0.f;
+    }
+    STAMP(7);
+  }
+}
+
+template <int NEE, int NED, int WPB>
+__global__ __launch_bounds__(64 * WPB) void mid_bwd_wave_kernel(MidBwd a) {
+  extern __shared__ __attribute__((aligned(16))) float dyn[];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int H = a.H, Hl = a.Hl, HE = a.H + a.Hl, L = a.L, Hd = a.Hd;
+  const MidLds w = mid_stage_weights(dyn, a.d_w, a.hz_w, a.hl_w, H, Hl, L, Hd, 64 * WPB);
+  const int LP = w.LP;
+  float gdv[NED], gev[NEE];
+#pragma unroll
+  for (int i = 0; i < NED; ++i) gdv[i] = lane + 64 * i < Hd ? a.gd[lane + 64 * i] : 0.f;
+#pragma unroll
+  for (int i = 0; i < NEE; ++i) {
+    const int e = lane + 64 * i;
+    gev[i] = e < HE ? (e < H ? a.gz[e] : a.gl[e - H]) : 0.f;
+  }
+  __syncthreads();
+
+  for (int b = blockIdx.x * WPB + wave; b < a.B; b += gridDim.x * WPB) {
+    // everything this cell needs from global memory, requested before the slab sums
+    const float mud = a.ln_md[b], rsd = a.ln_rd[b];
+    const float mu0 = a.ln_mz[b], rs0 = a.ln_rz[b], mu1 = a.ln_ml[b], rs1 = a.ln_rl[b];
+    float pdv[NED], pe[NEE];
+#pragma unroll
+    for (int i = 0; i < NED; ++i) pdv[i] = lane + 64 * i < Hd ? a.dec_pre[(int64_t)b * Hd + lane + 64 * i] : 0.f;
+#pragma unroll
+    for (int i = 0; i < NEE; ++i) pe[i] = lane + 64 * i < HE ? a.pre_enc0[(int64_t)b * HE + lane + 64 * i] : 0.f;
+    const float hzr = lane <= L ? a.heads_z[(int64_t)b * (L + 1) + lane] : 0.f;
+    const float epz = lane < L ? a.eps_z[(int64_t)b * L + lane] : 0.f;
+    const float dzx = (a.dz_extra && lane < L) ? a.dz_extra[(int64_t)b * L + lane] : 0.f;
+    const float qzv = a.qz_v[b], qlv = a.ql_v[b], dlib = a.dlibrary[b], epl = a.eps_l[b];
+    const float hl0 = a.heads_l[(int64_t)b * 2], hl1 = a.heads_l[(int64_t)b * 2 + 1];
+    // 1. d(dec_h): sum of the dgrad slabs; LayerNorm + GELU backward of the decoder layer
+    float dyv[NED], dx[NED], xh[NED], ds[NED];
+    slab_sum_wave<NED, WPB>(a.slabs + (int64_t)b * Hd, a.nslab, a.slab_stride, Hd, lane, dyv);
+    float s[2] = {0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < NED; ++i) {
+      const int n = lane + 64 * i;
+      dx[i] = xh[i] = 0.f;
+      if (n < Hd) {
+        float dy = dyv[i];
+        if (a.drop.on()) dy *= a.drop.mult(VAE_SITE_DEC(0), b, Hd, n);
+        xh[i] = (gelu_f(pdv[i]) - mud) * rsd;
+        dx[i] = dy * gdv[i];
+        a.dbet_d[(int64_t)b * Hd + n] = dy;
+        a.dgam_d[(int64_t)b * Hd + n] = dy * xh[i];
+        s[0] += dx[i];
+        s[1] += dx[i] * xh[i];
+      }
+    }
+    wave_sums<2>(s);
+    s[0] /= (float)Hd;
+    s[1] /= (float)Hd;
+#pragma unroll
+    for (int i = 0; i < NED; ++i) {
+      const int n = lane + 64 * i;
+      ds[i] = 0.f;
+      if (n < Hd) {
+        const float dg = rsd * (dx[i] - s[0] - xh[i] * s[1]);
+        ds[i] = dg * gelu_grad(pdv[i]);
+        a.dpre_d[(int64_t)b * Hd + n] = ds[i];
+      }
+    }
+    // 2. dz[j] = sum_n dpre_d[n] W[n][j] (+ cell-head gradient): lane j keeps dz[j]
+    float dz = 0.f;
+    int od[NED];
+#pragma unroll
+    for (int i = 0; i < NED; ++i) od[i] = min(lane + 64 * i, Hd - 1) * LP;   // ds[i] = 0 past Hd
+    for (int j0 = 0; j0 < L; j0 += 4) {
+      float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int j = min(j0 + u, L - 1);
+#pragma unroll
+        for (int i = 0; i < NED; ++i) acc[u] = fmaf(ds[i], w.wd[od[i] + j], acc[u]);
+      }
+      wave_sums<4>(acc);
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (lane == j0 + u && j0 + u < L) dz = acc[u];
+    }
+    dz += dzx;
+    // 3. reparameterisation / KL backward (reparam_bwd_wave above): lane j <= L keeps d head j; dl0 / dl1 the library pair
+    float dqz;
+    {
+      const float sq = sqrtf(qzv);
+      float dv = wave_sum_dpp(lane < L ? dz * epz : 0.f);
+      dv = dv * 0.5f / sq + a.g_kl * (float)L * 0.5f * (1.f - 1.f / qzv);
+      const float ov = dv * softplus20_grad(lane_bcast(hzr, L));
+      dqz = lane < L ? dz + a.g_kl * hzr : (lane == L ? ov : 0.f);
+      if (lane <= L) a.dq_z[(int64_t)b * (L + 1) + lane] = dqz;
+    }
+    float dl0, dl1;
+    {
+      const float sq = sqrtf(qlv), pv = a.l_var;
+      dl0 = dlib + a.g_kl * (hl0 - a.l_mean) / pv;
+      float dv = dlib * epl;
+      dv = dv * 0.5f / sq + a.g_kl * 0.5f * (1.f / pv - 1.f / qlv);
+      dl1 = dv * softplus20_grad(hl1);
+      if (lane == 0) { a.dq_l[(int64_t)b * 2] = dl0; a.dq_l[(int64_t)b * 2 + 1] = dl1; }
+    }
+    // 4. gradient at the LayerNorm outputs of both encoders, then LayerNorm + GELU backward
+    float dye[NEE], dyz[NEE];
+    int oz[NEE];
+#pragma unroll
+    for (int i = 0; i < NEE; ++i) {
+      const int e = lane + 64 * i;
+      const int el = min(max(e - H, 0), Hl - 1);
+      dye[i] = fmaf(dl1, w.wl[Hl + el], dl0 * w.wl[el]);   // library half (used where H <= e < HE)
+      dyz[i] = 0.f;
+      oz[i] = min(e, H - 1);
+    }
+#pragma unroll 4
+    for (int j = 0; j <= L; ++j) {   // z half, branch-free: every lane accumulates at a clamped offset
+      const float dq1 = lane_bcast(dqz, j);
+      const float* wr = w.wz + j * H;
+#pragma unroll
+      for (int i = 0; i < NEE; ++i) dyz[i] = fmaf(dq1, wr[oz[i]], dyz[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < NEE; ++i)
+      if (lane + 64 * i < H) dye[i] = dyz[i];
+    float q4[4] = {0.f, 0.f, 0.f, 0.f};
+    float dxe[NEE], xe[NEE];
+#pragma unroll
+    for (int i = 0; i < NEE; ++i) {
+      const int e = lane + 64 * i;
+      dxe[i] = xe[i] = 0.f;
+      if (e < HE) {
+        const bool zh = e < H;
+        float dy = dye[i];
+        if (zh && a.drop.on()) dy *= a.drop.mult(VAE_SITE_ENC_Z(0), b, H, e);
+        xe[i] = (gelu_f(pe[i]) - (zh ? mu0 : mu1)) * (zh ? rs0 : rs1);
+        dxe[i] = dy * gev[i];
+        a.dbet_e[(int64_t)b * HE + e] = dy;
+        a.dgam_e[(int64_t)b * HE + e] = dy * xe[i];
+        q4[zh ? 0 : 2] += dxe[i];
+        q4[zh ? 1 : 3] += dxe[i] * xe[i];
+      }
+    }
+    wave_sums<4>(q4);
+    q4[0] /= (float)H; q4[1] /= (float)H;
+    q4[2] /= (float)Hl; q4[3] /= (float)Hl;
+    float am = 0.f;
+#pragma unroll
+    for (int i = 0; i < NEE; ++i) {
+      const int e = lane + 64 * i;
+      if (e < HE) {
+        const bool zh = e < H;
+        const float dg = (zh ? rs0 : rs1) * (dxe[i] - (zh ? q4[0] : q4[2]) - xe[i] * (zh ? q4[1] : q4[3]));
+        const float o = dg * gelu_grad(pe[i]);
+        a.dpre_e[(int64_t)b * HE + e] = o;
+        am = fmaxf(am, fabsf(o));
+      }
+    }
+    if (a.absmax_dpre) {
+      am = wave_max_dpp(am);
+      if (lane < NWV) a.absmax_dpre[b * NWV + lane] = lane == 0 ? am : 0.f;
+    }
+  }
+}
+
+// (elements per lane of the encoder / decoder hidden vectors, waves per workgroup) of the wave-per-cell kernels for a shape;
+// false: the workgroup-per-cell kernels run
+struct MidWavePlan { int nee, ned, wpb, grid; size_t lds; };
+bool mid_wave_plan(const vae_step_config& c, const float* hz_w, MidWavePlan* p) {
+  static const bool off = getenv("VAE_MID_WORKGROUP_PER_CELL") != nullptr;   // A/B knob
+  const int HE = (int)(c.H + c.Hl), Hd = (int)c.Hd, L = (int)c.L;
+  // one wave per cell is one long dependent chain (~25 us at cfg2's widths): it wins once a CU has several cells to
+  // overlap (B = 4096: 44 / 60 us against 131 / 128); below, the workgroup-per-cell kernels' 22 us stand
+  static const int min_b = getenv("VAE_MID_WAVE_MIN_B") ? atoi(getenv("VAE_MID_WAVE_MIN_B")) : 768;
+  if (off || c.B < min_b || HE > 1024 || Hd > 1024 || c.H % 4 != 0 || L + 1 > 64 || !vae_aligned16(hz_w)) return false;
+  p->nee = HE <= 384 ? 6 : (HE <= 512 ? 8 : 16);
+  p->ned = Hd <= 256 ? 4 : (Hd <= 512 ? 8 : 16);
+  if (p->nee == 6 && p->ned != 4) p->nee = 8;           // instantiated pairs: (6, 4), (8, 4), (16, 8), (16, 16)
+  if (p->nee == 8 && p->ned == 8) p->nee = 16;
+  if (p->nee == 16 && p->ned == 4) p->ned = 8;
+  p->lds = (size_t)(((Hd * (L | 1) + 3) & ~3) + (L + 1) * (int)c.H + 2 * (int)c.Hl) * sizeof(float);
+  if (p->lds > 150 * 1024) return false;
+  p->wpb = c.B <= 1024 ? 4 : 8;
+  const int groups = (int)((c.B + p->wpb - 1) / p->wpb);
+  const int per_cu = p->lds <= 76 * 1024 ? 2 : 1;
+  p->grid = groups < 256 * per_cu ? groups : 256 * per_cu;
+  return true;
+}
+template <typename A, typename K>
+int mid_wave_launch(K kern, const MidWavePlan& p, const A& a, hipStream_t st) {
+  if (p.lds > 64 * 1024 &&
+      hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds) != hipSuccess)
+    return vae_set_error(VAE_ERR_LAUNCH, "vae_elbo_step (fused middle): cannot raise the LDS limit");
+  hipLaunchKernelGGL(kern, dim3((unsigned)p.grid), dim3(64 * p.wpb), p.lds, st, a);
+  return VAE_OK;
+}
+#define MID_WAVE_DISPATCH(KERN, A)                                                                             \
+  do {                                                                                                         \
+    int rc__;                                                                                                  \
+    if (pl.nee == 6 && pl.wpb == 4)       rc__ = mid_wave_launch(KERN<6, 4, 4>, pl, A, (hipStream_t)stream);   \
+    else if (pl.nee == 6)                 rc__ = mid_wave_launch(KERN<6, 4, 8>, pl, A, (hipStream_t)stream);   \
+    else if (pl.nee == 8 && pl.wpb == 4)  rc__ = mid_wave_launch(KERN<8, 4, 4>, pl, A, (hipStream_t)stream);   \
+    else if (pl.nee == 8)                 rc__ = mid_wave_launch(KERN<8, 4, 8>, pl, A, (hipStream_t)stream);   \
+    else if (pl.ned == 8 && pl.wpb == 4)  rc__ = mid_wave_launch(KERN<16, 8, 4>, pl, A, (hipStream_t)stream);  \
+    else if (pl.ned == 8)                 rc__ = mid_wave_launch(KERN<16, 8, 8>, pl, A, (hipStream_t)stream);  \
+    else if (pl.wpb == 4)                 rc__ = mid_wave_launch(KERN<16, 16, 4>, pl, A, (hipStream_t)stream); \
+    else                                  rc__ = mid_wave_launch(KERN<16, 16, 8>, pl, A, (hipStream_t)stream); \
+    if (rc__ != VAE_OK) return rc__;                                                                           \
+  } while (0)
+
+// ---------------------------------------------------------------------------------------
 // out[p*sp + q*sq] = sum_b U[b][p] * V[b][q]   (U null: column sums of V), for a table of tasks.
 // A workgroup (1024 threads) owns 8 p x 64 q outputs of one task: 256 cells at a time are staged in LDS (all
 // the global loads of a round in flight together); thread (q = t%64, r = t/64) sums the cells
@@ -671,7 +1207,10 @@ int vae_mid_forward(const vae_step_config& c, const vae_step_tensors* p, const f
   a.ql_v = ql_v; a.library = library; a.kl_l = kl_l;
   a.dec_pre = dec_pre; a.dec_h = dec_h; a.ln_md = ln_md; a.ln_rd = ln_rd;
   a.drop = vae_make_dropout(c.dropout_rate, c.rng_seed, c.rng_step);
-  hipLaunchKernelGGL(mid_fwd_kernel, dim3((unsigned)c.B), dim3(T), (size_t)(c.Hd * (c.L | 1) * 4), (hipStream_t)stream, a);
+  MidWavePlan pl;
+  if (mid_wave_plan(c, p->hz_w, &pl)) MID_WAVE_DISPATCH(mid_fwd_wave_kernel, a);
+  else
+    hipLaunchKernelGGL(mid_fwd_kernel, dim3((unsigned)c.B), dim3(T), (size_t)(c.Hd * (c.L | 1) * 4), (hipStream_t)stream, a);
   VAE_CHECK_LAUNCH("vae_elbo_step_forward(mid)");
   return VAE_OK;
 }
@@ -701,7 +1240,10 @@ int vae_mid_backward(const vae_step_config& c, const vae_step_tensors* p, const 
   a.dq_z = dq_z; a.dq_l = dq_l;
   a.dbet_e = dbet_e; a.dgam_e = dgam_e; a.dpre_e = dpre_e;
   a.drop = vae_make_dropout(c.dropout_rate, c.rng_seed, c.rng_step);
-  hipLaunchKernelGGL(mid_bwd_kernel, dim3((unsigned)c.B), dim3(T), (size_t)(c.Hd * (c.L | 1) * 4), (hipStream_t)stream, a);
+  MidWavePlan pl;
+  if (mid_wave_plan(c, p->hz_w, &pl)) MID_WAVE_DISPATCH(mid_bwd_wave_kernel, a);
+  else
+    hipLaunchKernelGGL(mid_bwd_kernel, dim3((unsigned)c.B), dim3(T), (size_t)(c.Hd * (c.L | 1) * 4), (hipStream_t)stream, a);
   VAE_CHECK_LAUNCH("vae_elbo_step_backward(mid)");
 
   // every small parameter gradient of the step, one launch
