@@ -1069,6 +1069,15 @@ int vae_nbzinb_fwd_tiled_ex(int x_dtype, int l_dtype, int zinb, const void* logi
   return VAE_OK;
 }
 
+// ll[b] / S[b] from the per-strip partials a vae_nbzinb_fwd_tiled_ex(ll = S = null) call left in its workspace
+int vae_nbzinb_fwd_finish(const float* part, int strips, int64_t B, float* ll, float* S, void* stream) {
+  VAE_REQUIRE(part && strips > 0 && B > 0 && ll && S, "vae_nbzinb_fwd_finish: bad arguments");
+  hipLaunchKernelGGL(fwd_partials_finish_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, (hipStream_t)stream, part, strips,
+                     (int)B, ll, S);
+  VAE_CHECK_LAUNCH("vae_nbzinb_fwd_finish");
+  return VAE_OK;
+}
+
 extern "C" int vae_nbzinb_fwd_ws(int zinb, const float* logit_scale, int64_t ld_s, const float* logit_dropout, int64_t ld_p,
                                  const void* x, int x_dtype, int64_t ld_x, const float* library, const float* gene_table,
                                  int64_t B, int64_t G, float* ll, float* rowmax, float* rowsum, float* S, int have_stats,

@@ -664,6 +664,14 @@ __device__ __forceinline__ void x3_epilogue(const GemmArgs& g, f32x16 (&acc)[BM 
   // a quarter of the vector-memory instructions against the 63-deep in-order queue of the wave.
   const bool vec_out = PATCHED && g.vecC && !(g.split == 1 && g.accumulate);
   float* patch = reinterpret_cast<float*>(smem) + wave * (32 * 40);
+  // the bias of every column block of this wave, requested before the barrier: a load inside the block loop is a
+  // dependent L2 round trip per block
+  float bvs[TNN];
+#pragma unroll
+  for (int ni = 0; ni < TNN; ++ni) {
+    const int n = n0 + wn * (32 * TNN) + ni * 32 + l31;
+    bvs[ni] = (g.split == 1 && g.bias && n < g.N) ? g.bias[n] : 0.f;
+  }
   if (vec_out) __syncthreads();   // every wave is done with the operand planes
   // running softmax statistics of this wave's rows over its column span: lane (8 r' + c) holds rows r' + 8 i, i < 4
   constexpr bool STAT_OK = LAYOUT == NT && TM <= 2;         // tile shapes whose epilogue carries the statistics registers
@@ -679,7 +687,7 @@ __device__ __forceinline__ void x3_epilogue(const GemmArgs& g, f32x16 (&acc)[BM 
     for (int ni = 0; ni < TNN; ++ni) {
       const int nb = n0 + wn * (32 * TNN) + ni * 32;
       const int n = nb + l31;
-      const float bv = (g.split == 1 && g.bias && n < g.N) ? g.bias[n] : 0.f;
+      const float bv = bvs[ni];
       if (CBF && vec_out && nb + 32 <= g.N) {
         // bf16 output: the 32 x 32 block leaves as 2 instructions of 16 rows x 64 B (8 bf16 per lane)
 #pragma unroll

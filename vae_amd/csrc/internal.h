@@ -87,6 +87,7 @@ int vae_nbzinb_fwd_tiled_ex(int x_dtype, int l_dtype, int zinb, const void* logi
 // vae_px_rate over logits of either storage type
 int vae_px_rate_ex(int l_dtype, const void* logit_scale, int64_t ld_s, const float* library, const float* rowmax,
                    const float* rowsum, int64_t B, int64_t G, float* px_rate, int64_t ld_r, void* stream);
+int vae_nbzinb_fwd_finish(const float* part, int strips, int64_t B, float* ll, float* S, void* stream);
 // vae_elbo_reduce whose ll[b] (and S[b]) are first formed from `strips` per-strip partials part[(s*2 + k)*B + b]
 int vae_elbo_reduce_parts(const float* part, int strips, float* ll, float* S, const float* kl_z, const float* kl_l, int64_t B,
                           float kl_weight, float gene_loss_coeff, float* out5, float* recon, void* stream);

@@ -364,8 +364,14 @@ extern "C" int vae_elbo_step_forward(const vae_step_config* cfg, const vae_step_
   TRY(vae_nbzinb_fwd_tiled_ex(c.x_dtype, k.ldt(), c.zinb, ws + lo.logits, NH, c.zinb ? lgp : nullptr, NH, xv, ldx,
                               ws + lo.library, ws + lo.table, B, G, nullptr, ws + lo.rowmax, ws + lo.rowsum, nullptr, rs.slots > 0,
                               ws + lo.fwd_part, vae_nbzinb_fwd_workspace_bytes(B, G), &strips, stream));
-  TRY(vae_elbo_reduce_parts(ws + lo.fwd_part, strips, ws + lo.ll, ws + lo.S, ws + lo.kl_z, ws + lo.kl_l, B, c.kl_weight,
-                            c.gene_loss_coeff, ws + lo.scalars, ws + lo.recon, stream));
+  if (B > 1024) {   // one workgroup walking strips x B partials is a latency chain (27 us at B = 4096): finish ll / S_b on
+                    // B / 256 workgroups first, then the scalars from three short arrays
+    TRY(vae_nbzinb_fwd_finish(ws + lo.fwd_part, strips, B, ws + lo.ll, ws + lo.S, stream));
+    TRY(vae_elbo_reduce(ws + lo.ll, ws + lo.kl_z, ws + lo.kl_l, B, c.kl_weight, c.gene_loss_coeff, ws + lo.scalars, ws + lo.recon,
+                        stream));
+  } else
+    TRY(vae_elbo_reduce_parts(ws + lo.fwd_part, strips, ws + lo.ll, ws + lo.S, ws + lo.kl_z, ws + lo.kl_l, B, c.kl_weight,
+                              c.gene_loss_coeff, ws + lo.scalars, ws + lo.recon, stream));
   return VAE_OK;
 }
 
