@@ -87,8 +87,11 @@ def time_kernel(fn, iters=5):
     return st.elapsed_time(en) / iters
 
 
-def kernel_breakdown(arena, cfg, x, precision):
-    """Per-kernel timings of the big stages at the bench shapes, on the launch stream."""
+def kernel_breakdown(arena, cfg, x, precision, bf16_storage=False):
+    """Per-kernel timings of the big stages at the bench shapes, on the launch stream.  bf16_storage: the step of this
+    configuration keeps xn / logits / logit gradients as bf16 and streams bf16 images of the weights: the
+    same kernels are timed here on such operands, and the likelihood passes are priced at their bytes (8 / 12 per
+    (cell, gene) for ZINB instead of 12 / 20)."""
     from vae_amd import ops
     from vae_amd.arena import _enc
     B, G, H, Hl, Hd = x.shape[0], cfg["G"], cfg["H"], cfg["Hl"], cfg["Hd"]
@@ -113,23 +116,36 @@ def kernel_breakdown(arena, cfg, x, precision):
     P = precision
     ks = {}
     fl = lambda m, n, k: 2.0 * m * n * k  # noqa: E731
-    if P == ops.F16X2:   # the step's producers hand the operand maxima to the GEMMs; here: computed once, outside the timing
+    if bf16_storage:
+        h = lambda t: t.bfloat16()  # noqa: E731
+        xn16, w_enc16, px16, w_heads16, dpre16 = h(xn), h(w_enc), h(px), h(w_heads), h(dpre)
+        logits = logits.bfloat16()
+        dl = torch.empty_like(logits)
+        mm = None
+        ks["gemm_enc_fwd"] = (time_kernel(lambda: ops.gemm_bf16_storage(ops.NT, xn16, w_enc16, 3)), "mfma", fl(B, H + Hl, G))
+        ks["gemm_dec_fwd"] = (time_kernel(lambda: ops.gemm_bf16_storage(ops.NT, px16, w_heads16, 7, out=logits)), "mfma", fl(B, NH, Hd))
+        ks["gemm_dec_wgrad"] = (time_kernel(lambda: ops.gemm_bf16_storage(ops.TN, logits, px16, 3, out=gw_heads)), "mfma", fl(NH, Hd, B))
+        ks["gemm_dec_dgrad"] = (time_kernel(lambda: ops.gemm_bf16_storage(ops.NN, logits, w_heads16, 3)), "mfma", fl(B, Hd, NH))
+        ks["gemm_enc_wgrad"] = (time_kernel(lambda: ops.gemm_bf16_storage(ops.TN, dpre16, xn16, 3, out=gw_enc)), "mfma", fl(H + Hl, G, B))
+    elif P == ops.F16X2:   # the step's producers hand the operand maxima to the GEMMs; here: computed once, outside the timing
         sc = {id(t): ops.absmax_scale(t) for t in (xn, w_enc, px, w_heads, logits, dpre)}
         mm = lambda lay, a, b, out=None: ops.gemm_scaled(lay, a, b, sc[id(a)], sc[id(b)], out=out)  # noqa: E731
     else:
         mm = lambda lay, a, b, out=None: ops.gemm(lay, a, b, out=out, precision=P)  # noqa: E731
-    ks["gemm_enc_fwd"] = (time_kernel(lambda: mm(ops.NT, xn, w_enc)), "mfma", fl(B, H + Hl, G))
-    ks["gemm_dec_fwd"] = (time_kernel(lambda: mm(ops.NT, px, w_heads, logits)), "mfma", fl(B, NH, Hd))
-    if P == ops.F16X2:
-        sc[id(logits)] = ops.absmax_scale(logits)
-    # the decoder wgrad runs the exact three-term split in both fp32-grade modes (step.hip: per-gene dynamic range of dlogits)
-    wg = (lambda: ops.gemm(ops.TN, logits, px, out=gw_heads, precision=ops.FP32)) if P == ops.F16X2 else \
-        (lambda: mm(ops.TN, logits, px, gw_heads))
-    ks["gemm_dec_wgrad"] = (time_kernel(wg), "mfma", fl(NH, Hd, B))
-    ks["gemm_dec_dgrad"] = (time_kernel(lambda: mm(ops.NN, logits, w_heads)), "mfma", fl(B, Hd, NH))
-    ks["gemm_enc_wgrad"] = (time_kernel(lambda: mm(ops.TN, dpre, xn, gw_enc)), "mfma", fl(H + Hl, G, B))
+    if mm is not None:
+        ks["gemm_enc_fwd"] = (time_kernel(lambda: mm(ops.NT, xn, w_enc)), "mfma", fl(B, H + Hl, G))
+        ks["gemm_dec_fwd"] = (time_kernel(lambda: mm(ops.NT, px, w_heads, logits)), "mfma", fl(B, NH, Hd))
+        if P == ops.F16X2:
+            sc[id(logits)] = ops.absmax_scale(logits)
+        # the decoder wgrad runs the exact three-term split in both fp32-grade modes (step.hip: per-gene dynamic range of dlogits)
+        wg = (lambda: ops.gemm(ops.TN, logits, px, out=gw_heads, precision=ops.FP32)) if P == ops.F16X2 else \
+            (lambda: mm(ops.TN, logits, px, gw_heads))
+        ks["gemm_dec_wgrad"] = (time_kernel(wg), "mfma", fl(NH, Hd, B))
+        ks["gemm_dec_dgrad"] = (time_kernel(lambda: mm(ops.NN, logits, w_heads)), "mfma", fl(B, Hd, NH))
+        ks["gemm_enc_wgrad"] = (time_kernel(lambda: mm(ops.TN, dpre, xn, gw_enc)), "mfma", fl(H + Hl, G, B))
     logits.normal_()
-    per = 12 if zinb else 8
+    lb = 2 if bf16_storage else 4                 # bytes per stored logit
+    per = 4 + (2 if zinb else 1) * lb
     # the step's likelihood forward: the streaming pass with the softmax statistics handed in (the decoder-head GEMM's
     # epilogue produces them); the statistics-only pass that serves shapes outside that GEMM path is timed beside it
     fo = torch.stack(ops.nbzinb_fwd(zinb, logits[:, :G], logits[:, G:] if zinb else None, x, lib, table, streaming=True))
@@ -138,9 +154,9 @@ def kernel_breakdown(arena, cfg, x, precision):
                         "hbm", float(per) * B * G)
     ks["nbzinb_fwd_with_own_statistics"] = (
         time_kernel(lambda: ops.nbzinb_fwd(zinb, logits[:, :G], logits[:, G:] if zinb else None, x, lib, table, streaming=True,
-                                           out=fo)), "hbm", float(per + 4) * B * G)
+                                           out=fo)), "hbm", float(per + lb) * B * G)
     rmax, rsum, S = fo[1], fo[2], fo[3]
-    per_b = 20 if zinb else 12
+    per_b = 4 + (2 if zinb else 1) * 2 * lb       # counts + logits read, gradients written
     ks["nbzinb_bwd"] = (time_kernel(lambda: ops.nbzinb_bwd(zinb, logits[:, :G], logits[:, G:] if zinb else None, x, lib, table,
                                                            rmax, rsum, S, None, -1e-5, dl[:, :G], dl[:, G:] if zinb else None,
                                                            dlib, dpxr, dbs, dbp if zinb else None)),
@@ -374,7 +390,9 @@ def main():
         }
     if rank == 0 and not args.no_breakdown:
         xb = x_all[:B].float()
-        ks = kernel_breakdown(arena, cfg, xb, precision)
+        bf16_st = step.bf16_activations(B)
+        ks = kernel_breakdown(arena, cfg, xb, precision, bf16_st)
+        result["config"]["bf16_activations"] = bf16_st
         name, (t_ms, bound, work) = max(ks.items(), key=lambda kv: kv[1][0])
         if bound == "hbm":
             ach, peak, unit = work / (t_ms * 1e-3) / 1e9, HBM_PEAK_GBS, "GB/s"

@@ -218,6 +218,22 @@ int vae_nbzinb_bwd_u8(int zinb, const float* logit_scale, int64_t ld_s, const fl
                    float* dpx_r, float* dbias_scale, float* dbias_dropout, float* workspace, int64_t workspace_bytes,
                    int overwrite, void* stream);
 
+/* The streaming forward and the backward over logits stored as bf16 (uint16_t = the upper half of the fp32 pattern;
+ * leading dimensions in elements; needs G % 4 == 0, ld % 4 == 0, 8-byte aligned rows) -- what a VAE_BF16 step runs on the
+ * logits its decoder-head product wrote (reference: nn.Linear outputs under autocast(bfloat16), config.py:87).  The
+ * gradients are written as bf16 (nearest even; may alias the logits); dpx_r / dbias_* are OVERWRITTEN (workspace required);
+ * the arithmetic is the fp32 arithmetic of the entry points above.                                                    */
+int vae_nbzinb_fwd_ws_bf16(int zinb, const uint16_t* logit_scale, int64_t ld_s, const uint16_t* logit_dropout, int64_t ld_p,
+                           const void* x, int x_dtype, int64_t ld_x, const float* library, const float* gene_table, int64_t B,
+                           int64_t G, float* ll, float* rowmax, float* rowsum, float* S, int have_stats, float* workspace,
+                           int64_t workspace_bytes, void* stream);
+int vae_nbzinb_bwd_bf16(int zinb, const uint16_t* logit_scale, int64_t ld_s, const uint16_t* logit_dropout, int64_t ld_p,
+                        const void* x, int x_dtype, int64_t ld_x, const float* library, const float* gene_table,
+                        const float* rowmax, const float* rowsum, const float* S, const float* g_ll, float g_scalar, int64_t B,
+                        int64_t G, uint16_t* dlogit_scale, int64_t ld_ds, uint16_t* dlogit_dropout, int64_t ld_dp, float* dlibrary,
+                        float* dpx_r, float* dbias_scale, float* dbias_dropout, float* workspace, int64_t workspace_bytes,
+                        void* stream);
+
 /* ---- stand-alone pieces behind the module API ----------------------------------------------------
  * (px_scale, px_rate) of DecoderSCVI.forward, modules.py:401-404, both (B,G) contiguous           */
 int vae_softmax_rate_fwd(const float* logit_scale, int64_t ld_s, const float* library, int64_t B, int64_t G,

@@ -515,6 +515,49 @@ def test_fused_epilogue_against_the_oracle_likelihood(ops, zinb, G, counts, stre
         assert rel_err(dbp.cpu().numpy(), leaves[1].grad.sum(0).numpy()) < 1e-4
 
 
+@pytest.mark.parametrize("zinb", [True, False])
+@pytest.mark.parametrize("counts", ["f32", "u8"])
+def test_fused_epilogue_over_bf16_logits(ops, zinb, counts):
+    """vae_nbzinb_fwd_ws_bf16 / vae_nbzinb_bwd_bf16 (what a bf16-mode step runs on the logits its decoder-head product
+    stored as bf16): the arithmetic is the fp32 kernels' on the widened logits, so the forward results are THEIR bits and
+    every gradient element is their fp32 gradient rounded to bf16 (nearest even); in place, as the step calls it."""
+    B, G = 70, 2048 + 1024 + 8      # three gene strips, the last nearly empty; two cell chunks
+    g = torch.Generator().manual_seed(78)
+    x = torch.poisson(torch.rand(B, G, generator=g) * 3, generator=g)
+    x[torch.rand(B, G, generator=g) < 0.4] = 0
+    x[:9, 5] = torch.tensor([0, 1, 15, 16, 17, 100, 255, 40, 3.0])
+    ls16 = (torch.randn(B, G, generator=g) * 2).bfloat16().cuda()
+    lp16 = (torch.randn(B, G, generator=g) * 3).bfloat16().cuda()
+    lib = (torch.randn(B, generator=g) * 0.5 + 6).cuda()
+    table = ops.gene_table((torch.randn(G, generator=g) * 0.7).cuda())
+    xd = x.to(torch.uint8).cuda() if counts == "u8" else x.cuda()
+    w = torch.linspace(0.5, 1.5, B).cuda()
+    ls32, lp32 = ls16.float(), lp16.float()
+
+    def run(ls, lp):
+        ll, rmax, rsum, S = ops.nbzinb_fwd(zinb, ls, lp if zinb else None, xd, lib, table, streaming=True)
+        dls, dlp = torch.empty_like(ls), torch.empty_like(lp)
+        dlib = torch.empty(B, device="cuda")
+        dpxr, dbs, dbp = (torch.full((G,), 7.0 if ls.dtype == torch.bfloat16 else 0.0, device="cuda") for _ in range(3))
+        ops.nbzinb_bwd(zinb, ls, lp if zinb else None, xd, lib, table, rmax, rsum, S, w, -3e-3, dls, dlp if zinb else None, dlib,
+                       dpxr, dbs, dbp if zinb else None)
+        return [t.clone() for t in (ll, rmax, rsum, S, dls, dlp, dlib, dpxr, dbs, dbp)]
+
+    r32, r16 = run(ls32, lp32), run(ls16, lp16)
+    for i in (0, 1, 2, 3, 6, 7, 8) + ((9,) if zinb else ()):      # ll, statistics, S_b, dlibrary, d px_r, d bias: the fp32 kernels' bits
+        assert torch.equal(r16[i], r32[i]), i
+    assert torch.equal(r16[4], r32[4].bfloat16())
+    if zinb:
+        assert torch.equal(r16[5], r32[5].bfloat16())
+    # in place: the gradients overwrite the logits they were computed from
+    a, b2 = ls16.clone(), lp16.clone()
+    ll, rmax, rsum, S = ops.nbzinb_fwd(zinb, a, b2 if zinb else None, xd, lib, table, streaming=True)
+    dpxr, dbs, dbp = (torch.zeros(G, device="cuda") for _ in range(3))
+    ops.nbzinb_bwd(zinb, a, b2 if zinb else None, xd, lib, table, rmax, rsum, S, w, -3e-3, a, b2 if zinb else None,
+                   torch.empty(B, device="cuda"), dpxr, dbs, dbp if zinb else None)
+    assert torch.equal(a, r16[4]) and (not zinb or torch.equal(b2, r16[5])) and torch.equal(dpxr, r16[7])
+
+
 def test_poisson_log_prob_matches_torch():
     """reconstruction_loss "poisson" (task.py:167-168): vae_amd.distributions.Poisson.log_prob on the HIP kernel
     vs torch.distributions.Poisson in fp64, values and gradient w.r.t. the rate."""

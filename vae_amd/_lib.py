@@ -63,6 +63,10 @@ SIGNATURES = {
     "vae_nbzinb_fwd_ws": (_i32, [_i32, _ptr, _i64, _ptr, _i64, _ptr, _i32, _i64, _ptr, _ptr, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _i32,
                                  _ptr, _i64, _ptr]),
     "vae_nbzinb_fwd_u8": (_i32, [_i32, _ptr, _i64, _ptr, _i64, _ptr, _i64, _ptr, _ptr, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _ptr]),
+    "vae_nbzinb_fwd_ws_bf16": (_i32, [_i32, _ptr, _i64, _ptr, _i64, _ptr, _i32, _i64, _ptr, _ptr, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _i32,
+                               _ptr, _i64, _ptr]),
+    "vae_nbzinb_bwd_bf16": (_i32, [_i32, _ptr, _i64, _ptr, _i64, _ptr, _i32, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _f32, _i64, _i64,
+                            _ptr, _i64, _ptr, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _i64, _ptr]),
     "vae_nbzinb_bwd_u8": (_i32, [_i32, _ptr, _i64, _ptr, _i64, _ptr, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _f32, _i64, _i64,
                                  _ptr, _i64, _ptr, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _i64, _i32, _ptr]),
     "vae_nbzinb_bwd_workspace_bytes": (_i64, [_i64, _i64]),

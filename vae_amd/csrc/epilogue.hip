@@ -1086,6 +1086,26 @@ extern "C" int vae_nbzinb_fwd_ws(int zinb, const float* logit_scale, int64_t ld_
                                  ll, rowmax, rowsum, S, have_stats, workspace, workspace_bytes, nullptr, stream);
 }
 
+// bf16 logits (and, in the backward, bf16 logit gradients, in place or not): what a bf16-mode step runs
+extern "C" int vae_nbzinb_fwd_ws_bf16(int zinb, const uint16_t* logit_scale, int64_t ld_s, const uint16_t* logit_dropout, int64_t ld_p,
+                                      const void* x, int x_dtype, int64_t ld_x, const float* library, const float* gene_table,
+                                      int64_t B, int64_t G, float* ll, float* rowmax, float* rowsum, float* S, int have_stats,
+                                      float* workspace, int64_t workspace_bytes, void* stream) {
+  return vae_nbzinb_fwd_tiled_ex(x_dtype, VAE_L_BF16, zinb, logit_scale, ld_s, logit_dropout, ld_p, x, ld_x, library, gene_table, B, G,
+                                 ll, rowmax, rowsum, S, have_stats, workspace, workspace_bytes, nullptr, stream);
+}
+extern "C" int vae_nbzinb_bwd_bf16(int zinb, const uint16_t* logit_scale, int64_t ld_s, const uint16_t* logit_dropout, int64_t ld_p,
+                                   const void* x, int x_dtype, int64_t ld_x, const float* library, const float* gene_table,
+                                   const float* rowmax, const float* rowsum, const float* S, const float* g_ll, float g_scalar,
+                                   int64_t B, int64_t G, uint16_t* dlogit_scale, int64_t ld_ds, uint16_t* dlogit_dropout,
+                                   int64_t ld_dp, float* dlibrary, float* dpx_r, float* dbias_scale, float* dbias_dropout,
+                                   float* workspace, int64_t workspace_bytes, void* stream) {
+  VAE_REQUIRE(x_dtype == VAE_X_F32 || x_dtype == VAE_X_U8, "vae_nbzinb_bwd_bf16: bad x_dtype");
+  return vae_nbzinb_bwd_ex(x_dtype, VAE_L_BF16, zinb, logit_scale, ld_s, logit_dropout, ld_p, x, ld_x, library, gene_table, rowmax,
+                           rowsum, S, g_ll, g_scalar, B, G, dlogit_scale, ld_ds, dlogit_dropout, ld_dp, dlibrary, dpx_r, dbias_scale,
+                           dbias_dropout, workspace, workspace_bytes, nullptr, nullptr, stream);
+}
+
 int vae_softmax_stats_merge(const float* stat_m, const float* stat_s, int slots, int64_t B, float* rowmax, float* rowsum,
                             void* stream) {
   VAE_REQUIRE(stat_m && stat_s && slots > 0 && B > 0 && rowmax && rowsum, "vae_softmax_stats_merge: bad arguments");

@@ -36,6 +36,16 @@ def _chk2d(t: torch.Tensor, name: str) -> None:
         raise ValueError(f"vae_amd.ops: {name} must be 2-D with a contiguous last dim, got {tuple(t.shape)} / {t.stride()}")
 
 
+def _chk_logits(t: torch.Tensor, name: str) -> bool:
+    """Logits may be float32 or bfloat16 (what a bf16-mode step stores); -> True for bfloat16."""
+    if t.dtype != torch.bfloat16:
+        _chk2d(t, name)
+        return False
+    if not t.is_cuda or t.dim() != 2 or t.stride(1) != 1:
+        raise ValueError(f"vae_amd.ops: {name} must be a 2-D GPU tensor with a contiguous last dim")
+    return True
+
+
 def _chk_counts(t: torch.Tensor, name: str = "x") -> bool:
     """Counts may be float32 or uint8 (the reference's on-disk format); -> True for uint8."""
     if t.dtype != torch.uint8:
@@ -360,15 +370,16 @@ def nbzinb_fwd(zinb: bool, logit_scale: torch.Tensor, logit_dropout: Optional[to
     results; with ``have_stats`` its rows 1 and 2 already hold rowmax / rowsum and the statistics launch is skipped;
     ``partials_only`` leaves the sum over gene strips to the caller (ll / S are then not written)."""
     lib = _lib.load()
-    _chk2d(logit_scale, "logit_scale")
+    l16 = _chk_logits(logit_scale, "logit_scale")
     u8 = _chk_counts(x)
     B, G = x.shape
     if logit_scale.shape != (B, G):
         raise ValueError("vae_amd.ops.nbzinb_fwd: logit_scale shape mismatch")
     if zinb:
-        _chk2d(logit_dropout, "logit_dropout")
-        if logit_dropout.shape != (B, G):
-            raise ValueError("vae_amd.ops.nbzinb_fwd: logit_dropout shape mismatch")
+        if _chk_logits(logit_dropout, "logit_dropout") != l16 or logit_dropout.shape != (B, G):
+            raise ValueError("vae_amd.ops.nbzinb_fwd: logit_dropout shape / dtype mismatch")
+    if l16 and not streaming:
+        raise ValueError("vae_amd.ops.nbzinb_fwd: bfloat16 logits exist in the streaming form only")
     _chk1d(library, B, "library")
     if table.shape != (lib.vae_gene_table_rows(), G) or not table.is_contiguous():
         raise ValueError("vae_amd.ops.nbzinb_fwd: table must be the gene table made by ops.gene_table")
@@ -380,7 +391,7 @@ def nbzinb_fwd(zinb: bool, logit_scale: torch.Tensor, logit_dropout: Optional[to
     if streaming:
         nbytes = lib.vae_nbzinb_fwd_workspace_bytes(B, G)
         ws = workspace(nbytes, x.device)
-        _lib.check(lib.vae_nbzinb_fwd_ws(int(zinb), _p(logit_scale), _ld(logit_scale), _p(logit_dropout if zinb else None),
+        _lib.check((lib.vae_nbzinb_fwd_ws_bf16 if l16 else lib.vae_nbzinb_fwd_ws)(int(zinb), _p(logit_scale), _ld(logit_scale), _p(logit_dropout if zinb else None),
                                          _ld(logit_dropout) if zinb else 0, _p(x), _lib.X_U8 if u8 else _lib.X_F32, _ld(x),
                                          _p(library), _p(table), B, G, None if partials_only else _p(o[0]), _p(o[1]), _p(o[2]),
                                          None if partials_only else _p(o[3]), int(have_stats), _p(ws), nbytes, _stream()),
@@ -421,14 +432,15 @@ def nbzinb_bwd(zinb: bool, logit_scale: torch.Tensor, logit_dropout: Optional[to
     (deterministic=True, default) or with float atomics."""
     lib = _lib.load()
     u8 = _chk_counts(x)
-    if u8 and not deterministic:
-        raise ValueError("vae_amd.ops.nbzinb_bwd: uint8 counts use the deterministic (workspace) mode")
+    l16 = _chk_logits(logit_scale, "logit_scale")
+    if (u8 or l16) and not deterministic:
+        raise ValueError("vae_amd.ops.nbzinb_bwd: uint8 counts / bfloat16 logits use the deterministic (workspace) mode")
     B, G = x.shape
     if table.shape != (lib.vae_gene_table_rows(), G) or not table.is_contiguous():
         raise ValueError("vae_amd.ops.nbzinb_bwd: table must be the gene table made by ops.gene_table")
-    _chk2d(dlogit_scale, "dlogit_scale")
-    if zinb:
-        _chk2d(dlogit_dropout, "dlogit_dropout")
+    if _chk_logits(dlogit_scale, "dlogit_scale") != l16 or (zinb and (_chk_logits(logit_dropout, "logit_dropout") != l16 or
+                                                                     _chk_logits(dlogit_dropout, "dlogit_dropout") != l16)):
+        raise TypeError("vae_amd.ops.nbzinb_bwd: logits and their gradients must share one dtype (float32 or bfloat16)")
     _chk1d(g_ll, B, "g_ll"); _chk1d(dlibrary, B, "dlibrary"); _chk1d(dpx_r, G, "dpx_r")
     _chk1d(dbias_scale, G, "dbias_scale"); _chk1d(dbias_dropout, G, "dbias_dropout")
     nbytes = lib.vae_nbzinb_bwd_workspace_bytes(B, G) if deterministic else 0
@@ -438,7 +450,12 @@ def nbzinb_bwd(zinb: bool, logit_scale: torch.Tensor, logit_dropout: Optional[to
             _p(rowsum), _p(S), _p(g_ll), float(g_scalar), B, G, _p(dlogit_scale), _ld(dlogit_scale),
             _p(dlogit_dropout if zinb else None), _ld(dlogit_dropout) if zinb else 0, _p(dlibrary),
             _p(dpx_r), _p(dbias_scale), _p(dbias_dropout if zinb else None), _p(ws), nbytes)
-    rc = lib.vae_nbzinb_bwd_u8(*args, 0, _stream()) if u8 else lib.vae_nbzinb_bwd(*args, _stream())
+    if l16:   # bf16 logits / gradients: dpx_r and the bias gradients are OVERWRITTEN (include/vae_amd.h)
+        a = list(args)
+        a[5:7] = [_p(x), _lib.X_U8 if u8 else _lib.X_F32, _ld(x)]
+        rc = lib.vae_nbzinb_bwd_bf16(*a, _stream())
+    else:
+        rc = lib.vae_nbzinb_bwd_u8(*args, 0, _stream()) if u8 else lib.vae_nbzinb_bwd(*args, _stream())
     _lib.check(rc, "nbzinb_bwd")
 
 
