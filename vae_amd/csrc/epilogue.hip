@@ -234,6 +234,108 @@ __device__ __forceinline__ Bwd elem_bwd(float x, float mu, float pi, float th, f
   return o;
 }
 
+// ---- two genes per instruction ------------------------------------------------------------------------------------
+// gfx950 issues v_pk_{add,mul,fma}_f32 on register PAIRS at the rate of the scalar forms: the streaming passes evaluate a
+// lane's four genes as two pairs.  Same expressions as elem_core / elem_fwd / elem_bwd, component-wise; the
+// transcendentals (v_exp / v_log / v_rcp) and the selects stay per component.
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2 mk2(float a, float b) { f2 v; v.x = a; v.y = b; return v; }
+__device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f2 rcp2(f2 v) { return mk2(frcp(v.x), frcp(v.y)); }
+__device__ __forceinline__ f2 log2_2(f2 v) { return mk2(__builtin_amdgcn_logf(v.x), __builtin_amdgcn_logf(v.y)); }
+__device__ __forceinline__ f2 exp2_2(f2 v) { return mk2(__builtin_amdgcn_exp2f(v.x), __builtin_amdgcn_exp2f(v.y)); }
+__device__ __forceinline__ f2 sel2(bool cx, bool cy, f2 a, f2 b) { return mk2(cx ? a.x : b.x, cy ? a.y : b.y); }
+constexpr float LN2 = 0.69314718055994531f;
+
+struct Core2 { f2 dlt, ltm, itm, rru; };
+__device__ __forceinline__ Core2 elem_core2(f2 mu, f2 lte, f2 ite) {
+  Core2 c;
+  const f2 r = mu * ite;
+  const f2 u = 1.f + r;
+  const f2 ru = rcp2(u);
+  const f2 l1p = fma2(log2_2(u), mk2(LN2, LN2), (r - (u - 1.f)) * ru);
+  c.dlt = -l1p;
+  c.ltm = lte + l1p;
+  c.itm = ite * ru;
+  c.rru = r * ru;
+  return c;
+}
+
+struct Fwd2 { f2 ll, a; };
+template <bool ZINB>
+__device__ __forceinline__ Fwd2 elem_fwd2(f2 x, f2 mu, f2 pi, f2 th, f2 lte, f2 ite, f2 lgd, const float* __restrict__ Tg0,
+                                          const float* __restrict__ Tg1, int G) {
+  Fwd2 o;
+  const Core2 k = elem_core2(mu, lte, ite);
+  const bool px = x.x > EPS, py = x.y > EPS;
+  if (px && !(x.x < (float)KTAB && x.x == truncf(x.x)))  // rare: large or fractional count
+    lgd.x = lgamma_any(x.x + th.x) - Tg0[ROW_LG * G] - lgamma_any(x.x + 1.f);
+  if (py && !(x.y < (float)KTAB && x.y == truncf(x.y)))
+    lgd.y = lgamma_any(x.y + th.y) - Tg1[ROW_LG * G] - lgamma_any(x.y + 1.f);
+  const f2 L2E2 = mk2(LOG2E, LOG2E), LN22 = mk2(LN2, LN2);
+  if (ZINB) {
+    const f2 npi = -pi;
+    const f2 spl = log2_2(1.f + exp2_2(npi * L2E2)) * LN22;
+    const f2 sp = sel2(npi.x > 20.f, npi.y > 20.f, npi, spl);
+    const f2 ptl = fma2(th, k.dlt, npi);
+    const f2 z = exp2_2(mk2(fminf(ptl.x, 20.f), fminf(ptl.y, 20.f)) * L2E2);
+    const bool bx = ptl.x > 20.f, by = ptl.y > 20.f;
+    const f2 s = sel2(px, py, mu + EPS, 1.f + z);
+    const f2 ls = log2_2(s) * LN22, is = rcp2(s);
+    const f2 nzterm = fma2(x, ls - k.ltm, lgd);                 // pos: ls = log(mu + eps)
+    const f2 a_nz = (x * is - (x + th) * k.itm) * mu;           // pos: is = 1 / (mu + eps)
+    const f2 spz = sel2(bx, by, ptl, ls);                       // zero: softplus(ptl), threshold 20
+    const f2 sgz = sel2(bx, by, mk2(1.f, 1.f), z * is);         // zero: its derivative
+    const bool zx = x.x < EPS, zy = x.y < EPS;
+    const f2 llp = (ptl - sp) + nzterm, llz = spz - sp;
+    const f2 az = -(sgz * th) * (k.itm * mu);
+    o.ll = mk2(px ? llp.x : (zx ? llz.x : 0.f), py ? llp.y : (zy ? llz.y : 0.f));
+    o.a = mk2(px ? a_nz.x : (zx ? az.x : 0.f), py ? a_nz.y : (zy ? az.y : 0.f));
+  } else {
+    const f2 s = mu + EPS;
+    const f2 nzterm = fma2(x, log2_2(s) * LN22 - k.ltm, lgd);
+    const f2 a_nz = (x * rcp2(s) - (x + th) * k.itm) * mu;
+    const f2 base = th * k.dlt, az = -(th * k.itm) * mu;
+    o.ll = mk2(base.x + (px ? nzterm.x : 0.f), base.y + (py ? nzterm.y : 0.f));
+    o.a = sel2(px, py, a_nz, az);
+  }
+  return o;
+}
+
+struct Bwd2 { f2 a, dpi, dth; };
+__device__ __forceinline__ f2 sigmoid20_2(f2 v) {   // fsigmoid20, component-wise
+  const f2 z = exp2_2(mk2(fminf(v.x, 20.f), fminf(v.y, 20.f)) * mk2(LOG2E, LOG2E));
+  const f2 q = z * rcp2(z + 1.f);
+  return mk2(v.x > 20.f ? 1.f : q.x, v.y > 20.f ? 1.f : q.y);
+}
+template <bool ZINB>
+__device__ __forceinline__ Bwd2 elem_bwd2(f2 x, f2 mu, f2 pi, f2 th, f2 lte, f2 ite, f2 dgd, const float* __restrict__ Tg0,
+                                          const float* __restrict__ Tg1, int G) {
+  Bwd2 o;
+  const Core2 k = elem_core2(mu, lte, ite);
+  const f2 dptl_dth = fma2(th * ite, k.rru, k.dlt);
+  const bool px = x.x > EPS, py = x.y > EPS;
+  if (px && !(x.x < (float)KTAB && x.x == truncf(x.x))) dgd.x = digamma_any(x.x + th.x) - Tg0[ROW_PSI * G];
+  if (py && !(x.y < (float)KTAB && x.y == truncf(x.y))) dgd.y = digamma_any(x.y + th.y) - Tg1[ROW_PSI * G];
+  const f2 a_nz = (x * rcp2(mu + EPS) - (x + th) * k.itm) * mu;
+  const f2 dth_nz = (dptl_dth - x * k.itm) + dgd;
+  if (ZINB) {
+    const f2 sg_pi = sigmoid20_2(-pi);
+    const f2 sg = sigmoid20_2(fma2(th, k.dlt, -pi));
+    const bool zx = x.x < EPS, zy = x.y < EPS;
+    const f2 az = -(sg * th) * (k.itm * mu), dpz = sg_pi - sg, dtz = sg * dptl_dth, dpp = sg_pi - 1.f;
+    o.a = mk2(px ? a_nz.x : (zx ? az.x : 0.f), py ? a_nz.y : (zy ? az.y : 0.f));
+    o.dpi = mk2(px ? dpp.x : (zx ? dpz.x : 0.f), py ? dpp.y : (zy ? dpz.y : 0.f));
+    o.dth = mk2(px ? dth_nz.x : (zx ? dtz.x : 0.f), py ? dth_nz.y : (zy ? dtz.y : 0.f));
+  } else {
+    const f2 az = -(th * k.itm) * mu;
+    o.dpi = mk2(0.f, 0.f);
+    o.a = sel2(px, py, a_nz, az);
+    o.dth = sel2(px, py, dth_nz, dptl_dth);
+  }
+  return o;
+}
+
 // ---- forward: one workgroup per cell ------------------------------------------------------
 // All HBM loads of the cell (scale-logit row, x row, then the dropout-logit row) are issued up
 // front; exp(l - max) is parked in LDS between the softmax statistics and the likelihood pass
@@ -520,11 +622,12 @@ __global__ __launch_bounds__(256) void nbzinb_fwd_tiled_kernel(
     const float x4[4] = {c0.x.x, c0.x.y, c0.x.z, c0.x.w};
     float sll = 0.f, sa = 0.f;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float p = softmax_w(l4[j], k.x);      // softmax weight, as the backward evaluates it
-      const Fwd f = elem_fwd<ZINB>(x4[j], k.y * p, p4[j], th[j], lt[j], it[j], d0[j], Tg[j], G);
-      sll += (VEC || j < nv) ? f.ll : 0.f;        // VEC: G % 4 == 0, a thread's four genes are all valid or all past G
-      sa += (VEC || j < nv) ? f.a : 0.f;
+    for (int j = 0; j < 4; j += 2) {              // two genes per packed instruction (elem_fwd2)
+      const f2 p = mk2(softmax_w(l4[j], k.x), softmax_w(l4[j + 1], k.x));   // softmax weights, as the backward evaluates them
+      const Fwd2 f = elem_fwd2<ZINB>(mk2(x4[j], x4[j + 1]), k.y * p, mk2(p4[j], p4[j + 1]), mk2(th[j], th[j + 1]),
+                                     mk2(lt[j], lt[j + 1]), mk2(it[j], it[j + 1]), mk2(d0[j], d0[j + 1]), Tg[j], Tg[j + 1], G);
+      sll += ((VEC || j < nv) ? f.ll.x : 0.f) + ((VEC || j + 1 < nv) ? f.ll.y : 0.f);   // VEC: all four genes valid, or none
+      sa += ((VEC || j < nv) ? f.a.x : 0.f) + ((VEC || j + 1 < nv) ? f.a.y : 0.f);
     }
     sll = wave_sum(nv > 0 ? sll : 0.f);
     sa = wave_sum(nv > 0 ? sa : 0.f);
@@ -661,15 +764,19 @@ __global__ __launch_bounds__(256) void nbzinb_bwd_kernel(
     const float x4[4] = {c0.x.x, c0.x.y, c0.x.z, c0.x.w};
     float o_s[4], o_p[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float p = softmax_w(l4[j], k.x);
-      const Bwd e = elem_bwd<ZINB>(x4[j], k.y * p, p4[j], th[j], lt[j], it[j], d0[j], Tg[j], G);
-      o_s[j] = k.w * (e.a - p * k.z);
-      o_p[j] = k.w * e.dpi;
-      if (j < nv) am = fmaxf(am, fmaxf(fabsf(o_s[j]), ZINB ? fabsf(o_p[j]) : 0.f));
-      acc_t[j] += k.w * e.dth * th[j];
-      acc_s[j] += o_s[j];
-      acc_p[j] += o_p[j];
+    for (int j = 0; j < 4; j += 2) {              // two genes per packed instruction (elem_bwd2)
+      const f2 p = mk2(softmax_w(l4[j], k.x), softmax_w(l4[j + 1], k.x));
+      const f2 th2 = mk2(th[j], th[j + 1]);
+      const Bwd2 e = elem_bwd2<ZINB>(mk2(x4[j], x4[j + 1]), k.y * p, mk2(p4[j], p4[j + 1]), th2, mk2(lt[j], lt[j + 1]),
+                                     mk2(it[j], it[j + 1]), mk2(d0[j], d0[j + 1]), Tg[j], Tg[j + 1], G);
+      const f2 os = k.w * (e.a - p * k.z), op = k.w * e.dpi, ot = (k.w * e.dth) * th2;
+      o_s[j] = os.x; o_s[j + 1] = os.y;
+      o_p[j] = op.x; o_p[j + 1] = op.y;
+      if (j < nv) am = fmaxf(am, fmaxf(fabsf(os.x), ZINB ? fabsf(op.x) : 0.f));
+      if (j + 1 < nv) am = fmaxf(am, fmaxf(fabsf(os.y), ZINB ? fabsf(op.y) : 0.f));
+      acc_t[j] += ot.x; acc_t[j + 1] += ot.y;
+      acc_s[j] += os.x; acc_s[j + 1] += os.y;
+      acc_p[j] += op.x; acc_p[j + 1] += op.y;
     }
     LT* w_s = dls + (int64_t)b * ld_ds + g0;
     LT* w_p = ZINB ? dlp + (int64_t)b * ld_dp + g0 : nullptr;
