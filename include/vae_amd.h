@@ -263,6 +263,13 @@ int vae_gather_counts(const uint8_t* store, int64_t n_cells, int64_t ld_store, c
  * out must not alias x.                                                                                              */
 int vae_mixup_counts(const void* x, int x_dtype, int64_t ldx, int64_t B, int64_t G, const int32_t* partner,
                      const double* alpha, float* out, int64_t ld_out, void* stream);
+/* vae_cutmix_counts replaces the array part of SingleCellDataset._cutmix (data.py:431-454): out[i, g] =
+ * take[i, g] ? x[partner[i], g] : x[i, g].  take: device (B, G) bytes, nonzero = gene g of cell i comes from the partner
+ * (the host replays the reference's np.random.choice(n_genes, int(alpha_i n_genes), replace=False) per cell and marks
+ * the subset); x: uint8 or fp32, out: uint8 (uint8 input only) or fp32 -- counts are copied, never blended, so uint8 stays
+ * exact.  The (B, P) label / mask tables are blended with alpha as in mixup: vae_mixup_counts.  out must not alias x.  */
+int vae_cutmix_counts(const void* x, int x_dtype, int64_t ldx, int64_t B, int64_t G, const int32_t* partner,
+                      const uint8_t* take, int64_t ld_take, void* out, int out_dtype, int64_t ld_out, void* stream);
 
 /* element-wise log_nb_positive / log_zinb_positive (distributions.py:65-90 / :22-62), eps = 1e-8;
  * theta addressed as theta[b*ld_theta + g] (ld_theta = 0 broadcasts a (G,) vector)                */

@@ -63,6 +63,31 @@ def mixup(gene_vals: np.ndarray, cell_vals: np.ndarray, cell_mask: np.ndarray, c
     return new_g, new_v, new_m, alpha, partners
 
 
+def cutmix(gene_vals: np.ndarray, cell_vals: np.ndarray, cell_mask: np.ndarray, cell_per_group: Optional[int], n_genes: int):
+    """data.py:431-454.  Returns (new_gene_vals, new_cell_vals, new_cell_mask, alpha, partners, take) with take[i, g] = 1
+    where gene g of cell i was taken from its partner."""
+    N = gene_vals.shape[0]
+    alpha = sample_beta(N)
+    new_g, new_v, new_m = np.zeros_like(gene_vals), np.zeros_like(cell_vals), np.zeros_like(cell_mask)
+    partners = np.zeros(N, dtype=np.int64)
+    take = np.zeros(gene_vals.shape, dtype=np.uint8)
+    for i in range(N):
+        if cell_per_group is not None:
+            k = i // cell_per_group
+            candidates = list(range(k * cell_per_group, (k + 1) * cell_per_group))
+        else:
+            candidates = list(range(N))
+        j = np.random.choice(candidates)
+        partners[i] = j
+        new_g[i, :] += gene_vals[i, :]
+        idx_mix = np.random.choice(n_genes, int(alpha[i] * n_genes), replace=False)
+        new_g[i, idx_mix] = gene_vals[j, idx_mix]
+        take[i, idx_mix] = 1
+        new_v[i, :] = alpha[i] * cell_vals[i, :] + (1 - alpha[i]) * cell_vals[j, :]
+        new_m[i, :] = alpha[i] * cell_mask[i, :] + (1 - alpha[i]) * cell_mask[j, :]
+    return new_g, new_v, new_m, alpha, partners, take
+
+
 def balanced_batch(group_idx: Dict[int, List[int]], cell_per_group: int):
     """data.py:480-495: ``cell_per_group`` cells of every group, without replacement, groups in dict order."""
     batch_idx: List[int] = []

@@ -105,9 +105,7 @@ def test_datamodule_fills_the_property_tables_like_the_oracle():
 
 def test_unbuilt_variants_raise():
     store, meta = synthetic_study(n_cells=400)
-    with pytest.raises(NotImplementedError):
-        _dataset(store, meta, None, cutmix=True)
-    # (the rest need no cell properties either)
+    # (cutmix is built since round 2: tests/test_data_gpu.py; these need no cell properties)
     with pytest.raises(NotImplementedError):
         _dataset(store, meta, None, group_balancing="bd_special")
     with pytest.raises(NotImplementedError):

@@ -122,6 +122,46 @@ def test_training_batches_follow_the_reference_pipeline():
     assert ds.count == 2
 
 
+def test_cutmix_batches_follow_the_reference_pipeline():
+    """cutmix (data.py:431-454): the dataset replays the reference's draws (partner, then the gene subset, per cell) and
+    copies the subset from the partner on the device -- the oracle's batch under the same np.random seed, bit for bit, the
+    generator left in the same state; with mixup on as well the reference applies cutmix first (data.py:513-519)."""
+    host, meta = synthetic_study()
+    gene_idx = np.sort(np.random.RandomState(6).choice(host.shape[1], 500, replace=False))
+    for both in (False, True):
+        ds, props = _study_dataset(host, meta, gene_idx=gene_idx, mixup=both, cutmix=True)
+        np.random.seed(11)
+        batch_idx, groups = DO.balanced_batch(ds.group_idx, ds.cell_per_group)
+        g = DO.gene_vals_batch(host, ds.cell_idx, batch_idx, gene_idx)
+        want_g, want_v, want_m, alpha, partners, take = DO.cutmix(g, ds.labels[batch_idx], ds.mask[batch_idx], ds.cell_per_group,
+                                                                  len(gene_idx))
+        assert 0 < take.mean() < 1 and (want_g != g).any()
+        if both:
+            want_g, want_v, want_m, _, _ = DO.mixup(want_g, want_v, want_m, ds.cell_per_group)
+        state = np.random.get_state()[1].copy()
+        np.random.seed(11)
+        gene_vals, vals, mask, *_ = ds[[0, 1, 2]]
+        assert gene_vals.dtype == torch.float32 and gene_vals.is_cuda
+        assert np.array_equal(gene_vals.cpu().numpy().view(np.uint32), want_g.view(np.uint32))
+        assert np.array_equal(vals.cpu().numpy().view(np.uint32), want_v.view(np.uint32))
+        assert np.array_equal(mask.cpu().numpy().view(np.uint32), want_m.view(np.uint32))
+        assert np.array_equal(np.random.get_state()[1], state)
+    # the kernel alone: ragged G, uint8 -> uint8 / fp32, fp32 -> fp32, a strided take
+    rng = np.random.RandomState(4)
+    B, G = 37, 1003
+    x8 = rng.poisson(2.0, size=(B, G)).astype(np.uint8)
+    tk = (rng.rand(B, G) < 0.3).astype(np.uint8)
+    pt = rng.randint(0, B, size=B)
+    want = np.where(tk > 0, x8[pt], x8)
+    p, t = torch.from_numpy(pt.astype(np.int32)).cuda(), torch.from_numpy(tk).cuda()
+    assert np.array_equal(ops.cutmix_counts(torch.from_numpy(x8).cuda(), p, t).cpu().numpy(), want)
+    assert np.array_equal(ops.cutmix_counts(torch.from_numpy(x8).cuda(), p, t, out_dtype=torch.float32).cpu().numpy(), want.astype(np.float32))
+    xf = x8.astype(np.float32) * np.float32(0.5)
+    assert np.array_equal(ops.cutmix_counts(torch.from_numpy(xf).cuda(), p, t).cpu().numpy(), np.where(tk > 0, xf[pt], xf))
+    with pytest.raises(TypeError):
+        ops.cutmix_counts(torch.from_numpy(xf).cuda(), p, t, out_dtype=torch.uint8)
+
+
 def test_validation_batches_and_library_prior():
     host, meta = synthetic_study()
     ds, _ = _study_dataset(host, meta, group_balancing=None, mixup=False, training=False, counts_dtype=torch.uint8)

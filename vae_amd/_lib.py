@@ -37,6 +37,7 @@ SIGNATURES = {
     "vae_gene_dropout": (_i32, [_ptr, _i32, _i64, _i64, _i64, _f32, _f32, C.c_uint64, C.c_uint32, _ptr, _ptr, _ptr, _ptr, _ptr,
                                 _ptr, _i64, _ptr]),
     "vae_gather_counts": (_i32, [_ptr, _i64, _i64, _ptr, _i64, _ptr, _i64, _ptr, _i32, _i64, _ptr]),
+    "vae_cutmix_counts": (_i32, [_ptr, _i32, _i64, _i64, _i64, _ptr, _ptr, _i64, _ptr, _i32, _i64, _ptr]),
     "vae_mixup_counts": (_i32, [_ptr, _i32, _i64, _i64, _i64, _ptr, _ptr, _ptr, _i64, _ptr]),
     "vae_poisson_fwd": (_i32, [_ptr, _i64, _ptr, _i64, _i64, _i64, _ptr, _i64, _ptr]),
     "vae_poisson_bwd": (_i32, [_ptr, _i64, _ptr, _i64, _ptr, _i64, _i64, _i64, _ptr, _i64, _ptr]),

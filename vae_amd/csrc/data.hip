@@ -121,6 +121,28 @@ __global__ __launch_bounds__(256) void mixup_kernel(const XT* __restrict__ x, in
   }
 }
 
+// cutmix (data.py:431-454): out[i, g] = take[i, g] ? x[partner[i], g] : x[i, g]; the reference draws the gene subset of
+// every cell with np.random.choice(n_genes, int(alpha n_genes), replace=False) -- the host replays those draws and hands
+// the subsets over as a (B, G) byte mask.  Counts stay what they are (no arithmetic): out has the dtype asked for.
+template <typename XT, typename OT>
+__global__ __launch_bounds__(256) void cutmix_kernel(const XT* __restrict__ x, int64_t ldx, int B, int G,
+                                                     const int32_t* __restrict__ partner, const uint8_t* __restrict__ take,
+                                                     int64_t ld_take, OT* __restrict__ out, int64_t ld_out) {
+  const int b = blockIdx.y;
+  const int g0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (g0 >= G) return;
+  int j = partner[b];
+  j = (j >= 0 && j < B) ? j : b;
+  const XT* ri = x + (int64_t)b * ldx + g0;
+  const XT* rj = x + (int64_t)j * ldx + g0;
+  const uint8_t* tk = take + (int64_t)b * ld_take + g0;
+  OT* o = out + (int64_t)b * ld_out + g0;
+  const int nv = min(4, G - g0);
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+    if (c < nv) o[c] = (OT)(tk[c] ? rj[c] : ri[c]);
+}
+
 template <typename XT>
 int mixup_impl(const XT* x, int64_t ldx, int64_t B, int64_t G, const int32_t* partner, const double* alpha, float* out,
                int64_t ld_out, hipStream_t st) {
@@ -148,6 +170,30 @@ extern "C" int vae_gather_counts(const uint8_t* store, int64_t n_cells, int64_t 
   if (out_dtype == VAE_X_U8)
     return gather_impl<uint8_t>(store, n_cells, ld_store, cell_rows, B, gene_idx, G, (uint8_t*)out, ld_out, (hipStream_t)stream);
   return gather_impl<float>(store, n_cells, ld_store, cell_rows, B, gene_idx, G, (float*)out, ld_out, (hipStream_t)stream);
+}
+
+extern "C" int vae_cutmix_counts(const void* x, int x_dtype, int64_t ldx, int64_t B, int64_t G, const int32_t* partner,
+                                 const uint8_t* take, int64_t ld_take, void* out, int out_dtype, int64_t ld_out, void* stream) {
+  VAE_REQUIRE(x && partner && take && out, "vae_cutmix_counts: null pointer");
+  VAE_REQUIRE(B > 0 && B <= 65535 && G > 0 && G < (1 << 30) && ldx >= G && ld_out >= G && ld_take >= G,
+              "vae_cutmix_counts: bad shape (B <= 65535)");
+  VAE_REQUIRE((x_dtype == VAE_X_U8 || x_dtype == VAE_X_F32) && (out_dtype == VAE_X_U8 || out_dtype == VAE_X_F32) &&
+                  !(x_dtype == VAE_X_F32 && out_dtype == VAE_X_U8),
+              "vae_cutmix_counts: dtypes must be VAE_X_U8 / VAE_X_F32 (fp32 counts cannot go out as uint8)");
+  VAE_REQUIRE(out != x, "vae_cutmix_counts: in-place mixing is not possible (rows read their partners)");
+  const dim3 grid((unsigned)((G + STRIP - 1) / STRIP), (unsigned)B);
+  hipStream_t st = (hipStream_t)stream;
+  if (x_dtype == VAE_X_U8 && out_dtype == VAE_X_U8)
+    hipLaunchKernelGGL((cutmix_kernel<uint8_t, uint8_t>), grid, dim3(256), 0, st, (const uint8_t*)x, ldx, (int)B, (int)G, partner,
+                       take, ld_take, (uint8_t*)out, ld_out);
+  else if (x_dtype == VAE_X_U8)
+    hipLaunchKernelGGL((cutmix_kernel<uint8_t, float>), grid, dim3(256), 0, st, (const uint8_t*)x, ldx, (int)B, (int)G, partner,
+                       take, ld_take, (float*)out, ld_out);
+  else
+    hipLaunchKernelGGL((cutmix_kernel<float, float>), grid, dim3(256), 0, st, (const float*)x, ldx, (int)B, (int)G, partner, take,
+                       ld_take, (float*)out, ld_out);
+  VAE_CHECK_LAUNCH("vae_cutmix_counts");
+  return VAE_OK;
 }
 
 extern "C" int vae_mixup_counts(const void* x, int x_dtype, int64_t ldx, int64_t B, int64_t G, const int32_t* partner,

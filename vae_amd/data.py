@@ -9,11 +9,11 @@ reference's numpy arithmetic).  Per step the host only draws indices.
 
 What is mirrored: ``__getitem__`` -> the 8-tuple ``(gene_vals, cell_prop_vals, cell_mask, batch_labels, batch_mask,
 cell_idx, group_idx, subject)`` (data.py:497-521), the balanced batch sampler (data.py:480-495, same ``np.random``
-call sequence, so the same indices under the same seed), mixup (data.py:457-477, same draws), the label / mask tables
+call sequence, so the same indices under the same seed), mixup and cutmix (data.py:431-477, same draws), the label / mask tables
 (data.py:327-390), sample restriction (data.py:247-288), the two-column group schemes (data.py:109-215),
 ``library_size_stats`` (data.py:233-244), and ``DataModule`` with ``_get_cell_prop_info`` / ``setup`` /
 ``train_dataloader`` / ``val_dataloader`` (data.py:524-729; torch's own ``BatchSampler(RandomSampler)``).
-Not mirrored: cutmix (off in every shipped configuration), the study-specific ``bd_augmented`` / ``bd_special`` group
+Not mirrored: the study-specific ``bd_augmented`` / ``bd_special`` group
 schemes and the polygenic-score restrictions.  No CPU fallback: without the HIP library this module raises.
 """
 from __future__ import annotations
@@ -187,8 +187,6 @@ class SingleCellDataset:
                  group_balancing: Optional[str] = "bcd", mixup: bool = True, cutmix: bool = False, training: bool = True, *,
                  metadata: Optional[Dict[str, Any]] = None, store: Optional[CountStore] = None, device="cuda",
                  counts_dtype: torch.dtype = torch.float32, min_group_cells: int = 250):
-        if cutmix:
-            raise NotImplementedError("vae_amd.data: cutmix (data.py:431-454) is not built; no shipped configuration uses it")
         if group_balancing is not None and group_balancing not in _GROUP_SCHEMES:
             raise NotImplementedError(f"vae_amd.data: group_balancing={group_balancing!r}; built: {sorted(_GROUP_SCHEMES)} / None")
         self.count = 0
@@ -313,7 +311,7 @@ class SingleCellDataset:
         if "class" in self.obs:
             hit = self.obs["class"][:, None] == self.cell_classes[None, :]
             self.cell_class = hit.argmax(axis=1).astype(np.uint8)
-        if self.mixup and self.training:
+        if (self.mixup or self.cutmix) and self.training:
             for n1, (k, prop) in enumerate(self.cell_properties.items()):
                 if prop["discrete"] and (mask[:, n1] == 0).any():
                     # alpha * (-100) + (1 - alpha) * class is no class index: cross_entropy then reads outside its
@@ -388,6 +386,32 @@ class SingleCellDataset:
             cell_mask = ops.mixup_counts(cell_mask, p, a)
         return gene_vals, cell_vals, cell_mask
 
+    def _cutmix(self, gene_vals, cell_vals, cell_mask, keep_u8=False):
+        """data.py:431-454: the reference's draws replayed on the host in its order (two gamma vectors, then per cell one
+        partner and one ``np.random.choice(n_genes, int(alpha n_genes), replace=False)``), the arrays on the device:
+        genes of the subset are COPIED from the partner (``vae_cutmix_counts``; counts stay integers), the label / mask
+        tables are blended with alpha as in mixup."""
+        N, G = gene_vals.shape
+        g1 = np.random.gamma(0.25, size=N)
+        g2 = np.random.gamma(0.25, size=N)
+        alpha = g1 / (g1 + g2)
+        partner = np.zeros(N, dtype=np.int64)
+        take = np.zeros((N, G), dtype=np.uint8)
+        cpg = self.cell_per_group if self.group_balancing is not None else None
+        for i in range(N):
+            partner[i] = np.random.randint(0, cpg) + (i // cpg) * cpg if cpg is not None else np.random.randint(0, N)
+            take[i, np.random.choice(self.n_genes, int(alpha[i] * self.n_genes), replace=False)] = 1
+        if partner.max() >= N:
+            raise ValueError("vae_amd.data: batch smaller than groups x cell_per_group, cutmix partner outside the batch")
+        p = self.store.upload(partner.astype(np.int32))
+        gene_vals = ops.cutmix_counts(gene_vals, p, torch.from_numpy(take).to(self.device),
+                                      out_dtype=gene_vals.dtype if (keep_u8 or self.counts_dtype != torch.float32) else torch.float32)
+        if cell_vals is not None:
+            a = self.store.upload(alpha)
+            cell_vals = ops.mixup_counts(cell_vals, p, a)
+            cell_mask = ops.mixup_counts(cell_mask, p, a)
+        return gene_vals, cell_vals, cell_mask
+
     def __getitem__(self, batch_idx):
         if isinstance(batch_idx, (int, np.integer)):
             batch_idx = [int(batch_idx)]
@@ -401,7 +425,8 @@ class SingleCellDataset:
             raise IndexError(f"vae_amd.data: batch index outside [0, {self.n_samples})")
         cell_idx = self.cell_idx[rows]
         mix = self.mixup and self.training
-        gene_vals = self.store.gather(cell_idx, self._gene_idx_dev, torch.uint8 if mix else self.counts_dtype)
+        cut = self.cutmix and self.training                    # data.py:513-519: cutmix first, then mixup (both may be on)
+        gene_vals = self.store.gather(cell_idx, self._gene_idx_dev, torch.uint8 if (mix or cut) else self.counts_dtype)
         cell_prop_vals = cell_mask = batch_labels = batch_mask = None
         if self.labels is not None or self.batch_properties is not None:
             rows_dev = self.store.upload(rows)
@@ -410,6 +435,8 @@ class SingleCellDataset:
         if self.batch_properties is not None:
             batch_labels, batch_mask = self._batch_labels_dev[rows_dev], self._batch_mask_dev[rows_dev]
         subject = self.subjects[rows] if self.subjects is not None else None
+        if cut:
+            gene_vals, cell_prop_vals, cell_mask = self._cutmix(gene_vals, cell_prop_vals, cell_mask, keep_u8=mix)
         if mix:
             gene_vals, cell_prop_vals, cell_mask = self._mixup(gene_vals, cell_prop_vals, cell_mask)
         return (gene_vals, cell_prop_vals, cell_mask, batch_labels, batch_mask, cell_idx, group_idx, subject)

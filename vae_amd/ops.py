@@ -527,6 +527,26 @@ def mixup_counts(x: torch.Tensor, partner: torch.Tensor, alpha: torch.Tensor) ->
     return out
 
 
+def cutmix_counts(x: torch.Tensor, partner: torch.Tensor, take: torch.Tensor, out_dtype=None) -> torch.Tensor:
+    """take[i, g] ? x[partner[i], g] : x[i, g] (data.py:431-454, the array part; include/vae_amd.h).  x: (B, G) uint8 or
+    float32; partner: int32 (B); take: (B, G) uint8 (nonzero = from the partner); -> uint8 or float32 (``out_dtype``,
+    default: x's)."""
+    lib = _lib.load()
+    u8 = _chk_counts(x, "x")
+    B, G = x.shape
+    if not partner.is_cuda or partner.dtype != torch.int32 or partner.shape != (B,) or not partner.is_contiguous():
+        raise TypeError("vae_amd.ops.cutmix_counts: partner must be a contiguous int32 GPU tensor of length B")
+    if not take.is_cuda or take.dtype != torch.uint8 or take.shape != (B, G) or take.stride(1) != 1:
+        raise TypeError("vae_amd.ops.cutmix_counts: take must be a (B, G) uint8 GPU tensor with a contiguous last dim")
+    out_dtype = out_dtype or x.dtype
+    if out_dtype not in (torch.uint8, torch.float32) or (out_dtype == torch.uint8 and not u8):
+        raise TypeError("vae_amd.ops.cutmix_counts: out_dtype must be uint8 (uint8 input only) or float32")
+    out = torch.empty(B, G, dtype=out_dtype, device=x.device)
+    _lib.check(lib.vae_cutmix_counts(_p(x), _lib.X_U8 if u8 else _lib.X_F32, _ld(x), B, G, _p(partner), _p(take), _ld(take), _p(out),
+                                     _lib.X_U8 if out_dtype == torch.uint8 else _lib.X_F32, G, _stream()), "cutmix_counts")
+    return out
+
+
 def loglik_elem_fwd(zinb: bool, x, mu, theta, pi) -> torch.Tensor:
     """Element-wise log_nb_positive / log_zinb_positive; theta is (G,) or (B,G)."""
     lib = _lib.load()
