@@ -110,6 +110,70 @@ def _nccl_worker(rank, world, port, payload, q):
         dist.destroy_process_group()
 
 
+def _rccl_one_rank_worker(port, q):
+    """One rank, backend nccl (= RCCL), collectives forced on: every call of the product path executes on the card --
+    the native events, the high-priority side stream, in-place all_reduce(AVG) on slices of the gradient arena, the bf16
+    wire copy, broadcast of the parameter arena -- and must leave the single rank's own gradients behind."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    try:
+        opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)      # as bench.py creates the group
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0), pg_options=opts)
+    except (AttributeError, TypeError):
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        from oracle import vae_oracle as O
+        from vae_amd.arena import ParamArena
+        from vae_amd.parallel import GradAllReducer, broadcast_parameters
+        from vae_amd.step import ElboStep
+        B, G, H, Hd, Hl, L = 512, 4000, 128, 128, 64, 10
+        p = O.init_params(G, H, Hd, Hl, L, 1, seed=21)
+        x = O.synthetic_counts(B, G, seed=21, zero_inflate=0.3).cuda()
+        g = torch.Generator().manual_seed(22)
+        ez, el = torch.randn(B, L, generator=g).cuda(), torch.randn(B, 1, generator=g).cuda()
+        arena = ParamArena(p, 1, "zinb", "cuda")
+        broadcast_parameters(arena)
+        dist.broadcast(arena.flat, src=0)                                   # (the call a larger group makes)
+        step = ElboStep(arena, l_mean=7.0, l_var=1.0)
+        step.run(x, ez, el)
+        torch.cuda.synchronize()
+        want = arena.flat_grad[:arena.used_end].clone()
+        res = {}
+        for payload in ("fp32", "bf16"):
+            red = GradAllReducer(arena, payload=payload, force_collectives=True)
+            assert red.active and red.avg_in_collective and not red.host_staged
+            for _ in range(5):                                              # several steps in flight, no synchronisation
+                arena.flat_grad.fill_(float("nan"))
+                step.run(x, ez, el, reducer=red)
+                red.finish()
+            torch.cuda.synchronize()
+            real = torch.zeros(arena.used_end, dtype=torch.bool, device="cuda")     # gradient elements (not alignment padding)
+            for k, (off, shape) in arena.offsets.items():
+                if k not in arena.no_grad and off < arena.used_end:
+                    real[off:off + arena.g(k).numel()] = True
+            got = arena.flat_grad[:arena.used_end]
+            res[payload] = float((got[real] - want[real]).abs().max() / want[real].abs().max())
+        ok = res["fp32"] == 0.0 and res["bf16"] < 1e-2
+        q.put(("ok" if ok else "fail", res))
+    except Exception as e:  # noqa: BLE001
+        q.put(("fail", repr(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_path_executes_with_one_rank():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    proc = ctx.Process(target=_rccl_one_rank_worker, args=(29500 + (os.getpid() % 2000) + 77, q))
+    proc.start()
+    res = q.get(timeout=240)
+    proc.join(timeout=60)
+    assert res[0] == "ok", res
+
+
 @pytest.mark.parametrize("payload", ["fp32", "bf16"])
 def test_two_ranks_rccl_match_the_full_batch_gradient(payload):
     if torch.cuda.device_count() < 2:

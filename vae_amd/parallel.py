@@ -40,18 +40,22 @@ BUCKET_ORDER = ("dec_heads", "small", "enc_w0")
 
 
 class GradAllReducer:
-    def __init__(self, arena: ParamArena, group: Optional["dist.ProcessGroup"] = None, payload: str = "fp32"):
+    def __init__(self, arena: ParamArena, group: Optional["dist.ProcessGroup"] = None, payload: str = "fp32",
+                 force_collectives: bool = False):
+        """``force_collectives``: run every collective although the group has ONE rank (they are identities then) --
+        lets a one-GPU box execute the whole RCCL path (events, side stream, in-place AVG on arena slices)."""
         if payload not in ("fp32", "bf16"):
             raise ValueError("payload must be 'fp32' or 'bf16'")
         self.arena = arena
         self.group = group
         self.payload = payload
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.active = self.world > 1 or (force_collectives and dist.is_initialized())
         self.on_gpu = arena.flat_grad.is_cuda
         backend = dist.get_backend(group) if dist.is_initialized() else None
-        self.host_staged = self.on_gpu and self.world > 1 and backend != "nccl"
+        self.host_staged = self.on_gpu and self.active and backend != "nccl"
         # RCCL averages in the collective itself (ReduceOp.AVG); gloo has no AVG: sum, then scale
-        self.avg_in_collective = self.world > 1 and self.on_gpu and backend == "nccl"
+        self.avg_in_collective = self.active and self.on_gpu and backend == "nccl"
         self.comm_stream = torch.cuda.Stream(device=arena.device, priority=-1) if self.on_gpu else None
         self._pending: List[tuple] = []
         # bucket boundaries (element offsets into flat_grad).  Under NB the dropout-head weights have no
@@ -72,7 +76,7 @@ class GradAllReducer:
         for spans in self.buckets.values():
             for span in spans:
                 n = span[1] - span[0]
-                if n <= 0 or self.world == 1:
+                if n <= 0 or not self.active:
                     continue
                 if payload == "bf16":
                     self._wire[span] = torch.empty(n, dtype=torch.bfloat16, device=arena.device)
@@ -83,7 +87,7 @@ class GradAllReducer:
     def bucket_ready(self, tag: str, after_event=None) -> None:
         """Start reducing bucket ``tag``.  ``after_event``: an event already recorded (by the native
         step) at the point of the compute stream where the bucket became final; default = now."""
-        if self.world == 1:
+        if not self.active:
             return
         for span in self.buckets[tag]:
             lo, hi = span
@@ -121,7 +125,7 @@ class GradAllReducer:
 
     def finish(self) -> None:
         """Wait for every bucket, apply the 1/world averaging; the compute stream then owns the grads."""
-        if self.world == 1:
+        if not self.active:
             return
         scale = 1.0 / self.world
         ctx = torch.cuda.stream(self.comm_stream) if self.on_gpu else _Null()

@@ -127,6 +127,7 @@ class ElboStep:
         self.grads = _tensors(a.g, a.gcat, self.n_layers, self.zinb)
         self.weight_maxima = None
         self._plans: Dict[int, tuple] = {}
+        self.max_plans = 4          # distinct (batch size, training) workspaces kept alive (train, validation, two tails)
         self._ev_heads = self._ev_small = None
         self._zero = None
         self._last_fwd = None
@@ -184,6 +185,10 @@ class ElboStep:
                 v["gene_threshold"] = ws[o:o + self.G].view(torch.int32)
                 v["gene_p_mean"] = ws[o + self.G:o + self.G + 1]
             self._plans[key] = (cfg, ws, nbytes, v)
+            while len(self._plans) > self.max_plans:      # a workspace is 0.3-1.5 GB: keep the most recent batch sizes only
+                self._plans.pop(next(iter(self._plans)))
+        else:
+            self._plans[key] = self._plans.pop(key)       # most recently used last
         cfg, ws, nbytes, v = self._plans[key]
         cfg.loss_scale = float(loss_scale)
         cfg.kl_weight = self.kl_weight
@@ -263,7 +268,7 @@ class ElboStep:
         # gradients final / everything but the first-layer encoder weights final -- and the reducer's side stream
         # waits for them, so the buckets travel while the rest of the backward computes (parallel.py).
         ev_heads = ev_small = None
-        if reducer is not None and reducer.world > 1 and reducer.on_gpu and not os.environ.get("VAE_NO_NATIVE_EVENT"):
+        if reducer is not None and getattr(reducer, "active", reducer.world > 1) and reducer.on_gpu and not os.environ.get("VAE_NO_NATIVE_EVENT"):
             if self._ev_heads is None:
                 self._ev_heads, self._ev_small = torch.cuda.Event(), torch.cuda.Event()
                 self._ev_heads.record()   # materialises the hipEvent_t handles (torch creates them lazily)
