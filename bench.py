@@ -54,7 +54,7 @@ MFMA_BASIS = {"fp32": "f16 dense 2500 TFLOP/s / 3 products per fp32 multiply-add
 DTYPE_TEXT = {"fp32": "f32 (the five gene-sized GEMMs: operands scaled by a power of two and split into 2 f16 terms, 3 f16 MFMA "
                       "products, f32 accumulate -- error vs f64 below the f32 MFMA's own; everything else f32)",
               "fp32x3": "f32 (GEMM operands split exactly into 3 bf16 terms, 6 bf16 MFMA products, f32 accumulate; everything else f32)",
-              "bf16": "bf16 GEMM operands, f32 accumulate and likelihood"}
+              "bf16": "bf16 GEMM operands, f32 accumulate and likelihood arithmetic; xn, logits and logit gradients stored as bf16 (the reference's autocast storage) where config.bf16_activations says so"}
 
 
 def synth_counts_device(n, G, device, seed, zero_inflate):
@@ -369,6 +369,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     loss = float(out["loss"])
+    bf16_st = step.bf16_activations(B)
 
     result = None
     if rank == 0:
@@ -383,16 +384,14 @@ def main():
             "config": {"workload": f"{args.config}: {cfg['desc']}", "batch_per_gpu": B, "global_batch": B * world,
                        "genes": G, "likelihood": cfg["likelihood"], "n_layers": cfg["n_layers"],
                        "parallelism": f"dp{world}", "grad_payload": args.grad_payload if world > 1 else None,
-                       "counts": args.counts,
+                       "counts": args.counts, "bf16_activations": bf16_st,
                        "weight_operand_scales": "maxima kept by the fused optimiser (vae_adamw_step_wmax)" if fopt is not None
                        else "scanned by every forward"},
             "final_loss": loss,
         }
     if rank == 0 and not args.no_breakdown:
         xb = x_all[:B].float()
-        bf16_st = step.bf16_activations(B)
         ks = kernel_breakdown(arena, cfg, xb, precision, bf16_st)
-        result["config"]["bf16_activations"] = bf16_st
         name, (t_ms, bound, work) = max(ks.items(), key=lambda kv: kv[1][0])
         if bound == "hbm":
             ach, peak, unit = work / (t_ms * 1e-3) / 1e9, HBM_PEAK_GBS, "GB/s"
