@@ -305,7 +305,7 @@ int vae_gene_dropout(const void* x, int x_dtype, int64_t ldx, int64_t B, int64_t
                      float* xn, int64_t ld_xn, void* stream);
 
 /* ---- the whole training step -------------------------------------------------------------------
- * LitVAE.training_step (task.py:453-502) for dispersion "gene", no batch covariates, no input dropout:
+ * LitVAE.training_step (task.py:453-502) for dispersion "gene":
  * one call enqueues the forward, one the backward; all intermediates live in `workspace`.
  * Parameter / gradient pointers follow the reference's state_dict (SURVEY.md par. 3.4); tensors the
  * kernels address as one stacked matrix must be adjacent in memory (vae_amd/arena.py):
@@ -339,16 +339,27 @@ typedef struct {
   const float* weight_max_enc;
   const float* weight_max_heads;
   int32_t weight_max_n;
+  /* Batch covariates (FCLayers.forward, modules.py:121-130; networks.py:187,218,229): the reference appends the masked
+   * one-hot block cov = [one_hot(label_p) * mask_p for every batch property p] (B, n_cov) to the input of the FIRST
+   * layer of both encoders (after the count normalisation, modules.py:264,267) and of the decoder.  With n_cov > 0
+   *   enc_w0 rows hold [G count columns | n_cov covariate columns | padding] with row stride ld_enc_w (0 = G + n_cov),
+   *   dec_w[0] is (Hd, L + n_cov) contiguous, in params and grads alike;
+   * the gene-wide products keep running on the count columns, the covariate columns add two small products
+   * (cov W_c^T forward, dpre^T cov for the gradient).  Padding columns are neither read nor written.  n_cov = 0: none. */
+  int32_t n_cov;
+  const float* batch_cov;     /* (B, n_cov) device, row stride ld_cov                                    */
+  int64_t ld_cov;
+  int64_t ld_enc_w;
 } vae_step_config;
 
 typedef struct {
   float* px_r;                                   /* (G)                                              */
-  float *enc_w0, *enc_b0;                        /* (H+Hl, G), (H+Hl)                                */
+  float *enc_w0, *enc_b0;                        /* (H+Hl, G) [batch covariates: see vae_step_config], (H+Hl) */
   float *encz_ln_g[VAE_MAX_LAYERS], *encz_ln_b[VAE_MAX_LAYERS]; /* z-encoder LayerNorm per layer (H)  */
   float *encz_w[VAE_MAX_LAYERS], *encz_b[VAE_MAX_LAYERS];       /* layers >= 1: (H,H), (H); [0] unused */
   float *encl_ln_g, *encl_ln_b;                  /* library-encoder LayerNorm (Hl)                   */
   float *hz_w, *hz_b, *hl_w, *hl_b;              /* (L+1,H), (L+1), (2,Hl), (2)                      */
-  float *dec_w[VAE_MAX_LAYERS], *dec_b[VAE_MAX_LAYERS];         /* (Hd, L) / (Hd, Hd), (Hd)          */
+  float *dec_w[VAE_MAX_LAYERS], *dec_b[VAE_MAX_LAYERS];         /* (Hd, L + n_cov) / (Hd, Hd), (Hd)  */
   float *dec_ln_g[VAE_MAX_LAYERS], *dec_ln_b[VAE_MAX_LAYERS];   /* (Hd)                              */
   float *heads_w, *heads_b;                      /* (2G or G, Hd), (2G or G)                         */
 } vae_step_tensors;

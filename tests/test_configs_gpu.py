@@ -27,9 +27,10 @@ HEADS = {   # bench.py's cfg5 heads: two discrete, one adversarial (gradient rev
 GRAD_REVERSE = {"Sex": 0.2}
 
 
-def _run_both(B, G, H, Hd, Hl, L, n_layers, precision, *, heads=False, seed=43, likelihood="zinb", tweak=None):
+def _run_both(B, G, H, Hd, Hl, L, n_layers, precision, *, heads=False, seed=43, likelihood="zinb", tweak=None, cov_sizes=None):
     """-> (oracle outputs, oracle grads, step outputs, arena).  precision: 0 / 3 fp32-grade (oracle in fp64), 1 bf16
-    (oracle in fp32 with bf16-rounded GEMM operands)."""
+    (oracle in fp32 with bf16-rounded GEMM operands).  cov_sizes: class counts of batch properties -- the model gets
+    the covariate columns of modules.py:102-107 and the step the masked one-hot block."""
     from oracle import vae_oracle as O
     from vae_amd.arena import ParamArena
     from vae_amd.step import ElboStep
@@ -38,11 +39,25 @@ def _run_both(B, G, H, Hd, Hl, L, n_layers, precision, *, heads=False, seed=43, 
     p = O.init_params(G, H, Hd, Hl, L, n_layers, seed=seed, cell_properties=props)
     if tweak is not None:
         tweak(p)
+    cov = None
+    if cov_sizes:   # widen the three first-layer weights by the covariate columns; labels with -1 and masked cells
+        gc = torch.Generator().manual_seed(seed + 2)
+        C = int(sum(cov_sizes))
+        for k in ("z_encoder.encoder.fc_layers.0.weight", "l_encoder.encoder.fc_layers.0.weight", "decoder.px_decoder.fc_layers.0.weight"):
+            w = p[k]
+            p[k] = torch.cat((w, torch.randn(w.shape[0], C, generator=gc) * w.std() * 3), dim=1).contiguous()
+        labels = torch.stack([torch.randint(-1, n, (B,), generator=gc) for n in cov_sizes], dim=1)
+        cmask = (torch.rand(B, len(cov_sizes), generator=gc) > 0.15).long()
+        cmask[labels < 0] = 0
+        cmask[3, :] = 0
+        cov = O.batch_covariates(labels.clone(), cmask, cov_sizes)
     x = O.synthetic_counts(B, G, seed=seed, zero_inflate=0.3 if likelihood == "zinb" else 0.0)
     g = torch.Generator().manual_seed(seed + 1)
     eps_z, eps_l = torch.randn(B, L, generator=g), torch.randn(B, 1, generator=g)
     lm, lv = O.library_prior(x)
     kw = dict(n_layers=n_layers, likelihood=likelihood, l_mean=lm, l_var=lv)
+    if cov is not None:
+        kw.update(cov=cov)
     targets = mask = None
     if heads:
         targets = torch.stack([torch.randint(0, len(v["values"]), (B,), generator=g).float() if v["discrete"]
@@ -71,7 +86,12 @@ def _run_both(B, G, H, Hd, Hl, L, n_layers, precision, *, heads=False, seed=43, 
                 q.data, q.grad = arena.p(f"cell_decoder.cell_mlp.{k}.{leaf}"), arena.g(f"cell_decoder.cell_mlp.{k}.{leaf}")
         t, m = targets.cuda(), mask.cuda()
         fn = lambda z: cell_loss(dec(z), HEADS, t, m)  # noqa: E731
-    out = step.run(x.cuda(), eps_z.cuda(), eps_l.cuda(), cell_head_fn=fn)
+    bc = None
+    if cov is not None:
+        lab = labels.clone().cuda()
+        bc = ElboStep.covariates(lab, cmask.cuda(), cov_sizes)
+        assert int(lab.min()) == 0 and torch.equal(bc.cpu(), cov.float())      # clamped in place, as the reference does
+    out = step.run(x.cuda(), eps_z.cuda(), eps_l.cuda(), cell_head_fn=fn, batch_cov=bc)
     torch.cuda.synchronize()
     return o_out, o_grads, out, arena
 
@@ -128,6 +148,31 @@ def test_gene_count_not_a_multiple_of_four(precision):
     VAE_FP32; arbitrary gene counts are normal (protein_coding_only filtering, data.py)."""
     o_out, o_grads, out, arena = _run_both(256, 4098, 128, 128, 128, 10, 1, precision=precision, seed=7)
     _check(o_out, o_grads, out, arena, TOL_CELL, TOL_GRAD, 25)
+
+
+@pytest.mark.parametrize("n_layers", [1, 2])
+@pytest.mark.parametrize("precision", [0, 3, 1], ids=["bf16x3", "f16x2", "bf16"])
+def test_batch_covariates_on_the_fused_step(precision, n_layers):
+    """VAE(batch_properties=...) on the native step.  11 one-hot columns make the encoder rows 4096 + 11
+    wide: the arena pads the row stride to 4112 so that the gene-wide products stay on the tile pipeline (16-byte rows),
+    the covariate columns add cov W_c^T to both first layers (encoders after the count normalisation, and the decoder)
+    and dpre^T cov to their weight gradients (modules.py:121-130).  Labels contain -1 (clamped in place) and masked cells."""
+    G, sizes = 4096, (3, 2, 6)
+    o_out, o_grads, out, arena = _run_both(256, G, 128, 128, 128, 10, n_layers, precision=precision, seed=11, cov_sizes=sizes)
+    assert arena.n_cov == 11 and arena.ld_enc_w == 4112
+    bf16 = precision == 1
+    tc, tg = (TOL_CELL_BF16, TOL_GRAD_BF16) if bf16 else (TOL_CELL, TOL_GRAD)
+    _check(o_out, o_grads, out, arena, tc, tg, 25 if n_layers == 1 else 33)
+    for k in ("z_encoder.encoder.fc_layers.0.weight", "l_encoder.encoder.fc_layers.0.weight"):   # covariate columns on their own scale
+        got, ref = arena.g(k)[:, G:].cpu().numpy(), o_grads[k][:, G:].double().numpy()
+        assert rel_err(got, ref) < tg, k
+    k = "decoder.px_decoder.fc_layers.0.weight"
+    assert rel_err(arena.g(k)[:, 10:].cpu().numpy(), o_grads[k][:, 10:].double().numpy()) < tg
+    # padding columns of the strided rows: zero in weights and gradients
+    z = arena.pcat("z_encoder.encoder.fc_layers.0.weight", "l_encoder.encoder.fc_layers.0.weight")
+    flat_w = arena.flat[:256 * 4112].view(256, 4112)
+    flat_g = arena.flat_grad[:256 * 4112].view(256, 4112)
+    assert z.shape == (256, G + 11) and float(flat_w[:, G + 11:].abs().max()) == 0.0 and float(flat_g[:, G + 11:].abs().max()) == 0.0
 
 
 # ---------------------------------------------------------------------------------------------------------------

@@ -356,17 +356,23 @@ def test_likelihood_grid_elementwise(ops, zinb):
 # fused optimiser step against torch.nn.utils.clip_grad_norm_ + torch.optim.AdamW,
 # the optimiser the reference configures (task.py:534-553, train.py:54), run on the CPU in fp32.
 # ------------------------------------------------------------------------------------------------
-def _tiny_arena(likelihood="zinb"):
+def _tiny_arena(likelihood="zinb", n_cov=0):
     from oracle import vae_oracle as O
     from vae_amd.arena import ParamArena
     p = O.init_params(77, 12, 10, 6, 3, 1, seed=3)
+    if n_cov:   # batch-covariate columns (modules.py:102-107): the arena stores the encoder rows with a padded stride
+        g = torch.Generator().manual_seed(4)
+        for k in ("z_encoder.encoder.fc_layers.0.weight", "l_encoder.encoder.fc_layers.0.weight", "decoder.px_decoder.fc_layers.0.weight"):
+            p[k] = torch.cat((p[k], torch.randn(p[k].shape[0], n_cov, generator=g) * 0.1), dim=1).contiguous()
     return p, ParamArena(p, 1, likelihood, "cuda")
 
 
-@pytest.mark.parametrize("max_norm,wd", [(0.5, 0.1), (0.0, 0.0), (1e9, 0.05)])
-def test_fused_adamw_matches_torch_trajectory(max_norm, wd):
+@pytest.mark.parametrize("max_norm,wd,n_cov", [(0.5, 0.1, 0), (0.0, 0.0, 0), (1e9, 0.05, 0), (0.5, 0.1, 5)])
+def test_fused_adamw_matches_torch_trajectory(max_norm, wd, n_cov):
     from vae_amd.optim import FusedAdamW, reference_weight_decay
-    p0, arena = _tiny_arena()
+    p0, arena = _tiny_arena(n_cov=n_cov)
+    if n_cov:
+        assert arena.ld_enc_w == 88 and arena.p("z_encoder.encoder.fc_layers.0.weight").stride() == (88, 1)
     warm = 4.0
     lam = lambda s: (warm ** 0.5) * min((s + 1) ** -0.5, (s + 1) * warm ** -1.5)  # noqa: E731
     skip = [k for k in arena.offsets if k.startswith("cell_decoder")]
@@ -398,6 +404,8 @@ def test_fused_adamw_matches_torch_trajectory(max_norm, wd):
             assert rel_err(arena.p(k).cpu().numpy(), tp[k].detach().numpy()) < 2e-6, (it, k)
     for k, v in before_unused.items():   # parameters without a gradient are never touched
         assert torch.equal(arena.p(k), v), k
+    if n_cov:   # the padding columns of the strided rows stay zero through clipping, decay and the update
+        assert float(arena.flat[:18 * 88].view(18, 88)[:, 77 + n_cov:].abs().max()) == 0.0
 
 
 def test_fused_adamw_rejects_bad_arguments():

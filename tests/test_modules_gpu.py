@@ -376,9 +376,51 @@ def test_batch_covariates_training_step_matches_the_reference(monkeypatch):
             assert rel_err(p.grad[:, G:].cpu().numpy(), g[:, G:]) < TOL_GRAD, k + " (covariate columns)"
         n += 1
     assert n >= 30
-    # the fused step refuses this configuration loudly
-    with pytest.raises(NotImplementedError):
-        task.training_step_fused(batch)
+
+
+@pytest.mark.parametrize("precision", ["fp32x3", "f16x2"])
+def test_batch_covariates_fused_step_matches_the_reference(precision):
+    """The same reference-made fixture through LitVAE.training_step_fused: the arena re-homes the (H, G + 5) first-layer
+    weights with padded rows, the native step adds the covariate products (include/vae_amd.h, vae_step_config.n_cov)."""
+    from golden_inputs import F4_CASES, build_f4_inputs
+    from vae_amd import ops
+    from vae_amd.task import LitVAE
+    case = copy.deepcopy(F4_CASES[0])
+    gold = load_golden("f4_batchcov.npz")
+    x, eps_z, eps_l, bl, bm, targets, mask = build_f4_inputs(case)
+    net = _f4_network(case, gold)
+    G = case["G"]
+    task = LitVAE(net, cell_properties=case["cell_properties"], batch_properties=case["batch_properties"],
+                  reconstruction_loss="zinb", n_epochs_kl_warmup=None, gene_loss_coeff=case["gene_loss_coeff"],
+                  library_mean=np.float32(case["l_mean"]), library_var=np.float32(case["l_var"]),
+                  precision=ops.FP32 if precision == "fp32x3" else ops.F16X2).train()
+    labels = bl.clone().cuda()
+    batch = (x.float().cuda(), targets.cuda(), mask.cuda(), labels, bm.cuda(), None, None, None)
+    out = task.training_step_fused(batch, eps_z=eps_z[0].float().cuda(), eps_l=eps_l.float().cuda())
+    torch.cuda.synchronize()
+    assert int(labels.min()) == 0
+    assert net.z_encoder.encoder.fc_layers[0].weight.shape == (case["H"], G + 5)
+    assert net.z_encoder.encoder.fc_layers[0].weight.stride() == (72, 1)            # 64 + 5 columns, rows padded to 72
+    for k in ("qz_m", "qz_v", "z", "ql_m", "ql_v", "library", "recon", "kl_z", "kl_l"):
+        assert rel_err(out[k].cpu().numpy().reshape(gold[f"out/{k}"].shape), gold[f"out/{k}"]) < TOL_CELL, k
+    for k in ("loss", "gene_loss", "cell_loss"):
+        assert abs(float(out[k]) - float(gold[f"out/{k}"])) < TOL_CELL * abs(float(gold[f"out/{k}"])), k
+    n = 0
+    for k, p in net.named_parameters():
+        if f"gradnone/{k}" in gold.files:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+            continue
+        g = gold[f"grad/{k}"]
+        assert rel_err(p.grad.cpu().numpy(), g) < TOL_GRAD, k
+        if k.endswith("encoder.fc_layers.0.weight"):
+            assert rel_err(p.grad[:, G:].cpu().numpy(), g[:, G:]) < TOL_GRAD, k + " (covariate columns)"
+        if k == "decoder.px_decoder.fc_layers.0.weight":
+            assert rel_err(p.grad[:, case["L"]:].cpu().numpy(), g[:, case["L"]:]) < TOL_GRAD, k + " (covariate columns)"
+        n += 1
+    assert n >= 30
+    # the state dict keeps the reference's shapes (strided views of the arena are saved as plain tensors)
+    sd = net.state_dict()
+    assert sd["z_encoder.encoder.fc_layers.0.weight"].shape == (case["H"], G + 5)
 
 
 def test_grouped_encoder_forward_matches_the_reference(monkeypatch):

@@ -109,7 +109,8 @@ class StepConfig(C.Structure):
                 ("l_mean", _f32), ("l_var", _f32), ("kl_weight", _f32), ("gene_loss_coeff", _f32), ("loss_scale", _f32),
                 ("x_dtype", C.c_int32), ("dropout_rate", _f32), ("rng_step", C.c_uint32), ("rng_seed", C.c_uint64),
                 ("input_dropout_rate", _f32), ("input_dropout_alpha", _f32), ("gene_running", _ptr),
-                ("weight_max_enc", _ptr), ("weight_max_heads", _ptr), ("weight_max_n", C.c_int32)]
+                ("weight_max_enc", _ptr), ("weight_max_heads", _ptr), ("weight_max_n", C.c_int32),
+                ("n_cov", C.c_int32), ("batch_cov", _ptr), ("ld_cov", _i64), ("ld_enc_w", _i64)]
 
 
 class StepTensors(C.Structure):

@@ -11,6 +11,11 @@ All parameters of the model live in ONE contiguous fp32 buffer in HBM, ordered s
 The gradient arena mirrors the layout, which makes the data-parallel all-reduce a handful
 of large contiguous buckets (vae_amd/parallel.py).  State-dict key names are the
 reference's (networks.py:162-231).
+
+Batch covariates (``VAE(batch_properties=...)``, modules.py:102-107): the first-layer weights of the encoders are
+(H, G + n_cov).  Their rows are stored with a stride rounded up to 8 floats (``ld_enc_w``) so that the gene-wide GEMMs
+keep 16-byte aligned rows for any n_cov; the parameter is a strided VIEW of shape (H, G + n_cov), the padding columns
+are zero in the weights and in the gradients and stay so (nothing reads or writes them; AdamW maps 0 -> 0).
 """
 from __future__ import annotations
 
@@ -67,6 +72,13 @@ class ParamArena:
             raise KeyError(f"ParamArena: parameter set mismatch; missing {missing}, unexpected {sorted(extra)}")
 
         self.offsets: "OrderedDict[str, Tuple[int, torch.Size]]" = OrderedDict()
+        G = params["px_r"].shape[0]
+        self.n_cov = int(params[big[0][0]].shape[1]) - G          # one-hot batch-covariate columns (0: none)
+        if self.n_cov < 0 or params[big[0][1]].shape[1] != G + self.n_cov or params[_dec(0, "w")].shape[1] != \
+                params["z_encoder.mean_encoder.weight"].shape[0] + self.n_cov:
+            raise ValueError("ParamArena: first-layer weight widths do not agree on the number of covariate columns")
+        self.ld_enc_w = (G + self.n_cov + 7) & ~7 if self.n_cov else G
+        self.row_stride: Dict[str, int] = {k: self.ld_enc_w for k in big[0]} if self.n_cov else {}
         off = 0
         for grp in groups:
             off = (off + 3) & ~3  # 16-byte alignment of every group start (vector loads)
@@ -76,7 +88,7 @@ class ParamArena:
                 self.small_end = off
             for k in grp:
                 self.offsets[k] = (off, params[k].shape)
-                off += params[k].numel()
+                off += self.extent(k)
         self.used_end = self.small_end
         self.cell_begin = self.offsets[cell[0]][0] if cell else self.small_end   # cell heads: last groups of "small"
         self.total = (off + 3) & ~3
@@ -90,12 +102,21 @@ class ParamArena:
             self.no_grad |= {"decoder.px_dropout_decoder.weight", "decoder.px_dropout_decoder.bias"}
 
     # -- views ---------------------------------------------------------------------------
-    def _view(self, buf: torch.Tensor, k: str) -> torch.Tensor:
-        off, shape = self.offsets[k]
+    def extent(self, k: str) -> int:
+        """Floats the parameter occupies in the arena (rows x row stride for a padded matrix)."""
+        _, shape = self.offsets[k]
+        if k in self.row_stride:
+            return shape[0] * self.row_stride[k]
         n = 1
         for s in shape:
             n *= s
-        return buf[off:off + n].view(shape)
+        return n
+
+    def _view(self, buf: torch.Tensor, k: str) -> torch.Tensor:
+        off, shape = self.offsets[k]
+        if k in self.row_stride:
+            return buf.as_strided(tuple(shape), (self.row_stride[k], 1), off)
+        return buf[off:off + self.extent(k)].view(shape)
 
     def p(self, k: str) -> torch.Tensor:
         return self._view(self.flat, k)
@@ -112,13 +133,12 @@ class ParamArena:
         for k in keys:
             off, shape = self.offsets[k]
             tail = shape[1:] if len(shape) > 1 else torch.Size([])
-            if off != expect or tail != cols:
+            if off != expect or tail != cols or self.row_stride.get(k) != self.row_stride.get(keys[0]):
                 raise RuntimeError(f"ParamArena: {keys} are not adjacent / compatible in the arena")
-            n = 1
-            for s in shape:
-                n *= s
-            expect = off + n
+            expect = off + self.extent(k)
             rows += shape[0]
+        if keys[0] in self.row_stride:
+            return buf.as_strided((rows,) + tuple(cols), (self.row_stride[keys[0]], 1), off0)
         return buf[off0:expect].view((rows,) + tuple(cols))
 
     def pcat(self, *keys: str) -> torch.Tensor:

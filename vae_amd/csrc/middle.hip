@@ -1182,6 +1182,7 @@ __global__ __launch_bounds__(TW) void small_wgrad_kernel(WgradBatch wb) {
 bool vae_mid_supported(const vae_step_config& c) {
   static const bool off = getenv("VAE_NO_FUSED_MIDDLE") != nullptr;  // A/B knob: run the unfused launch sequence
   if (off) return false;
+  if (c.n_cov > 0) return false;   // batch covariates widen the first decoder weight and add a product to both first layers
   return c.n_layers == 1 && c.H + c.Hl <= ME * T && c.Hd <= ME * T && c.L + 3 <= 64 && c.L >= 1 &&
          c.Hd * (c.L | 1) * 4 <= 48 * 1024;  // the first decoder weight is staged in LDS
 }

@@ -58,6 +58,9 @@ bool bf16_storage(const vae_step_config& c) {
   return ok(VAE_NT, 3, c.B, HE, c.G) && ok(VAE_TN, 3, HE, c.G, c.B);
 }
 inline int64_t maxi(int64_t a, int64_t b) { return a > b ? a : b; }
+// batch covariates (vae_step_config.n_cov): row strides of the two first-layer weights that hold covariate columns
+inline int64_t ld_enc_w(const vae_step_config& c) { return c.n_cov > 0 ? (c.ld_enc_w > 0 ? c.ld_enc_w : c.G + c.n_cov) : c.G; }
+inline int64_t ld_dec_w0(const vae_step_config& c) { return c.L + (c.n_cov > 0 ? c.n_cov : 0); }
 
 bool make_layout(const vae_step_config& c, Layout* lo) {
   if (c.B <= 0 || c.G <= 0 || c.H <= 0 || c.Hl <= 0 || c.L <= 0 || c.Hd <= 0) return false;
@@ -98,7 +101,7 @@ bool make_layout(const vae_step_config& c, Layout* lo) {
   }
   lo->w_enc16 = lo->w_heads16 = lo->px16 = lo->dpre16 = -1;
   if (hb) {
-    lo->w_enc16 = take((H + Hl) * G / 2 + 4);
+    lo->w_enc16 = take((H + Hl) * ld_enc_w(c) / 2 + 4);
     lo->w_heads16 = take(NH * Hd / 2 + 4);
     lo->px16 = take(B * Hd / 2 + 4);
     lo->dpre16 = take(B * (H + Hl) / 2 + 4);
@@ -121,6 +124,10 @@ bool make_layout(const vae_step_config& c, Layout* lo) {
   gw(B, Hd, L); gw(Hd, L, B); gw(B, L, Hd);                 // decoder first layer
   gw(B, Hd, Hd); gw(Hd, Hd, B);                             // deeper decoder layers
   gw(B, NH, Hd); gw(NH, Hd, B); gw(B, Hd, NH);              // decoder heads
+  if (c.n_cov > 0) {                                          // the covariate columns' small products
+    const int64_t Cc = c.n_cov;
+    gw(B, H + Hl, Cc); gw(H + Hl, Cc, B); gw(B, Hd, Cc); gw(Hd, Cc, B);
+  }
   s = maxi(s, vae_gemm_slabs_workspace_bytes(B, H + Hl, G));  // slabs consumed by the fused middle
   s = maxi(s, vae_gemm_slabs_workspace_bytes(B, Hd, NH));
   s = maxi(s, vae_nbzinb_bwd_workspace_bytes(B, G));
@@ -150,7 +157,11 @@ struct Ctx {
   // the two-f16-term pipeline needs 16-byte rows everywhere; ragged shapes run as VAE_FP32
   bool hb() const { return bf16_storage(c); }   // logits / logit gradients held as bf16
   int ldt() const { return hb() ? VAE_L_BF16 : VAE_L_F32; }
-  bool fx() const { return c.precision == VAE_FP32_F16X2 && c.G % 4 == 0 && c.Hd % 4 == 0 && (c.H + c.Hl) % 4 == 0; }
+  bool fx() const {
+    return c.precision == VAE_FP32_F16X2 && c.G % 4 == 0 && c.Hd % 4 == 0 && (c.H + c.Hl) % 4 == 0 && ld_enc_w(c) % 4 == 0;
+  }
+  int64_t ldw() const { return ld_enc_w(c); }
+  bool cov() const { return c.n_cov > 0; }
   // the two weight matrices' maxima may come from outside (vae_step_config.weight_max_*: the optimiser keeps them)
   bool wext() const { return c.weight_max_enc && c.weight_max_heads && c.weight_max_n > 0; }
   float* am(int slot) const {
@@ -178,15 +189,15 @@ struct Ctx {
   // the two products over the normalised counts (xn: fp32, or bf16 when hb()): forward NT (xn = A), weight gradient TN (xn = B)
   int enc_fwd(int64_t N, const float* xn, int slot_x, const float* W, float* C, int64_t ldc, const float* bias, int* slabs_out) const {
     if (hb())   // bf16 xn x the bf16 image of the weight rows
-      return vae_gemm_bf16io(VAE_NT, VAE_IO_A_BF16 | VAE_IO_B_BF16, c.B, N, c.G, xn, lo.ld_xn, h16(lo.w_enc16) + (W - par->enc_w0), c.G, C,
+      return vae_gemm_bf16io(VAE_NT, VAE_IO_A_BF16 | VAE_IO_B_BF16, c.B, N, c.G, xn, lo.ld_xn, h16(lo.w_enc16) + (W - par->enc_w0), ldw(), C,
                              ldc, bias, ws + lo.scratch, lo.scratch_floats * 4, slabs_out, nullptr, st);
-    return big(VAE_NT, c.B, N, c.G, xn, lo.ld_xn, slot_x, W, c.G, AM_WENC, C, ldc, bias, slabs_out);
+    return big(VAE_NT, c.B, N, c.G, xn, lo.ld_xn, slot_x, W, ldw(), AM_WENC, C, ldc, bias, slabs_out);
   }
   int enc_wgrad(int64_t M, const float* dpre, int64_t ld_dpre, const float* xn, int slot_x, float* dW) const {
     if (hb())   // the bf16 image of dpre (cast by the caller) x bf16 xn
       return vae_gemm_bf16io(VAE_TN, VAE_IO_A_BF16 | VAE_IO_B_BF16, M, c.G, c.B, h16(lo.dpre16) + (dpre - (ws + lo.dpre_enc0)), ld_dpre, xn,
-                             lo.ld_xn, dW, c.G, nullptr, ws + lo.scratch, lo.scratch_floats * 4, nullptr, nullptr, st);
-    return big(VAE_TN, M, c.G, c.B, dpre, ld_dpre, AM_DPRE, xn, lo.ld_xn, slot_x, dW, c.G, nullptr, nullptr);
+                             lo.ld_xn, dW, ldw(), nullptr, ws + lo.scratch, lo.scratch_floats * 4, nullptr, nullptr, st);
+    return big(VAE_TN, M, c.G, c.B, dpre, ld_dpre, AM_DPRE, xn, lo.ld_xn, slot_x, dW, ldw(), nullptr, nullptr);
   }
   // nn.Dropout after a hidden LayerNorm (forward: the activation; backward: the gradient arriving there)
   int drop(float* x, int64_t ld, int64_t W, uint32_t site) const {
@@ -217,6 +228,9 @@ int check_common(const vae_step_config* cfg, const void* a, const void* b, const
     return vae_set_error(VAE_ERR_ARG, "%s: input_dropout_rate must be in [0, 1]", who);
   if (cfg->input_dropout_rate > 0.f && (!cfg->gene_running || cfg->G % 4 != 0))
     return vae_set_error(VAE_ERR_ARG, "%s: input dropout needs gene_running and G %% 4 == 0", who);
+  if (cfg->n_cov < 0 || (cfg->n_cov > 0 && (!cfg->batch_cov || cfg->ld_cov < cfg->n_cov ||
+                                            (cfg->ld_enc_w != 0 && cfg->ld_enc_w < cfg->G + cfg->n_cov))))
+    return vae_set_error(VAE_ERR_ARG, "%s: batch covariates need batch_cov (B, n_cov), ld_cov >= n_cov and ld_enc_w >= G + n_cov (or 0)", who);
   if (ws_bytes < lo->total * 4)
     return vae_set_error(VAE_ERR_ARG, "%s: workspace too small: %lld < %lld bytes", who, (long long)ws_bytes,
                          (long long)(lo->total * 4));
@@ -270,10 +284,10 @@ extern "C" int vae_elbo_step_forward(const vae_step_config* cfg, const vae_step_
       return vae_set_error(VAE_ERR_ARG, "vae_elbo_step_forward: weight_max_* must be 16-byte aligned");
     TRY(vae_gene_table(p->px_r, G, ws + lo.table, stream));
   } else if (k.fx())  // weight maxima of the two-f16-term products and the gene table, one launch
-    TRY(vae_step_prologue(p->enc_w0, HE * G, p->heads_w, NH * Hd, k.am(AM_WENC), k.am(AM_WHEADS), p->px_r, G, ws + lo.table,
+    TRY(vae_step_prologue(p->enc_w0, HE * k.ldw(), p->heads_w, NH * Hd, k.am(AM_WENC), k.am(AM_WHEADS), p->px_r, G, ws + lo.table,
                           stream));
   if (k.hb())   // bf16 images of the two gene-sized weight matrices: every product of this step streams those
-    TRY(vae_cast_bf16(p->enc_w0, k.h16(lo.w_enc16), HE * G, p->heads_w, k.h16(lo.w_heads16), NH * Hd, stream));
+    TRY(vae_cast_bf16(p->enc_w0, k.h16(lo.w_enc16), HE * k.ldw(), p->heads_w, k.h16(lo.w_heads16), NH * Hd, stream));
   // encoders: x/mean-1 -> Linear(G, H+Hl) -> GELU -> LayerNorm (z and library halves)
   TRY(vae_normalize_rows_ex(xv, c.x_dtype, ldx, B, G, ws + lo.mean, ws + lo.xn, k.hb(), lo.ld_xn, k.am(AM_XN), stream));
   // GeneDropout (training): the z-encoder reads its own masked + normalised counts, the library encoder xn
@@ -289,7 +303,7 @@ extern "C" int vae_elbo_step_forward(const vae_step_config* cfg, const vae_step_
     const float* slabs = ws + lo.scratch;
     if (gd) {  // two products (different inputs), left without bias in pre_enc0 = a single "slab"
       TRY(k.enc_fwd(H, ws + lo.xn_z, AM_XNZ, p->enc_w0, ws + lo.pre_enc0, HE, nullptr, nullptr));
-      TRY(k.enc_fwd(Hl, ws + lo.xn, AM_XN, p->enc_w0 + H * G, ws + lo.pre_enc0 + H, HE, nullptr, nullptr));
+      TRY(k.enc_fwd(Hl, ws + lo.xn, AM_XN, p->enc_w0 + H * k.ldw(), ws + lo.pre_enc0 + H, HE, nullptr, nullptr));
       slabs = ws + lo.pre_enc0;
       nslab = 1;
     } else {
@@ -303,10 +317,12 @@ extern "C" int vae_elbo_step_forward(const vae_step_config* cfg, const vae_step_
   } else {
     if (gd) {
       TRY(k.enc_fwd(H, ws + lo.xn_z, AM_XNZ, p->enc_w0, ws + lo.pre_enc0, HE, p->enc_b0, nullptr));
-      TRY(k.enc_fwd(Hl, ws + lo.xn, AM_XN, p->enc_w0 + H * G, ws + lo.pre_enc0 + H, HE, p->enc_b0 + H, nullptr));
+      TRY(k.enc_fwd(Hl, ws + lo.xn, AM_XN, p->enc_w0 + H * k.ldw(), ws + lo.pre_enc0 + H, HE, p->enc_b0 + H, nullptr));
     } else {
       TRY(k.enc_fwd(HE, ws + lo.xn, AM_XN, p->enc_w0, ws + lo.pre_enc0, HE, p->enc_b0, nullptr));
     }
+    if (k.cov())   // + cov W_c^T: the covariate columns of both encoders' first layer (modules.py:130)
+      TRY(k.gemm(VAE_NT, B, HE, c.n_cov, c.batch_cov, c.ld_cov, p->enc_w0 + G, k.ldw(), ws + lo.pre_enc0, HE, nullptr, nullptr, 1));
     TRY(vae_gelu_ln_fwd(ws + lo.pre_enc0, HE, p->encz_ln_g[0], p->encz_ln_b[0], B, H, ws + lo.h_enc0, HE,
                         ws + lo.ln_mz[0], ws + lo.ln_rz[0], stream));
     TRY(vae_gelu_ln_fwd(ws + lo.pre_enc0 + H, HE, p->encl_ln_g, p->encl_ln_b, B, Hl, ws + lo.h_enc0 + H, HE,
@@ -332,7 +348,10 @@ extern "C" int vae_elbo_step_forward(const vae_step_config* cfg, const vae_step_
     px = ws + lo.z;
     int64_t kin = L;
     for (int n = 0; n < c.n_layers; ++n) {
-      TRY(k.gemm(VAE_NT, B, Hd, kin, px, kin, p->dec_w[n], kin, ws + lo.dec_pre[n], Hd, p->dec_b[n], nullptr, 0));
+      const int64_t ldwd = n == 0 ? ld_dec_w0(c) : Hd;
+      TRY(k.gemm(VAE_NT, B, Hd, kin, px, kin, p->dec_w[n], ldwd, ws + lo.dec_pre[n], Hd, p->dec_b[n], nullptr, 0));
+      if (n == 0 && k.cov())   // the decoder's covariate columns (modules.py:400,130)
+        TRY(k.gemm(VAE_NT, B, Hd, c.n_cov, c.batch_cov, c.ld_cov, p->dec_w[0] + L, ldwd, ws + lo.dec_pre[0], Hd, nullptr, nullptr, 1));
       TRY(vae_gelu_ln_fwd(ws + lo.dec_pre[n], Hd, p->dec_ln_g[n], p->dec_ln_b[n], B, Hd, ws + lo.dec_h[n], Hd,
                           ws + lo.ln_md[n], ws + lo.ln_rd[n], stream));
       TRY(k.drop(ws + lo.dec_h[n], Hd, Hd, VAE_SITE_DEC(n)));
@@ -475,14 +494,17 @@ extern "C" int vae_elbo_step_backward_events(const vae_step_config* cfg, const v
       TRY(k.drop(dcur, Hd, Hd, VAE_SITE_DEC(n)));
       TRY(vae_gelu_ln_bwd(dcur, Hd, ws + lo.dec_pre[n], Hd, ws + lo.ln_md[n], ws + lo.ln_rd[n], p->dec_ln_g[n], B, Hd, dcur,
                           Hd, g->dec_ln_g[n], g->dec_ln_b[n], g->dec_b[n], stream));
-      TRY(k.gemm(VAE_TN, Hd, kin, B, dcur, Hd, inp, kin, g->dec_w[n], kin, nullptr, nullptr, 0));
+      const int64_t ldwd = n == 0 ? ld_dec_w0(c) : Hd;
+      TRY(k.gemm(VAE_TN, Hd, kin, B, dcur, Hd, inp, kin, g->dec_w[n], ldwd, nullptr, nullptr, 0));
+      if (n == 0 && k.cov())   // gradient of the covariate columns: dpre^T cov
+        TRY(k.gemm(VAE_TN, Hd, c.n_cov, B, dcur, Hd, c.batch_cov, c.ld_cov, g->dec_w[0] + L, ldwd, nullptr, nullptr, 0));
       if (n > 0) {
         // dgrad into the scratch-free buffer of the layer below: reuse dec_pre[n] (no longer needed)
         float* nxt = ws + lo.dec_pre[n];
         TRY(k.gemm(VAE_NN, B, Hd, Hd, dcur, Hd, p->dec_w[n], Hd, nxt, Hd, nullptr, nullptr, 0));
         dcur = nxt;
       } else {
-        TRY(k.gemm(VAE_NN, B, L, Hd, dcur, Hd, p->dec_w[0], L, ws + lo.dz, L, nullptr, nullptr, 0));
+        TRY(k.gemm(VAE_NN, B, L, Hd, dcur, Hd, p->dec_w[0], ldwd, ws + lo.dz, L, nullptr, nullptr, 0));
       }
     }
     // reparameterisation / KL backward (cell-head gradient enters through dz_extra)
@@ -527,10 +549,13 @@ extern "C" int vae_elbo_step_backward_events(const vae_step_config* cfg, const v
     if (hipEventRecord((hipEvent_t)event_small_ready, (hipStream_t)stream) != hipSuccess)
       return vae_set_error(VAE_ERR_LAUNCH, "vae_elbo_step_backward: hipEventRecord failed");
   }
+  if (k.cov())   // covariate columns of both encoders' first-layer weight gradient: dpre^T cov (small; before the release point
+                 // it would delay -- the whole enc_w0 slice travels last anyway)
+    TRY(k.gemm(VAE_TN, HE, c.n_cov, B, ws + lo.dpre_enc0, HE, c.batch_cov, c.ld_cov, g->enc_w0 + G, k.ldw(), nullptr, nullptr, 0));
   if (k.hb()) TRY(vae_cast_bf16(ws + lo.dpre_enc0, k.h16(lo.dpre16), B * HE, nullptr, nullptr, 0, stream));
   if (c.input_dropout_rate > 0.f) {  // GeneDropout: each encoder's weight gradient over its own input
     TRY(k.enc_wgrad(H, ws + lo.dpre_enc0, HE, ws + lo.xn_z, AM_XNZ, g->enc_w0));
-    TRY(k.enc_wgrad(Hl, ws + lo.dpre_enc0 + H, HE, ws + lo.xn, AM_XN, g->enc_w0 + H * G));
+    TRY(k.enc_wgrad(Hl, ws + lo.dpre_enc0 + H, HE, ws + lo.xn, AM_XN, g->enc_w0 + H * k.ldw()));
   } else {
     TRY(k.enc_wgrad(HE, ws + lo.dpre_enc0, HE, ws + lo.xn, AM_XN, g->enc_w0));
   }

@@ -56,9 +56,7 @@ class FusedAdamW:
         for name, (off, shape) in arena.offsets.items():
             if name in skipped:
                 continue
-            n = 1
-            for s in shape:
-                n *= s
+            n = arena.extent(name)
             wd = float(decay_of(name, weight_decay))
             if ranges and ranges[-1][1] == off and ranges[-1][2] == wd:
                 ranges[-1] = (ranges[-1][0], off + n, wd)
@@ -68,10 +66,8 @@ class FusedAdamW:
         # but only when the gap really is padding: a skipped / gradient-less parameter of <= 3 elements sitting there
         # must stay untouched, as torch leaves grad=None parameters alone
         def is_padding(lo: int, hi: int) -> bool:
-            for off, shape in arena.offsets.values():
-                n = 1
-                for d in shape:
-                    n *= d
+            for name, (off, shape) in arena.offsets.items():
+                n = arena.extent(name)
                 if off < hi and off + n > lo:
                     return False
             return True
@@ -91,7 +87,7 @@ class FusedAdamW:
             from .arena import _enc
             def span(first, last):
                 b = arena.offsets[first][0]
-                e = arena.offsets[last][0] + arena.p(last).numel()
+                e = arena.offsets[last][0] + arena.extent(last)
                 return b, e
             enc = span(_enc("z_encoder", 0, "w"), _enc("l_encoder", 0, "w"))
             heads = span("decoder.px_scale_decoder.0.weight",
@@ -159,9 +155,7 @@ class L1Penalty:
         for name, (off, shape) in arena.offsets.items():
             if name in arena.no_grad or not selects(name):
                 continue
-            n = 1
-            for d in shape:
-                n *= d
+            n = arena.extent(name)
             if ranges and ranges[-1][1] == off:
                 ranges[-1] = (ranges[-1][0], off + n)
             else:

@@ -115,6 +115,7 @@ class ElboStep:
         self.G = a.p("px_r").shape[0]
         self.L = a.p("z_encoder.mean_encoder.weight").shape[0]
         self.Hd = a.p(_dec(0, "w")).shape[0]
+        self.n_cov = int(getattr(a, "n_cov", 0))     # one-hot batch-covariate columns (modules.py:102-107); 0 = none
         if self.n_layers > _lib.VAE_MAX_LAYERS:
             raise ValueError(f"ElboStep: at most {_lib.VAE_MAX_LAYERS} layers")
         if self.input_dropout_rate > 0:
@@ -156,6 +157,8 @@ class ElboStep:
             cfg = _lib.StepConfig(B=B, G=self.G, H=self.H, Hl=self.Hl, L=self.L, Hd=self.Hd, n_layers=self.n_layers,
                                   zinb=int(self.zinb), precision=self.precision, l_mean=self.l_mean, l_var=self.l_var,
                                   kl_weight=self.kl_weight, gene_loss_coeff=self.coeff, loss_scale=1.0)
+            if self.n_cov:
+                cfg.n_cov, cfg.ld_cov, cfg.ld_enc_w = self.n_cov, self.n_cov, self.a.ld_enc_w
             if gene_drop:
                 cfg.input_dropout_rate = self.input_dropout_rate
                 cfg.input_dropout_alpha = self.input_dropout_alpha
@@ -200,16 +203,33 @@ class ElboStep:
         return cfg, ws, nbytes, v
 
     # ------------------------------------------------------------------------------------
+    @staticmethod
+    def covariates(batch_labels: torch.Tensor, batch_mask: torch.Tensor, sizes) -> torch.Tensor:
+        """The block FCLayers.forward appends to its input (modules.py:123-130): ``one_hot(label_p) * mask_p`` for every
+        batch property p, (B, sum(sizes)) float32.  Negative labels are clamped to 0 IN PLACE, as the reference does."""
+        batch_labels[batch_labels < 0] = 0
+        cols = [torch.nn.functional.one_hot(batch_labels[:, n].long(), num_classes=int(k)) * batch_mask[:, n:n + 1]
+                for n, k in enumerate(sizes)]
+        return torch.cat(cols, dim=-1).to(torch.float32).contiguous()
+
     def run(self, x: torch.Tensor, eps_z: torch.Tensor, eps_l: torch.Tensor,
             cell_head_fn: Optional[Callable[[torch.Tensor], torch.Tensor]] = None,
             backward: bool = True, loss_scale: float = 1.0, reducer=None, train: Optional[bool] = None,
-            rng_step: Optional[int] = None) -> Dict[str, torch.Tensor]:
+            rng_step: Optional[int] = None, batch_cov: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
         """One step.  The returned tensors are VIEWS of the step workspace: they are overwritten by
         the next ``run`` with the same batch size (clone what must survive).
 
         ``train`` (default: ``backward``) switches the dropout masks on; ``rng_step`` picks the mask set
-        (default: a counter that advances with every training-mode run)."""
+        (default: a counter that advances with every training-mode run).
+
+        ``batch_cov`` (B, n_cov): the masked one-hot batch covariates (``ElboStep.covariates``) of a model built with
+        ``batch_properties``; required exactly then."""
         a = self.a
+        if (batch_cov is not None) != (self.n_cov > 0):
+            raise ValueError(f"ElboStep: the model has {self.n_cov} batch-covariate columns; batch_cov must be given exactly then")
+        if batch_cov is not None and (not batch_cov.is_cuda or batch_cov.dtype != torch.float32 or not batch_cov.is_contiguous()
+                                      or tuple(batch_cov.shape) != (x.shape[0], self.n_cov)):
+            raise ValueError(f"ElboStep: batch_cov must be a contiguous float32 GPU tensor of shape {(x.shape[0], self.n_cov)}")
         for t, name in ((x, "x"), (eps_z, "eps_z"), (eps_l, "eps_l")):
             ok_dtype = t.dtype == torch.float32 or (name == "x" and t.dtype == torch.uint8)
             if not t.is_cuda or not ok_dtype or t.dim() != 2 or t.stride(1) != 1:
@@ -223,6 +243,7 @@ class ElboStep:
         train = backward if train is None else bool(train)
         cfg, ws, nbytes, v = self._plan(B, loss_scale, train)
         cfg.x_dtype = 1 if x.dtype == torch.uint8 else 0   # uint8 counts: the reference's on-disk format (f2)
+        cfg.batch_cov = batch_cov.data_ptr() if batch_cov is not None else None
         cfg.dropout_rate = self.dropout_rate if train else 0.0
         cfg.rng_seed = self.seed
         if rng_step is None:
@@ -302,10 +323,11 @@ class ElboStep:
         return out
 
     def infer(self, x: torch.Tensor, eps_z: torch.Tensor, eps_l: torch.Tensor, *, want_px_rate: bool = False,
-              cell_head_fn: Optional[Callable[[torch.Tensor], torch.Tensor]] = None) -> Dict[str, torch.Tensor]:
+              cell_head_fn: Optional[Callable[[torch.Tensor], torch.Tensor]] = None,
+              batch_cov: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
         """Validation / inference pass (LitVAE.validation_step, task.py:235-282): the forward alone, no
         gradient is touched; ``px_rate`` (B, G) on request."""
-        out = self.run(x, eps_z, eps_l, cell_head_fn=cell_head_fn, backward=False)
+        out = self.run(x, eps_z, eps_l, cell_head_fn=cell_head_fn, backward=False, batch_cov=batch_cov)
         if want_px_rate:
             out["px_rate"] = self.px_rate()
         return out

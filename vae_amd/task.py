@@ -271,7 +271,10 @@ class LitVAE(nn.Module):
             eps_l = torch.empty(B, 1, device=gene_vals.device).normal_()
         self._fused_val.use_weight_maxima(self.weight_maxima_source)
         self._fused_val.kl_weight = self.kl_weight      # KL warm-up: a field of the step's config, not a new step
-        out = self._fused_val.infer(gene_vals, eps_z, eps_l, want_px_rate=self.save_gene_vals)
+        cov = None
+        if self.batch_properties:
+            cov = ElboStep.covariates(batch[3], batch[4], self.network.z_encoder.encoder.batch_dims)
+        out = self._fused_val.infer(gene_vals, eps_z, eps_l, want_px_rate=self.save_gene_vals, batch_cov=cov)
         self.log("recon_loss_val", out["recon_mean"])
         self.log("kl_z_val", out["scalars"][1])
         self._record_validation(batch, out["qz_m"], out.get("px_rate"))
@@ -295,8 +298,8 @@ class LitVAE(nn.Module):
         views), so the fused step, the module-API path, the optimiser and the gradient
         all-reduce share one storage."""
         net = self.network
-        if net.dispersion != "gene" or net.grouped_encoder or self.batch_properties:
-            raise NotImplementedError("fused step: dispersion 'gene', single encoder, no batch covariates")
+        if net.dispersion != "gene" or net.grouped_encoder:
+            raise NotImplementedError("fused step: dispersion 'gene', single encoder")
         sd = {k: v for k, v in net.named_parameters()}
         arena = ParamArena(sd, net.n_layers, self.reconstruction_loss, device)
         net.to(device)
@@ -362,7 +365,10 @@ class LitVAE(nn.Module):
             if reducer is not None and reducer.world > 1:
                 raise NotImplementedError("fused step: l1_lambda with a gradient reducer (add the penalty after finish())")
         self._fused.kl_weight = self.kl_weight          # KL warm-up (task.py:213-220): a field of the step's config
-        out = self._fused.run(gene_vals, eps_z, eps_l, cell_head_fn=fn, loss_scale=loss_scale, reducer=reducer)
+        cov = None
+        if self.batch_properties:   # modules.py:121-130: the masked one-hot block every FCLayers appends to its input
+            cov = ElboStep.covariates(batch[3], batch[4], self.network.z_encoder.encoder.batch_dims)
+        out = self._fused.run(gene_vals, eps_z, eps_l, cell_head_fn=fn, loss_scale=loss_scale, reducer=reducer, batch_cov=cov)
         if self.l1_lambda > 0:
             l1 = self._l1.apply(self.l1_lambda * loss_scale)
             out["l1"] = l1

@@ -122,12 +122,10 @@ def _main_datamodule(dm, model_cfg, task_cfg, trainer_cfg, max_steps, log_every,
     use_heads = bool(dm.cell_properties)
     cell_properties = dm.cell_properties if use_heads else {"_": {"discrete": True, "values": [0, 1], "stop_grad": True}}
     mcfg["grad_reverse_dict"] = {k: v for k, v in mcfg.get("grad_reverse_dict", {}).items() if k in cell_properties}
-    if dm.batch_properties is not None:
-        raise NotImplementedError("vae_amd.train.main: batch covariates run on the module path only (INTEGRATION.md)")
-    network = VAE(n_input=ds.n_genes, cell_properties=cell_properties, batch_properties=None, **mcfg)
+    network = VAE(n_input=ds.n_genes, cell_properties=cell_properties, batch_properties=dm.batch_properties, **mcfg)
     precision = ops.BF16 if str(rcfg["precision"]).startswith("bf16") else ops.F16X2
     task = LitVAE(network, cell_properties=cell_properties if use_heads else None, library_mean=lib_mean,
-                  library_var=lib_var, precision=precision,
+                  library_var=lib_var, precision=precision, batch_properties=dm.batch_properties,
                   **{k: v for k, v in tcfg.items() if k not in ("batch_properties",)})
     task.train()
     if dist.is_initialized():
