@@ -545,9 +545,17 @@ __global__ __launch_bounds__(256) void softmax_stats_kernel(const LT* __restrict
 
 // rowmax / rowsum from the per-slot statistics the decoder-head GEMM's epilogue wrote: one WAVE per row, its lanes
 // across the slots (every load in flight at once), shuffles for the two reductions; fixed order -> deterministic
+// Workgroups past the (B + 3) / 4 merging ones build the gene table (px_r != null): two short, independent jobs that
+// would otherwise cost a launch each (both are needed by the likelihood pass that follows).
 __global__ __launch_bounds__(256) void softmax_stats_merge_kernel(const float* __restrict__ sm, const float* __restrict__ ss,
                                                                   int slots, int B, float* __restrict__ rowmax,
-                                                                  float* __restrict__ rowsum) {
+                                                                  float* __restrict__ rowsum, const float* __restrict__ px_r,
+                                                                  int G, float* __restrict__ T) {
+  const int merge_blocks = (B + 3) / 4;
+  if ((int)blockIdx.x >= merge_blocks) {
+    gene_table_entry(px_r, G, T, ((int)blockIdx.x - merge_blocks) * 256 + threadIdx.x);
+    return;
+  }
   const int lane = threadIdx.x & 63;
   const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (b >= B) return;
@@ -1214,10 +1222,12 @@ extern "C" int vae_nbzinb_bwd_bf16(int zinb, const uint16_t* logit_scale, int64_
 }
 
 int vae_softmax_stats_merge(const float* stat_m, const float* stat_s, int slots, int64_t B, float* rowmax, float* rowsum,
-                            void* stream) {
+                            const float* px_r, int64_t G, float* table, void* stream) {
   VAE_REQUIRE(stat_m && stat_s && slots > 0 && B > 0 && rowmax && rowsum, "vae_softmax_stats_merge: bad arguments");
-  hipLaunchKernelGGL(softmax_stats_merge_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, (hipStream_t)stream, stat_m,
-                     stat_s, slots, (int)B, rowmax, rowsum);
+  VAE_REQUIRE(!px_r || (table && G > 0), "vae_softmax_stats_merge: the gene table needs px_r, G and the table");
+  const unsigned extra = px_r ? (unsigned)((G + 255) / 256) : 0u;
+  hipLaunchKernelGGL(softmax_stats_merge_kernel, dim3((unsigned)((B + 3) / 4) + extra), dim3(256), 0, (hipStream_t)stream, stat_m,
+                     stat_s, slots, (int)B, rowmax, rowsum, px_r, (int)G, table);
   VAE_CHECK_LAUNCH("vae_softmax_stats_merge");
   return VAE_OK;
 }

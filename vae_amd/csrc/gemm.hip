@@ -809,9 +809,23 @@ __device__ __forceinline__ void x3_epilogue(const GemmArgs& g, f32x16 (&acc)[BM 
 // by 8-byte loads straight into the operand plane -- no conversion, half the bytes), bit 2: C is written as bf16 (rounded
 // to nearest even; the softmax statistics are then taken from the ROUNDED values, the ones the consumer will read).
 // Leading dimensions count elements of the respective type.
+// PIPE (NP <= 2): software-pipelined K loop.  The workgroups resident on a CU run the same code from the same start and
+// stay in phase: all of them convert (VALU) at the same time, then all of them multiply (matrix cores) at the same
+// time, so the two never overlap (tools/micro/gemm_probe.hip: the phases ADD).  Here the overlap is built into each
+// wave: two LDS stages and two sets of staging registers; while the MFMAs of K step i run from stage i & 1, the same
+// wave converts step i + 1 (loaded one iteration earlier) into the other stage between them, and the loads of step
+// i + 2 are in flight -- one barrier per K step instead of two, a whole iteration of slack for the global loads.
+#ifndef VAE_X3_PIPE
+#define VAE_X3_PIPE 1
+#endif
+#ifndef VAE_X3_SCHEDB
+#define VAE_X3_SCHEDB 0
+#endif
 template <int LAYOUT, int BM, int BN, int WAVES_M, int NP, int IO = 0>
-__global__ __launch_bounds__(256, (NP <= 2 ? 3 : 2)) void gemm_x3_kernel(GemmArgs g) {
+__global__ __launch_bounds__(256, ((VAE_X3_PIPE && NP <= 2 && BM == 128 && BN == 128) ? 2 : (NP <= 2 ? 3 : 2))) void gemm_x3_kernel(GemmArgs g) {
   static_assert(IO == 0 || NP == 1, "bf16 storage goes with the one-plane bf16 product");
+  constexpr bool PIPE = VAE_X3_PIPE && NP <= 2 && BM == 128 && BN == 128;   // the 160-wide tiles do not fit two waves per SIMD
+  constexpr int STAGES = PIPE ? 2 : 1;
   constexpr bool ABF = (IO & 1) != 0, BBF = (IO & 2) != 0, CBF = (IO & 4) != 0;
   using TA = std::conditional_t<ABF, uint16_t, float>;
   using TB = std::conditional_t<BBF, uint16_t, float>;
@@ -825,7 +839,8 @@ __global__ __launch_bounds__(256, (NP <= 2 ? 3 : 2)) void gemm_x3_kernel(GemmArg
   constexpr int LDK = 40, LDR = 160;                        // bf16 row strides of the two images
   constexpr int PLA = A_KC ? BM * LDK : 32 * LDR;           // bf16 per plane
   constexpr int PLB = B_KC ? BN * LDK : 32 * LDR;
-  __shared__ __attribute__((aligned(16))) __bf16 smem[NP * (PLA + PLB)];
+  constexpr int STG = NP * (PLA + PLB);                     // bf16 per LDS stage
+  __shared__ __attribute__((aligned(16))) __bf16 smem[STAGES * STG];
   __bf16* sA = smem;
   __bf16* sB = smem + NP * PLA;
 
@@ -858,21 +873,23 @@ __global__ __launch_bounds__(256, (NP <= 2 ? 3 : 2)) void gemm_x3_kernel(GemmArg
   const int l31 = lane & 31, h = lane >> 5;
 
   // ---- global -> register staging: unconditional 16-byte (bf16 storage: 8-byte) loads from clamped addresses ----
-  const TA* gA = reinterpret_cast<const TA*>(g.A);
-  const TB* gB = reinterpret_cast<const TB*>(g.B);
-  const TA* pa[NA];
-  const TB* pb[NB];
+  // addresses = a workgroup-uniform base (the tile's origin at this K step: scalar registers, advanced per step) + a
+  // per-lane 32-bit byte offset that stays the same for every step (row inside the tile x leading dimension: < 2^32 for
+  // any leading dimension below 6 M elements) -- one register per load instead of a 64-bit pointer
+  const char* bA = reinterpret_cast<const char*>(reinterpret_cast<const TA*>(g.A) + (A_KC ? (int64_t)m0 * g.lda + kbeg : (int64_t)kbeg * g.lda));
+  const char* bB = reinterpret_cast<const char*>(reinterpret_cast<const TB*>(g.B) + (B_KC ? (int64_t)n0 * g.ldb + kbeg : (int64_t)kbeg * g.ldb));
+  uint32_t oa[NA], ob[NB];
   int wa[NA], wb[NB];  // LDS element offsets inside a plane
 #pragma unroll
   for (int i = 0; i < NA; ++i) {
     const int c = tid + 256 * i;
     if (A_KC) {
       const int row = c >> 3, k4 = c & 7;
-      pa[i] = gA + (int64_t)min(m0 + row, g.M - 1) * g.lda + kbeg + 4 * k4;
+      oa[i] = (uint32_t)(((int64_t)min(row, g.M - 1 - m0) * g.lda + 4 * k4) * (int64_t)sizeof(TA));
       wa[i] = row * LDK + 4 * k4;
     } else {
       const int k = c / (BM / 4), r4 = c % (BM / 4);
-      pa[i] = gA + (int64_t)(kbeg + k) * g.lda + min(m0 + 4 * r4, g.M - 4);
+      oa[i] = (uint32_t)(((int64_t)k * g.lda + min(m0 + 4 * r4, g.M - 4)) * (int64_t)sizeof(TA));
       wa[i] = k * LDR + 4 * r4;
     }
   }
@@ -881,26 +898,32 @@ __global__ __launch_bounds__(256, (NP <= 2 ? 3 : 2)) void gemm_x3_kernel(GemmArg
     const int c = tid + 256 * i;
     if (B_KC) {
       const int row = c >> 3, k4 = c & 7;
-      pb[i] = gB + (int64_t)min(n0 + row, g.N - 1) * g.ldb + kbeg + 4 * k4;
+      ob[i] = (uint32_t)(((int64_t)min(row, g.N - 1 - n0) * g.ldb + 4 * k4) * (int64_t)sizeof(TB));
       wb[i] = row * LDK + 4 * k4;
     } else {
       const int k = c / (BN / 4), r4 = c % (BN / 4);
-      pb[i] = gB + (int64_t)(kbeg + k) * g.ldb + min(n0 + 4 * r4, g.N - 4);
+      ob[i] = (uint32_t)(((int64_t)k * g.ldb + min(n0 + 4 * r4, g.N - 4)) * (int64_t)sizeof(TB));
       wb[i] = k * LDR + 4 * r4;
     }
   }
-  const int64_t step_a = A_KC ? 32 : 32 * g.lda;
-  const int64_t step_b = B_KC ? 32 : 32 * g.ldb;
-  RA ra[NA];
+  const int64_t step_a = (A_KC ? 32 : 32 * g.lda) * (int64_t)sizeof(TA);   // bytes per K step
+  const int64_t step_b = (B_KC ? 32 : 32 * g.ldb) * (int64_t)sizeof(TB);
+  RA ra[NA];   // staging registers
   RB rb[NB];
-  auto fetch = [&]() {
+  auto load_to = [&](RA* ra, RB* rb) {
 #pragma unroll
-    for (int i = 0; i < NA; ++i) { ra[i] = *reinterpret_cast<const RA*>(pa[i]); pa[i] += step_a; }
+    for (int i = 0; i < NA; ++i) ra[i] = *reinterpret_cast<const RA*>(bA + oa[i]);
 #pragma unroll
-    for (int i = 0; i < NB; ++i) { rb[i] = *reinterpret_cast<const RB*>(pb[i]); pb[i] += step_b; }
+    for (int i = 0; i < NB; ++i) rb[i] = *reinterpret_cast<const RB*>(bB + ob[i]);
   };
+  auto fetch_to = [&](RA* ra, RB* rb) {
+    load_to(ra, rb);
+    bA += step_a;
+    bB += step_b;
+  };
+  auto fetch = [&]() { fetch_to(ra, rb); };
   // last, partial K step (K % 32 != 0, K % 4 == 0): chunks past kend read a safe address and count as zeros
-  auto fetch_tail = [&](int tail) {
+  auto fetch_tail_to = [&](int tail, RA* ra, RB* rb) {
     RA ZA;
     RB ZB;
     memset(&ZA, 0, sizeof(ZA));
@@ -909,15 +932,16 @@ __global__ __launch_bounds__(256, (NP <= 2 ? 3 : 2)) void gemm_x3_kernel(GemmArg
     for (int i = 0; i < NA; ++i) {
       const int c = tid + 256 * i;
       const int kk = A_KC ? 4 * (c & 7) : c / (BM / 4);
-      ra[i] = kk < tail ? *reinterpret_cast<const RA*>(pa[i]) : ZA;
+      ra[i] = kk < tail ? *reinterpret_cast<const RA*>(bA + oa[i]) : ZA;
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
       const int c = tid + 256 * i;
       const int kk = B_KC ? 4 * (c & 7) : c / (BN / 4);
-      rb[i] = kk < tail ? *reinterpret_cast<const RB*>(pb[i]) : ZB;
+      rb[i] = kk < tail ? *reinterpret_cast<const RB*>(bB + ob[i]) : ZB;
     }
   };
+  auto fetch_tail = [&](int tail) { fetch_tail_to(tail, ra, rb); };
   float scA = 1.f, scB = 1.f;   // NP == 2: operand scales
   // Maximum of n partial maxima (16-byte aligned array): 16-byte loads, four in flight per lane
   auto partial_max = [&](const float* __restrict__ p, int n) {
@@ -938,7 +962,10 @@ __global__ __launch_bounds__(256, (NP <= 2 ? 3 : 2)) void gemm_x3_kernel(GemmArg
   auto scales = [&]() {
     if (NP != 2) return;
     if (g.na > 0 || g.nb > 0) {  // reduce the producers' partial maxima (a few KB, L2-resident)
-      __shared__ float red_s[8];
+      // 8 floats: own storage, or (PIPE: two stages of exactly 40 KB = two workgroups per CU, not a byte to spare) the start
+      // of LDS stage 1, which nothing writes before the barrier that follows the first conversion
+      __shared__ float red_own[PIPE ? 1 : 8];
+      float* red_s = PIPE ? reinterpret_cast<float*>(smem + STG) : red_own;
       float ma = partial_max(g.sa, g.na), mb = partial_max(g.sb, g.nb);
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) {
@@ -1033,19 +1060,21 @@ __global__ __launch_bounds__(256, (NP <= 2 ? 3 : 2)) void gemm_x3_kernel(GemmArg
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  auto multiply = [&]() {
+  // `between(group)` runs after the MFMAs of each of the 2 * TNN (ks, tj) groups: the pipelined loop converts the next
+  // K step there, in the shadow of the matrix cores
+  auto multiply_from = [&](const __bf16* sAst, const __bf16* sBst, auto&& between) {
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       bf16x8 a[TM][NP];
 #pragma unroll
       for (int ti = 0; ti < TM; ++ti)
 #pragma unroll
-        for (int q = 0; q < NP; ++q) a[ti][q] = frag(sA + q * PLA, A_KC, fa, ti, ks);
+        for (int q = 0; q < NP; ++q) a[ti][q] = frag(sAst + q * PLA, A_KC, fa, ti, ks);
 #pragma unroll
       for (int tj = 0; tj < TNN; ++tj) {
         bf16x8 b[NP];
 #pragma unroll
-        for (int q = 0; q < NP; ++q) b[q] = frag(sB + q * PLB, B_KC, fb, tj, ks);
+        for (int q = 0; q < NP; ++q) b[q] = frag(sBst + q * PLB, B_KC, fb, tj, ks);
 #pragma unroll
         for (int ti = 0; ti < TM; ++ti) {
           f32x16 c = acc[ti][tj];  // smallest terms first
@@ -1070,13 +1099,66 @@ __global__ __launch_bounds__(256, (NP <= 2 ? 3 : 2)) void gemm_x3_kernel(GemmArg
           c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ti][0], b[0], c, 0, 0, 0);
           acc[ti][tj] = c;
         }
+        between(ks * TNN + tj);
       }
     }
   };
+  auto multiply = [&]() { multiply_from(sA, sB, [](int) {}); };
 
+  (void)stage; (void)multiply; (void)fetch; (void)fetch_tail;   // the unpipelined loop's helpers
   GSTAMP();
   const int nfull = kend > kbeg ? (kend - kbeg) / BK : 0;
   const int tail = kend > kbeg ? (kend - kbeg) % BK : 0;   // only the last slab of a K that is not a multiple of 32
+  if constexpr (PIPE) {
+    // the pipelined loop covers the FULL K steps; a partial last step (K % 32 != 0) runs unpipelined after it
+    int left = nfull;                                    // full steps not fetched yet
+    auto fetch_full = [&]() {                            // branch-free: past the end the last step is read again (unused)
+      load_to(ra, rb);
+      bA += left > 1 ? step_a : 0;
+      bB += left > 1 ? step_b : 0;
+      --left;
+    };
+    // Step i: the loads of step i + 1 are issued first and land during the first half of the MFMA groups; the second
+    // half alternates with their conversion into the other LDS stage (after the last step the registers hold a re-read
+    // of it, written to the stage nobody reads again).
+    constexpr int NGRP = 2 * TNN, G0 = NGRP / 2, NPUT = NA + NB;
+    auto put_one = [&](int pidx, __bf16* base) {
+      if (pidx < NA) put(base, PLA, wa[pidx], ra[pidx], scA);
+      else put(base + NP * PLA, PLB, wb[pidx - NA], rb[pidx - NA], scB);
+    };
+    auto step = [&](int cur) {
+      fetch_full();
+      __bf16* nxt = smem + (cur ^ 1) * STG;
+      multiply_from(smem + cur * STG, smem + cur * STG + NP * PLA, [&](int grp) {
+#pragma unroll
+        for (int pidx = 0; pidx < NPUT; ++pidx)
+          if (G0 + pidx * (NGRP - G0) / NPUT == grp) put_one(pidx, nxt);
+        if (VAE_X3_SCHEDB) __builtin_amdgcn_sched_barrier(0);   // keep a group's conversions in its own slot
+      });
+      __syncthreads();   // stage cur ^ 1 published; every wave is done reading stage cur
+    };
+    if (nfull > 0) {
+      fetch_full();
+      scales();
+#pragma unroll
+      for (int pidx = 0; pidx < NPUT; ++pidx) put_one(pidx, smem);
+      __syncthreads();
+      for (int i = 0; i < nfull; i += 2) {
+        step(0);
+        if (i + 1 < nfull) step(1);
+      }
+      if (tail) {   // the base pointers stopped at the last full step: move on to the partial one
+        bA += step_a;
+        bB += step_b;
+      }
+    } else scales();
+    if (tail) {
+      fetch_tail(tail);
+      stage();
+      multiply();
+      __syncthreads();
+    }
+  } else {
   if (nfull > 0) fetch();
   else if (tail) fetch_tail(tail);
   scales();
@@ -1095,6 +1177,7 @@ __global__ __launch_bounds__(256, (NP <= 2 ? 3 : 2)) void gemm_x3_kernel(GemmArg
   if (tail) {
     stage();
     multiply();
+  }
   }
   GSTAMP();
 

@@ -43,8 +43,9 @@ int vae_gemm_bf16io(int layout, int io, int64_t M, int64_t N, int64_t K, const v
 // bf16 images of up to two dense fp32 arrays (s1 nullable), one launch (gemm.hip)
 int vae_cast_bf16(const float* s0, void* d0, int64_t n0, const float* s1, void* d1, int64_t n1, void* stream);
 // rowmax[b] / rowsum[b] from the `slots` per-slot statistics a GEMM left (epilogue.hip)
+// px_r != null: extra workgroups of the same launch build the gene table (vae_gene_table) as well
 int vae_softmax_stats_merge(const float* stat_m, const float* stat_s, int slots, int64_t B, float* rowmax, float* rowsum,
-                            void* stream);
+                            const float* px_r, int64_t G, float* table, void* stream);
 
 // Entries of the partial-maxima arrays the producers below fill (all of them, every call)
 #define VAE_NORM_WAVES 4           /* vae_normalize_rows_ex / vae_gene_dropout_ex: B * 4 entries      */

@@ -361,7 +361,6 @@ __global__ __launch_bounds__(1024) void elbo_reduce_kernel(float* __restrict__ l
                                                            float coeff, float* __restrict__ out,
                                                            float* __restrict__ recon, const float* __restrict__ part,
                                                            int strips, float* __restrict__ S) {
-  __shared__ float red[16];
   if (part) {
     for (int j = threadIdx.x; j < 2 * B; j += 1024) {
       const int i = j >> 1, k = j & 1;
@@ -369,6 +368,13 @@ __global__ __launch_bounds__(1024) void elbo_reduce_kernel(float* __restrict__ l
       const int64_t st = (int64_t)2 * B;
       float v = 0.f;
       int s = 0;
+      for (; s + 8 <= strips; s += 8) {   // eight loads in flight, summed in strip order
+        float q[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) q[u] = p[(s + u) * st];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v += q[u];
+      }
       for (; s + 4 <= strips; s += 4) {
         const float a = p[s * st], b2 = p[(s + 1) * st], c2 = p[(s + 2) * st], d2 = p[(s + 3) * st];
         v = (((v + a) + b2) + c2) + d2;
@@ -386,10 +392,18 @@ __global__ __launch_bounds__(1024) void elbo_reduce_kernel(float* __restrict__ l
     c += kl_l[i];
     d += kl_l[i] + kl_z[i];
   }
-  a = block_sum<16>(a, red);
-  b = block_sum<16>(b, red);
-  c = block_sum<16>(c, red);
-  d = block_sum<16>(d, red);
+  // the four block sums share one pair of barriers (the per-wave order of additions is that of block_sum)
+  __shared__ float red4[4][16];
+  a = wave_sum(a); b = wave_sum(b); c = wave_sum(c); d = wave_sum(d);
+  if ((threadIdx.x & 63) == 0) {
+    const int w = threadIdx.x >> 6;
+    red4[0][w] = a; red4[1][w] = b; red4[2][w] = c; red4[3][w] = d;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    a = b = c = d = 0.f;
+    for (int w = 0; w < 16; ++w) { a += red4[0][w]; b += red4[1][w]; c += red4[2][w]; d += red4[3][w]; }
+  }
   if (threadIdx.x == 0) {
     const float n = (float)B;
     const float gl = a / n + kl_weight * (d / n);

@@ -279,13 +279,15 @@ extern "C" int vae_elbo_step_forward(const vae_step_config* cfg, const vae_step_
   const int64_t B = c.B, G = c.G, H = c.H, Hl = c.Hl, L = c.L, Hd = c.Hd, HE = c.H + c.Hl;
   const int64_t NH = c.zinb ? 2 * G : G;
 
-  if (k.fx() && k.wext()) {  // the caller keeps the weight maxima current: only the gene table is left to build
+  bool table_built = false;   // the gene table rides in another launch where one is at hand
+  if (k.fx() && k.wext()) {  // the caller keeps the weight maxima current: only the gene table is left to build (below)
     if (!vae_aligned16(c.weight_max_enc) || !vae_aligned16(c.weight_max_heads))
       return vae_set_error(VAE_ERR_ARG, "vae_elbo_step_forward: weight_max_* must be 16-byte aligned");
-    TRY(vae_gene_table(p->px_r, G, ws + lo.table, stream));
-  } else if (k.fx())  // weight maxima of the two-f16-term products and the gene table, one launch
+  } else if (k.fx()) {  // weight maxima of the two-f16-term products and the gene table, one launch
     TRY(vae_step_prologue(p->enc_w0, HE * k.ldw(), p->heads_w, NH * Hd, k.am(AM_WENC), k.am(AM_WHEADS), p->px_r, G, ws + lo.table,
                           stream));
+    table_built = true;
+  }
   if (k.hb())   // bf16 images of the two gene-sized weight matrices: every product of this step streams those
     TRY(vae_cast_bf16(p->enc_w0, k.h16(lo.w_enc16), HE * k.ldw(), p->heads_w, k.h16(lo.w_heads16), NH * Hd, stream));
   // encoders: x/mean-1 -> Linear(G, H+Hl) -> GELU -> LayerNorm (z and library halves)
@@ -374,8 +376,12 @@ extern "C" int vae_elbo_step_forward(const vae_step_config* cfg, const vae_step_
   else
     TRY(k.big(VAE_NT, B, NH, Hd, px, Hd, AM_PX, p->heads_w, Hd, AM_WHEADS, ws + lo.logits, NH, p->heads_b, nullptr,
               no_gemm_stats ? nullptr : &rs));
-  if (rs.slots > 0) TRY(vae_softmax_stats_merge(ws + lo.stat_m, ws + lo.stat_s, rs.slots, B, ws + lo.rowmax, ws + lo.rowsum, stream));
-  if (!k.fx()) TRY(vae_gene_table(p->px_r, G, ws + lo.table, stream));
+  if (rs.slots > 0) {   // ... and, in extra workgroups of the same launch, the gene table when it is still to build
+    TRY(vae_softmax_stats_merge(ws + lo.stat_m, ws + lo.stat_s, rs.slots, B, ws + lo.rowmax, ws + lo.rowsum,
+                                table_built ? nullptr : p->px_r, G, ws + lo.table, stream));
+    table_built = true;
+  }
+  if (!table_built) TRY(vae_gene_table(p->px_r, G, ws + lo.table, stream));
   // streaming likelihood pass: row statistics, then (gene strip x cell chunk) tiles; its per-strip partial sums are added
   // up by the ELBO reduction
   int strips = 0;
