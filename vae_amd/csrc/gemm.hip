@@ -1092,8 +1092,8 @@ __global__ __launch_bounds__(256, ((VAE_X3_PIPE && NP <= 2 && BM == 128 && BN ==
             continue;
           }
           c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ti][NP > 1 ? 1 : 0], b[NP > 1 ? 1 : 0], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ti][NP > 1 ? 2 : 0], b[0], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ti][0], b[NP > 1 ? 2 : 0], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ti][NP > 2 ? 2 : 0], b[0], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ti][0], b[NP > 2 ? 2 : 0], c, 0, 0, 0);
           c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ti][NP > 1 ? 1 : 0], b[0], c, 0, 0, 0);
           c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ti][0], b[NP > 1 ? 1 : 0], c, 0, 0, 0);
           c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ti][0], b[0], c, 0, 0, 0);
