@@ -47,6 +47,17 @@ int main(int argc, char** argv) {
   hipMemcpyFromSymbol(h, HIP_SYMBOL(g_probe), sizeof(h));
   // stamps: [0] start, then per K-step 4 (loop top, after sync1, after LDS writes, after sync2), then end of loop, end of kernel
   const int ksteps = g.k_per_split / 32;
+  if (getenv("PIPE_STAMPS")) {   // pipelined loop: [0] start, [1] before the loop, then per K step 3 (top, MFMAs + conversion issued, after the barrier)
+    for (int w = 0; w < 4; ++w) {
+      printf("wave %d: prologue %lld |", w, h[w][2] - h[w][0]);
+      for (int k = 0; k < (ksteps < 12 ? ksteps : 12); ++k) {
+        const long long* s = &h[w][2 + 3 * k];
+        printf(" [work %lld barrier %lld]", s[1] - s[0], s[2] - s[1]);
+      }
+      printf(" | loop %lld\n", h[w][2 + 3 * ksteps] - h[w][2]);
+    }
+    return 0;
+  }
   for (int w = 0; w < 4; ++w) {
     printf("wave %d: prologue %lld |", w, h[w][1] - h[w][0]);
     const int show = ksteps < 10 ? ksteps : 10;

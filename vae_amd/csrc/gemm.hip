@@ -1121,12 +1121,16 @@ __global__ __launch_bounds__(256, ((VAE_X3_PIPE && NP <= 2 && BM == 128 && BN ==
     // Step i: the loads of step i + 1 are issued first and land during the first half of the MFMA groups; the second
     // half alternates with their conversion into the other LDS stage (after the last step the registers hold a re-read
     // of it, written to the stage nobody reads again).
-    constexpr int NGRP = 2 * TNN, G0 = NGRP / 2, NPUT = NA + NB;
+    #ifndef VAE_X3_G0
+#define VAE_X3_G0 (NGRP / 2)
+#endif
+    constexpr int NGRP = 2 * TNN, G0 = VAE_X3_G0, NPUT = NA + NB;
     auto put_one = [&](int pidx, __bf16* base) {
       if (pidx < NA) put(base, PLA, wa[pidx], ra[pidx], scA);
       else put(base + NP * PLA, PLB, wb[pidx - NA], rb[pidx - NA], scB);
     };
     auto step = [&](int cur) {
+      GSTAMP();
       fetch_full();
       __bf16* nxt = smem + (cur ^ 1) * STG;
       multiply_from(smem + cur * STG, smem + cur * STG + NP * PLA, [&](int grp) {
@@ -1135,7 +1139,9 @@ __global__ __launch_bounds__(256, ((VAE_X3_PIPE && NP <= 2 && BM == 128 && BN ==
           if (G0 + pidx * (NGRP - G0) / NPUT == grp) put_one(pidx, nxt);
         if (VAE_X3_SCHEDB) __builtin_amdgcn_sched_barrier(0);   // keep a group's conversions in its own slot
       });
+      GSTAMP();
       __syncthreads();   // stage cur ^ 1 published; every wave is done reading stage cur
+      GSTAMP();
     };
     if (nfull > 0) {
       fetch_full();
