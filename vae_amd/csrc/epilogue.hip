@@ -637,8 +637,8 @@ __global__ __launch_bounds__(256) void nbzinb_fwd_tiled_kernel(
       sll += ((VEC || j < nv) ? f.ll.x : 0.f) + ((VEC || j + 1 < nv) ? f.ll.y : 0.f);   // VEC: all four genes valid, or none
       sa += ((VEC || j < nv) ? f.a.x : 0.f) + ((VEC || j + 1 < nv) ? f.a.y : 0.f);
     }
-    sll = wave_sum(nv > 0 ? sll : 0.f);
-    sa = wave_sum(nv > 0 ? sa : 0.f);
+    sll = wave_sum_dpp(nv > 0 ? sll : 0.f);   // DPP butterfly + four row totals: no LDS round trips in the cell loop
+    sa = wave_sum_dpp(nv > 0 ? sa : 0.f);
     if (lane == 0) red[b - b0][wave] = make_float2(sll, sa);
     c0 = c1;
     c1 = c2;

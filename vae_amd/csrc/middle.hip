@@ -85,34 +85,7 @@ __device__ __forceinline__ void slab_sum(const float* __restrict__ base, int nsl
   else slab_sum_ne<2>(base, nslab, stride, W, v);
 }
 
-// Wave-wide sum / max on the DPP path: quad butterfly, two rotations inside the 16-lane row, then the four row totals
-// through scalar registers -- ~12 short instructions, where __shfl_xor (ds_bpermute) costs an LDS round trip per step
-// (a 31-output head loop of shuffled reductions was 9 us of a cell's 28).  Every lane gets the result; fixed order.
-template <int CTRL>
-__device__ __forceinline__ float dpp_move(float v) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
-}
-__device__ __forceinline__ float row_total(float v) {   // lanes 0, 16, 32, 48 hold their row's value
-  const int i = __float_as_int(v);
-  return (__int_as_float(__builtin_amdgcn_readlane(i, 0)) + __int_as_float(__builtin_amdgcn_readlane(i, 16))) +
-         (__int_as_float(__builtin_amdgcn_readlane(i, 32)) + __int_as_float(__builtin_amdgcn_readlane(i, 48)));
-}
-__device__ __forceinline__ float wave_sum_dpp(float v) {
-  v += dpp_move<0xB1>(v);    // quad_perm [1, 0, 3, 2]
-  v += dpp_move<0x4E>(v);    // quad_perm [2, 3, 0, 1]
-  v += dpp_move<0x124>(v);   // row_ror:4
-  v += dpp_move<0x128>(v);   // row_ror:8
-  return row_total(v);
-}
-__device__ __forceinline__ float wave_max_dpp(float v) {
-  v = fmaxf(v, dpp_move<0xB1>(v));
-  v = fmaxf(v, dpp_move<0x4E>(v));
-  v = fmaxf(v, dpp_move<0x124>(v));
-  v = fmaxf(v, dpp_move<0x128>(v));
-  const int i = __float_as_int(v);
-  return fmaxf(fmaxf(__int_as_float(__builtin_amdgcn_readlane(i, 0)), __int_as_float(__builtin_amdgcn_readlane(i, 16))),
-               fmaxf(__int_as_float(__builtin_amdgcn_readlane(i, 32)), __int_as_float(__builtin_amdgcn_readlane(i, 48))));
-}
+// wave_sum_dpp / wave_max_dpp: common.h
 // Sums N values over the workgroup's NWV waves (wave order); red holds >= NWV*N floats.  Every thread gets all sums.
 template <int N>
 __device__ __forceinline__ void block_sums(float (&v)[N], float* red) {
