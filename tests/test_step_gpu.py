@@ -298,8 +298,11 @@ def test_midsize_against_oracle(likelihood, precision):
 @pytest.mark.parametrize("widths", [(256, 128, 256, 30), (192, 64, 320, 17), (512, 256, 576, 32), (128, 128, 128, 10)],
                          ids=["cfg2_widths", "ragged_lanes", "wide", "narrow"])
 @pytest.mark.parametrize("precision", [0, 3, 1], ids=["bf16x3", "f16x2", "bf16"])
-def test_wave_per_cell_middle_against_oracle(widths, precision):
-    """From 768 cells on, a 1-layer step runs the wave-per-cell middle kernels (middle.hip: one wave owns a cell, weights
+@pytest.mark.parametrize("split", [False, True], ids=["one_pass", "cell_chunks"])
+def test_wave_per_cell_middle_against_oracle(widths, precision, split, monkeypatch):
+    """cell_chunks: the small weight-gradient reductions cut into chunks of 512 cells + the combine launch, the form that
+    batches from 2048 cells on run (middle.hip, small_wgrad_kernel), forced here at B = 1024.
+    From 768 cells on, a 1-layer step runs the wave-per-cell middle kernels (middle.hip: one wave owns a cell, weights
     staged once per workgroup, DPP reductions); the workgroup-per-cell kernels serve smaller batches and are what the
     other step tests see.  B = 1024 with hidden dropout and a gradient arriving from cell heads (dz_extra), every
     instantiated (elements per lane) class, vs the oracle fed the host-regenerated masks."""
@@ -309,6 +312,8 @@ def test_wave_per_cell_middle_against_oracle(widths, precision):
     from helpers import dropout_multiplier
     H, Hl, Hd, L = widths
     B, G = 1024, 1600
+    if split:
+        monkeypatch.setenv("VAE_SMALL_WGRAD_SPLIT_MIN_B", "512")
     p_drop, seed, rng_step = 0.25, 424242, 3
     props = {"Dx": {"discrete": True, "values": [0, 1, 2], "stop_grad": False}}
     p = O.init_params(G, H, Hd, Hl, L, 1, seed=15, cell_properties=props)

@@ -1053,6 +1053,9 @@ int mid_wave_launch(K kern, const MidWavePlan& p, const A& a, hipStream_t st) {
 // A workgroup (1024 threads) owns 8 p x 64 q outputs of one task: 256 cells at a time are staged in LDS (all
 // the global loads of a round in flight together); thread (q = t%64, r = t/64) sums the cells
 // b = r (mod 16) in ascending order, the sixteen partial sums are combined r = 0..15: deterministic.
+// Large batches (nsplit > 1): the ~70 workgroups of the task table would each walk B / 256 rounds, one load latency
+// after the other (60 us at B = 4096).  The cells are then cut into nsplit chunks (grid.y), every chunk leaves its
+// partial outputs in `part` ([task][chunk][P][Q]), and small_wgrad_combine_kernel adds them in chunk order.
 // ---------------------------------------------------------------------------------------
 constexpr int MAX_TASKS = 16;
 constexpr int PT = 8;
@@ -1061,10 +1064,14 @@ struct WgradTask {
   const float* V; int ldV, Q;
   float* out; int sp, sq;
   int tile0;  // first workgroup of this task
+  int part0;  // offset of this task's partial outputs in WgradBatch::part (nsplit > 1)
 };
 struct WgradBatch {
   WgradTask task[MAX_TASKS];
   int ntask, B;
+  int nsplit, chunk;         // cells [y * chunk, (y + 1) * chunk) for grid row y
+  float* part;               // nsplit > 1: partial outputs; part_total floats = sum of P * Q over the tasks, per chunk
+  int part_total;
   int cr_tile0;              // workgroups from here on reduce the epilogue backward's column slabs (cr.slab != null)
   VaeDeferredColreduce cr;
 };
@@ -1077,6 +1084,7 @@ __global__ __launch_bounds__(TW) void small_wgrad_kernel(WgradBatch wb) {
   __shared__ float Us[RC][PT];            // U[b0+row][p0+i] (ones for a column sum)
   float (*comb)[PT][64] = reinterpret_cast<float (*)[PT][64]>(&Vs[0][0]);  // [NR][PT][64], reuses Vs after the last round
   if ((int)blockIdx.x >= wb.cr_tile0) {   // d px_r / d head biases: one column per thread, slabs summed in chunk order
+    if (blockIdx.y != 0) return;
     const int strips = (wb.cr.G + TW - 1) / TW;
     const int t = blockIdx.x - wb.cr_tile0, kk = t / strips, g = (t - kk * strips) * TW + threadIdx.x;
     if (g < wb.cr.G && wb.cr.out[kk]) vae_colreduce_column(wb.cr.slab, wb.cr.chunks, wb.cr.G, kk, g, wb.cr.out[kk], 1);
@@ -1096,10 +1104,11 @@ __global__ __launch_bounds__(TW) void small_wgrad_kernel(WgradBatch wb) {
 #pragma unroll
   for (int i = 0; i < PT; ++i) acc[i] = 0.f;
 
+  const int bbeg = min(wb.B, (int)blockIdx.y * wb.chunk), bend = min(wb.B, bbeg + wb.chunk);   // this grid row's cells
   constexpr int UJ = (RC * PT + TW - 1) / TW;
   float vreg[RC / NR], ureg[UJ];
   auto fetch = [&](int b0) {  // thread (l, r) loads column l of rows r, r+NR, ...: coalesced, all in flight
-    const int rows = min(RC, wb.B - b0);
+    const int rows = min(RC, bend - b0);
 #pragma unroll
     for (int j = 0; j < RC / NR; ++j) {
       const int row = r + NR * j;
@@ -1113,9 +1122,9 @@ __global__ __launch_bounds__(TW) void small_wgrad_kernel(WgradBatch wb) {
       ureg[j] = u;
     }
   };
-  fetch(0);
-  for (int b0 = 0; b0 < wb.B; b0 += RC) {
-    const int rows = min(RC, wb.B - b0);
+  fetch(bbeg);
+  for (int b0 = bbeg; b0 < bend; b0 += RC) {
+    const int rows = min(RC, bend - b0);
     __syncthreads();  // previous round's reads are done
 #pragma unroll
     for (int j = 0; j < RC / NR; ++j) Vs[r + NR * j][l] = vreg[j];
@@ -1125,7 +1134,7 @@ __global__ __launch_bounds__(TW) void small_wgrad_kernel(WgradBatch wb) {
       if (idx < RC * PT) Us[idx / PT][idx % PT] = ureg[j];
     }
     __syncthreads();
-    if (b0 + RC < wb.B) fetch(b0 + RC);  // next round's loads fly during this round's sums
+    if (b0 + RC < bend) fetch(b0 + RC);  // next round's loads fly during this round's sums
     // thread (l, r) accumulates rows r, r+NR, ... in ascending order
     for (int row = r; row < rows; row += NR) {
       const float v = Vs[row][l];
@@ -1145,8 +1154,22 @@ __global__ __launch_bounds__(TW) void small_wgrad_kernel(WgradBatch wb) {
     float v = comb[0][r][l];
 #pragma unroll
     for (int j = 1; j < NR; ++j) v += comb[j][r][l];
-    tk.out[(int64_t)(p0 + r) * tk.sp + (int64_t)(q0 + l) * tk.sq] = v;
+    if (wb.nsplit > 1) wb.part[(int64_t)blockIdx.y * wb.part_total + tk.part0 + (p0 + r) * tk.Q + q0 + l] = v;
+    else tk.out[(int64_t)(p0 + r) * tk.sp + (int64_t)(q0 + l) * tk.sq] = v;
   }
+}
+// out = sum over the chunks of the partial outputs, in chunk order: one thread per output element
+__global__ __launch_bounds__(256) void small_wgrad_combine_kernel(WgradBatch wb) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= wb.part_total) return;
+  int k = 0;
+#pragma unroll
+  for (int i = 1; i < MAX_TASKS; ++i) k += (i < wb.ntask && e >= wb.task[i].part0) ? 1 : 0;
+  const WgradTask tk = wb.task[k];
+  const int o = e - tk.part0, p = o / tk.Q, q = o - p * tk.Q;
+  float v = 0.f;
+  for (int s = 0; s < wb.nsplit; ++s) v += wb.part[(int64_t)s * wb.part_total + e];
+  tk.out[(int64_t)p * tk.sp + (int64_t)q * tk.sq] = v;
 }
 
 }  // namespace
@@ -1223,12 +1246,14 @@ int vae_mid_backward(const vae_step_config& c, const vae_step_tensors* p, const 
   // every small parameter gradient of the step, one launch
   const int B = (int)c.B, H = (int)c.H, Hl = (int)c.Hl, HE = H + Hl, L = (int)c.L, Hd = (int)c.Hd;
   WgradBatch wb;
-  int n = 0, tiles = 0;
+  int n = 0, tiles = 0, ptotal = 0;
   auto add = [&](const float* U, int ldU, int P, const float* V, int ldV, int Q, float* out, int sp, int sq) {
     WgradTask& k = wb.task[n++];
     k.U = U; k.ldU = ldU; k.P = P; k.V = V; k.ldV = ldV; k.Q = Q; k.out = out; k.sp = sp; k.sq = sq;
     k.tile0 = tiles;
+    k.part0 = ptotal;
     tiles += ((P + PT - 1) / PT) * ((Q + 63) / 64);
+    ptotal += P * Q;
   };
   add(z, L, L, dpre_d, Hd, Hd, g->dec_w[0], 1, L);              // dW_dec0[n][j] = sum_b dpre_d[b][n] z[b][j]
   add(dq_z, L + 1, L + 1, h_enc0, HE, H, g->hz_w, H, 1);         // dW_heads_z[j][k] = sum_b dq_z[b][j] h_z[b][k]
@@ -1251,7 +1276,19 @@ int vae_mid_backward(const vae_step_config& c, const vae_step_tensors* p, const 
     wb.cr = *cr;
     tiles += cr->nk * ((cr->G + TW - 1) / TW);
   }
-  hipLaunchKernelGGL(small_wgrad_kernel, dim3((unsigned)tiles), dim3(TW), 0, (hipStream_t)stream, wb);
+  // chunks of 512 cells from B = 2048 on; their partial outputs go where the dgrad slabs were (mid_bwd, enqueued above,
+  // was their last reader)
+  const int split_min_b = getenv("VAE_SMALL_WGRAD_SPLIT_MIN_B") ? atoi(getenv("VAE_SMALL_WGRAD_SPLIT_MIN_B")) : 2048;   // A/B knob
+  wb.nsplit = 1; wb.chunk = B; wb.part = nullptr; wb.part_total = ptotal;
+  if (B >= split_min_b && nslab > 0) {
+    const int ns = (B + 511) / 512;
+    if ((int64_t)ns * ptotal <= (int64_t)nslab * B * Hd) { wb.nsplit = ns; wb.chunk = 512; wb.part = const_cast<float*>(slabs); }
+  }
+  hipLaunchKernelGGL(small_wgrad_kernel, dim3((unsigned)tiles, (unsigned)wb.nsplit), dim3(TW), 0, (hipStream_t)stream, wb);
   VAE_CHECK_LAUNCH("vae_elbo_step_backward(small wgrad)");
+  if (wb.nsplit > 1) {
+    hipLaunchKernelGGL(small_wgrad_combine_kernel, dim3((unsigned)((ptotal + 255) / 256)), dim3(256), 0, (hipStream_t)stream, wb);
+    VAE_CHECK_LAUNCH("vae_elbo_step_backward(small wgrad combine)");
+  }
   return VAE_OK;
 }
