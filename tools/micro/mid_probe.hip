@@ -18,7 +18,7 @@ int main(int argc, char** argv) {
   float* eps_z = dmalloc(B * L); float* eps_l = dmalloc(B);
   for (int it = 0; it < 3; ++it)
     vae_mid_forward(c, &p, slabs, NS, eps_z, eps_l, buf[0], buf[1], buf[2], buf[3], buf[4], buf[5], buf[6], buf[7], buf[8], buf[9],
-                    buf[10], buf[11], buf[12], buf[13], buf[14], buf[15], buf[16], buf[17], nullptr, nullptr);
+                    buf[10], buf[11], buf[12], buf[13], buf[14], buf[15], buf[16], buf[17], nullptr, nullptr, nullptr);
   hipDeviceSynchronize();
   std::vector<unsigned long long> h(4096 * 16);
   hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(vae_probe), h.size() * 8);

@@ -147,6 +147,7 @@ struct MidFwd {
   float *dec_pre, *dec_h, *ln_md, *ln_rd;
   VaeDropout drop;                                       // nn.Dropout after each LayerNorm (off: scale == 0)
   float* absmax_px;                                      // nullable: B * NWV per-wave maxima of |dec_h| (f16x2 GEMMs)
+  uint16_t* px16;                                        // nullable: dec_h again as bf16 (a bf16-storage step's operand image)
 };
 
 // softplus variance, sample and KL for one encoder, executed by ONE wave (lane j = latent j).
@@ -351,6 +352,7 @@ __global__ __launch_bounds__(T) void mid_fwd_kernel(MidFwd a) {
       float h = (gd[i] - mu[0]) * rs[0] * dgam[i] + dbet[i];
       if (a.drop.on()) h *= a.drop.mult(VAE_SITE_DEC(0), b, Hd, n);
       a.dec_h[(int64_t)b * Hd + n] = h;
+      if (a.px16) a.px16[(int64_t)b * Hd + n] = __builtin_bit_cast(uint16_t, (__bf16)h);
       am = fmaxf(am, fabsf(h));
     }
   }
@@ -377,6 +379,7 @@ struct MidBwd {
   float *dbet_e, *dgam_e, *dpre_e;                       // (B, H+Hl) rows
   VaeDropout drop;
   float* absmax_dpre;                                    // nullable: B * NWV per-wave maxima of |dpre_e|
+  uint16_t* dpre16;                                      // nullable: dpre_e again as bf16 (a bf16-storage step's operand image)
 };
 
 // Backward of reparam_wave, by one wave.  Mirrors reparam_kl_bwd_kernel (rowops.hip).
@@ -540,6 +543,7 @@ __global__ __launch_bounds__(T) void mid_bwd_kernel(MidBwd a) {
       const float dg = (zh ? rs0 : rs1) * (dx[i] - (zh ? q4[0] : q4[2]) - xh[i] * (zh ? q4[1] : q4[3]));
       const float o = dg * gelu_grad(pv[i]);
       a.dpre_e[(int64_t)b * HE + e] = o;
+      if (a.dpre16) a.dpre16[(int64_t)b * HE + e] = __builtin_bit_cast(uint16_t, (__bf16)o);
       am = fmaxf(am, fabsf(o));
     }
   }
@@ -829,6 +833,7 @@ __global__ __launch_bounds__(64 * WPB) void mid_fwd_wave_kernel(MidFwd a) {
         float v = (gd[i] - mud) * rsd * dgam[i] + dbet[i];
         if (a.drop.on()) v *= a.drop.mult(VAE_SITE_DEC(0), b, Hd, n);
         a.dec_h[(int64_t)b * Hd + n] = v;
+        if (a.px16) a.px16[(int64_t)b * Hd + n] = __builtin_bit_cast(uint16_t, (__bf16)v);
         am = fmaxf(am, fabsf(v));
       }
     }
@@ -993,6 +998,7 @@ __global__ __launch_bounds__(64 * WPB) void mid_bwd_wave_kernel(MidBwd a) {
         const float dg = (zh ? rs0 : rs1) * (dxe[i] - (zh ? q4[0] : q4[2]) - xe[i] * (zh ? q4[1] : q4[3]));
         const float o = dg * gelu_grad(pe[i]);
         a.dpre_e[(int64_t)b * HE + e] = o;
+        if (a.dpre16) a.dpre16[(int64_t)b * HE + e] = __builtin_bit_cast(uint16_t, (__bf16)o);
         am = fmaxf(am, fabsf(o));
       }
     }
@@ -1187,9 +1193,10 @@ int vae_mid_forward(const vae_step_config& c, const vae_step_tensors* p, const f
                     const float* eps_l, float* pre_enc0, float* h_enc0, float* ln_mz, float* ln_rz, float* ln_ml,
                     float* ln_rl, float* heads_z, float* heads_l, float* qz_v, float* z, float* kl_z, float* ql_v,
                     float* library, float* kl_l, float* dec_pre, float* dec_h, float* ln_md, float* ln_rd, float* absmax_px,
-                    void* stream) {
+                    uint16_t* px16, void* stream) {
   MidFwd a;
   a.absmax_px = absmax_px;
+  a.px16 = px16;
   a.slabs = slabs; a.nslab = nslab; a.slab_stride = c.B * (c.H + c.Hl);
   a.enc_b0 = p->enc_b0;
   a.gz = p->encz_ln_g[0]; a.bz = p->encz_ln_b[0]; a.gl = p->encl_ln_g; a.bl = p->encl_ln_b;
@@ -1219,8 +1226,9 @@ int vae_mid_backward(const vae_step_config& c, const vae_step_tensors* p, const 
                      const float* pre_enc0, const float* ln_mz, const float* ln_rz, const float* ln_ml,
                      const float* ln_rl, const float* z, const float* h_enc0, float* dbet_d, float* dgam_d,
                      float* dpre_d, float* dq_z, float* dq_l, float* dbet_e, float* dgam_e, float* dpre_e,
-                     float* absmax_dpre, const VaeDeferredColreduce* cr, void* stream) {
+                     float* absmax_dpre, uint16_t* dpre16, const VaeDeferredColreduce* cr, void* stream) {
   MidBwd a;
+  a.dpre16 = dpre16;
   a.absmax_dpre = absmax_dpre;
   a.slabs = slabs; a.nslab = nslab; a.slab_stride = c.B * c.Hd;
   a.dec_pre = dec_pre; a.ln_md = ln_md; a.ln_rd = ln_rd; a.gd = p->dec_ln_g[0];

@@ -314,7 +314,7 @@ extern "C" int vae_elbo_step_forward(const vae_step_config* cfg, const vae_step_
     TRY(vae_mid_forward(c, p, slabs, nslab, eps_z, eps_l, ws + lo.pre_enc0, ws + lo.h_enc0, ws + lo.ln_mz[0],
                         ws + lo.ln_rz[0], ws + lo.ln_ml, ws + lo.ln_rl, ws + lo.heads_z, ws + lo.heads_l, ws + lo.qz_v,
                         ws + lo.z, ws + lo.kl_z, ws + lo.ql_v, ws + lo.library, ws + lo.kl_l, ws + lo.dec_pre[0],
-                        ws + lo.dec_h[0], ws + lo.ln_md[0], ws + lo.ln_rd[0], k.am(AM_PX), stream));
+                        ws + lo.dec_h[0], ws + lo.ln_md[0], ws + lo.ln_rd[0], k.am(AM_PX), k.hb() ? k.h16(lo.px16) : nullptr, stream));
     px = ws + lo.dec_h[0];
   } else {
     if (gd) {
@@ -368,7 +368,8 @@ extern "C" int vae_elbo_step_forward(const vae_step_config* cfg, const vae_step_
   VaeGemmRowStats rs{ws + lo.stat_m, ws + lo.stat_s, (int)G, lo.stat_cap, 0};
   static const bool no_gemm_stats = getenv("VAE_NO_GEMM_STATS") != nullptr;   // A/B knob
   if (k.hb()) {
-    TRY(vae_cast_bf16(px, k.h16(lo.px16), B * Hd, nullptr, nullptr, 0, stream));
+    if (!vae_mid_supported(c))   // (the fused middle writes the bf16 image of its output itself)
+      TRY(vae_cast_bf16(px, k.h16(lo.px16), B * Hd, nullptr, nullptr, 0, stream));
     TRY(vae_gemm_bf16io(VAE_NT, VAE_IO_A_BF16 | VAE_IO_B_BF16 | VAE_IO_C_BF16, B, NH, Hd, k.h16(lo.px16), Hd, k.h16(lo.w_heads16), Hd,
                         ws + lo.logits, NH, p->heads_b, ws + lo.scratch, lo.scratch_floats * 4, nullptr, no_gemm_stats ? nullptr : &rs,
                         stream));
@@ -472,7 +473,7 @@ extern "C" int vae_elbo_step_backward_events(const vae_step_config* cfg, const v
                          ws + lo.qz_v, ws + lo.ql_v, ws + lo.dlibrary, ws + lo.pre_enc0, ws + lo.ln_mz[0], ws + lo.ln_rz[0],
                          ws + lo.ln_ml, ws + lo.ln_rl, ws + lo.z, ws + lo.h_enc0, ws + lo.dbet_d, ws + lo.dgam_d,
                          ws + lo.dpx, ws + lo.dheads_z, ws + lo.dheads_l, ws + lo.dbet_e, ws + lo.dgam_e,
-                         ws + lo.dpre_enc0, k.am(AM_DPRE), &cr, stream));
+                         ws + lo.dpre_enc0, k.am(AM_DPRE), k.hb() ? k.h16(lo.dpre16) : nullptr, &cr, stream));
   } else {
     // the unfused kernels ACCUMULATE the LayerNorm / bias gradients with atomics: clear them first
     auto zero = [&](float* q, int64_t n) {
@@ -558,7 +559,8 @@ extern "C" int vae_elbo_step_backward_events(const vae_step_config* cfg, const v
   if (k.cov())   // covariate columns of both encoders' first-layer weight gradient: dpre^T cov (small; before the release point
                  // it would delay -- the whole enc_w0 slice travels last anyway)
     TRY(k.gemm(VAE_TN, HE, c.n_cov, B, ws + lo.dpre_enc0, HE, c.batch_cov, c.ld_cov, g->enc_w0 + G, k.ldw(), nullptr, nullptr, 0));
-  if (k.hb()) TRY(vae_cast_bf16(ws + lo.dpre_enc0, k.h16(lo.dpre16), B * HE, nullptr, nullptr, 0, stream));
+  if (k.hb() && !vae_mid_supported(c))   // (the fused middle writes the bf16 image of dpre itself)
+    TRY(vae_cast_bf16(ws + lo.dpre_enc0, k.h16(lo.dpre16), B * HE, nullptr, nullptr, 0, stream));
   if (c.input_dropout_rate > 0.f) {  // GeneDropout: each encoder's weight gradient over its own input
     TRY(k.enc_wgrad(H, ws + lo.dpre_enc0, HE, ws + lo.xn_z, AM_XNZ, g->enc_w0));
     TRY(k.enc_wgrad(Hl, ws + lo.dpre_enc0 + H, HE, ws + lo.xn, AM_XN, g->enc_w0 + H * k.ldw()));
