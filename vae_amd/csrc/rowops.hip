@@ -9,13 +9,15 @@
 // with one float atomic per column per workgroup.
 #include "../../include/vae_amd.h"
 #include "common.h"
+#include <stdlib.h>
 #include "philox.h"
 #include "internal.h"
 
 namespace {
 
 constexpr int MAXW = 1024;           // widest hidden layer a wave keeps in registers
-constexpr int NPL = MAXW / WAVE;     // elements per lane
+constexpr int NPL_MAX = MAXW / WAVE;  // elements per lane at the widest layer; the kernels are instantiated for 2 / 4 / 8 / 16
+                                      // (a 256-wide layer evaluated with 16 slots per lane spends 3/4 of its erf on padding)
 
 // ---------------------------------------------------------------------------------------
 // per-cell mean of x (Encoder.forward: x.mean(dim=-1), modules.py:264).  Counts are integers
@@ -140,6 +142,7 @@ __device__ __forceinline__ float gelu_grad(float v) {
   return cdf + v * pdf;
 }
 
+template <int NPL>
 __global__ __launch_bounds__(256) void gelu_ln_fwd_kernel(const float* __restrict__ pre, int64_t ld_pre,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           int B, int W, float* __restrict__ out, int64_t ld_out,
@@ -156,7 +159,7 @@ __global__ __launch_bounds__(256) void gelu_ln_fwd_kernel(const float* __restric
     g[j] = c < W ? gelu_f(p[c]) : 0.f;
     s += g[j];
   }
-  const float mu = wave_sum(s) / (float)W;
+  const float mu = wave_sum_dpp(s) / (float)W;
   float q = 0.f;
 #pragma unroll
   for (int j = 0; j < NPL; ++j) {
@@ -180,6 +183,7 @@ __global__ __launch_bounds__(256) void gelu_ln_fwd_kernel(const float* __restric
 // Backward of the above plus the three per-column reductions over cells that sit on it:
 // dgamma += sum_b dout*xhat, dbeta += sum_b dout, dbias += sum_b dpre (bias of the Linear
 // that produced `pre`).  dpre may alias dout.
+template <int NPL>
 __global__ __launch_bounds__(256) void gelu_ln_bwd_kernel(const float* dout, int64_t ld_dout,
                                                           const float* __restrict__ pre, int64_t ld_pre,
                                                           const float* __restrict__ mean, const float* __restrict__ rstd,
@@ -195,18 +199,38 @@ __global__ __launch_bounds__(256) void gelu_ln_bwd_kernel(const float* dout, int
     const int c = lane + j * WAVE;
     gam[j] = c < W ? gamma[c] : 0.f;
   }
-  for (int row = blockIdx.x * 4 + wave; row < B; row += gridDim.x * 4) {
+  // A wave walks its cells with the NEXT cell's loads issued before this cell's stores (dpre may alias dout, so the
+  // compiler cannot hoist them itself): one memory latency per cell instead of two in a row.
+  struct RowIn { float pv[NPL], dy[NPL], mu, rs; };
+  auto load_row = [&](int row) {
+    RowIn r;
     const float* p = pre + (int64_t)row * ld_pre;
     const float* d = dout + (int64_t)row * ld_dout;
-    const float mu = mean[row], rs = rstd[row];
+#pragma unroll
+    for (int j = 0; j < NPL; ++j) {
+      const int c = lane + j * WAVE;
+      r.pv[j] = c < W ? p[c] : 0.f;
+      r.dy[j] = c < W ? d[c] : 0.f;
+    }
+    r.mu = mean[row];
+    r.rs = rstd[row];
+    return r;
+  };
+  const int stride = gridDim.x * 4;
+  int row = blockIdx.x * 4 + wave;
+  RowIn cur, nxt;
+  if (row < B) cur = load_row(row);
+  for (; row < B; row += stride) {
+    if (row + stride < B) nxt = load_row(row + stride);
+    const float mu = cur.mu, rs = cur.rs;
     float xh[NPL], dx[NPL], pv[NPL];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int j = 0; j < NPL; ++j) {
       const int c = lane + j * WAVE;
       const bool ok = c < W;
-      pv[j] = ok ? p[c] : 0.f;
-      const float dy = ok ? d[c] : 0.f;
+      pv[j] = cur.pv[j];
+      const float dy = cur.dy[j];
       xh[j] = ok ? (gelu_f(pv[j]) - mu) * rs : 0.f;
       dx[j] = dy * gam[j];
       s1 += dx[j];
@@ -214,8 +238,8 @@ __global__ __launch_bounds__(256) void gelu_ln_bwd_kernel(const float* dout, int
       ag[j] += dy * xh[j];
       ab[j] += dy;
     }
-    s1 = wave_sum(s1) / (float)W;
-    s2 = wave_sum(s2) / (float)W;
+    s1 = wave_sum_dpp(s1) / (float)W;
+    s2 = wave_sum_dpp(s2) / (float)W;
     float* o = dpre + (int64_t)row * ld_dpre;
 #pragma unroll
     for (int j = 0; j < NPL; ++j) {
@@ -227,6 +251,7 @@ __global__ __launch_bounds__(256) void gelu_ln_bwd_kernel(const float* dout, int
         ap[j] += v;
       }
     }
+    cur = nxt;
   }
   // combine the 4 waves of the workgroup, then one atomic per column per workgroup
 #pragma unroll
@@ -276,7 +301,7 @@ __global__ __launch_bounds__(256) void reparam_kl_fwd_kernel(const float* __rest
     acc = 0.5f * (r + t * t - 1.f - lr);
     z[(int64_t)b * ld_z + lane] = m + eps[(int64_t)b * ld_e + lane] * sq;
   }
-  acc = wave_sum(acc);
+  acc = wave_sum_dpp(acc);
   if (lane == 0) {
     qv[b] = v;
     kl[b] = acc;
@@ -309,7 +334,7 @@ __global__ __launch_bounds__(256) void reparam_kl_bwd_kernel(const float* __rest
       col += o;
       dv = d * eps[(int64_t)b * ld_e + lane];
     }
-    dv = wave_sum(dv);
+    dv = wave_sum_dpp(dv);
     // d z_j / d v = eps_j / (2 sqrt v);  d kl / d v = L * 0.5 * (1/pv - 1/v)
     dv = dv * 0.5f / sq + gk * (float)L * 0.5f * (1.f / prior_var - 1.f / v);
     const float o = dv * softplus20_grad(hrow[L]);
@@ -394,7 +419,7 @@ __global__ __launch_bounds__(1024) void elbo_reduce_kernel(float* __restrict__ l
   }
   // the four block sums share one pair of barriers (the per-wave order of additions is that of block_sum)
   __shared__ float red4[4][16];
-  a = wave_sum(a); b = wave_sum(b); c = wave_sum(c); d = wave_sum(d);
+  a = wave_sum_dpp(a); b = wave_sum_dpp(b); c = wave_sum_dpp(c); d = wave_sum_dpp(d);
   if ((threadIdx.x & 63) == 0) {
     const int w = threadIdx.x >> 6;
     red4[0][w] = a; red4[1][w] = b; red4[2][w] = c; red4[3][w] = d;
@@ -598,8 +623,13 @@ extern "C" int vae_gelu_ln_fwd(const float* pre, int64_t ld_pre, const float* ga
   VAE_REQUIRE(pre && gamma && beta && out && mean && rstd, "vae_gelu_ln_fwd: null pointer");
   VAE_REQUIRE(B > 0 && W > 0 && W <= MAXW, "vae_gelu_ln_fwd: width %lld not in [1, %d]", (long long)W, MAXW);
   VAE_REQUIRE(ld_pre >= W && ld_out >= W, "vae_gelu_ln_fwd: leading dimension too small");
-  hipLaunchKernelGGL(gelu_ln_fwd_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, (hipStream_t)stream, pre, ld_pre,
-                     gamma, beta, (int)B, (int)W, out, ld_out, mean, rstd);
+#define VAE_LN_FWD(N) hipLaunchKernelGGL(gelu_ln_fwd_kernel<N>, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, (hipStream_t)stream, pre, \
+                                         ld_pre, gamma, beta, (int)B, (int)W, out, ld_out, mean, rstd)
+  if (W <= 2 * WAVE) VAE_LN_FWD(2);
+  else if (W <= 4 * WAVE) VAE_LN_FWD(4);
+  else if (W <= 8 * WAVE) VAE_LN_FWD(8);
+  else VAE_LN_FWD(NPL_MAX);
+#undef VAE_LN_FWD
   VAE_CHECK_LAUNCH("vae_gelu_ln_fwd");
   return VAE_OK;
 }
@@ -611,9 +641,15 @@ extern "C" int vae_gelu_ln_bwd(const float* dout, int64_t ld_dout, const float* 
   VAE_REQUIRE(B > 0 && W > 0 && W <= MAXW, "vae_gelu_ln_bwd: width %lld not in [1, %d]", (long long)W, MAXW);
   VAE_REQUIRE(ld_dout >= W && ld_pre >= W && ld_dpre >= W, "vae_gelu_ln_bwd: leading dimension too small");
   int blocks = (int)((B + 3) / 4);
-  if (blocks > 256) blocks = 256;
-  hipLaunchKernelGGL(gelu_ln_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dout, ld_dout, pre, ld_pre,
-                     mean, rstd, gamma, (int)B, (int)W, dpre, ld_dpre, dgamma, dbeta, dbias);
+  static const int cap = getenv("VAE_LN_BWD_BLOCKS") ? atoi(getenv("VAE_LN_BWD_BLOCKS")) : 256;   // tuning knob
+  if (blocks > cap) blocks = cap;
+#define VAE_LN_BWD(N) hipLaunchKernelGGL(gelu_ln_bwd_kernel<N>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dout, ld_dout, pre, \
+                                         ld_pre, mean, rstd, gamma, (int)B, (int)W, dpre, ld_dpre, dgamma, dbeta, dbias)
+  if (W <= 2 * WAVE) VAE_LN_BWD(2);
+  else if (W <= 4 * WAVE) VAE_LN_BWD(4);
+  else if (W <= 8 * WAVE) VAE_LN_BWD(8);
+  else VAE_LN_BWD(NPL_MAX);
+#undef VAE_LN_BWD
   VAE_CHECK_LAUNCH("vae_gelu_ln_bwd");
   return VAE_OK;
 }
@@ -639,7 +675,8 @@ extern "C" int vae_reparam_kl_bwd(const float* dz, int64_t ld_dz, const float* g
   VAE_REQUIRE(B > 0 && L > 0 && L <= WAVE && ld_heads >= L + 1 && ld_eps >= L && ld_dz >= L && ld_dheads >= L + 1,
               "vae_reparam_kl_bwd: bad shape");
   int blocks = (int)((B + 3) / 4);
-  if (blocks > 64) blocks = 64;  // few workgroups: one float atomic per column per workgroup
+  static const int cap = getenv("VAE_REPARAM_BWD_BLOCKS") ? atoi(getenv("VAE_REPARAM_BWD_BLOCKS")) : 256;   // tuning knob
+  if (blocks > cap) blocks = cap;  // few workgroups: one float atomic per column per workgroup
   hipLaunchKernelGGL(reparam_kl_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dz, ld_dz, g_kl,
                      g_kl_scalar, heads, ld_heads, eps, ld_eps, qv, (int)B, (int)L, prior_mean, prior_var, dheads,
                      ld_dheads, dbias);
