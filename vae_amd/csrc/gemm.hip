@@ -1419,10 +1419,15 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 
 // Tile size and K split for a shape.  small = 64x64 tiles (one dimension <= 64, or little work).
 struct Plan { int tile; int split; };
-Plan make_plan(int M, int N, int K) {
+Plan make_plan(int M, int N, int K, bool short_k_rule = true) {
   Plan p;
   static const int force_tile = getenv("VAE_GEMM_TILE") ? atoi(getenv("VAE_GEMM_TILE")) : 0;  // tuning knob
   bool small = (M <= 64 || N <= 64) || (2.0 * M * N * K < 2e8);
+  // a short contraction with few 128-wide tiles (hidden-layer products of a large batch: 4096 x 256 x 256 = 64 tiles)
+  // cannot buy parallelism with a K split worth its reduce launch: 64-wide tiles fill the chip instead
+  static const int short_k = getenv("VAE_GEMM_SHORT_K") ? atoi(getenv("VAE_GEMM_SHORT_K")) : 512;   // A/B knob, 0 = off
+  // (not for products over bf16-stored operands: those exist on the 128-wide pipeline only)
+  if (short_k_rule && !small && K <= short_k && ((M + 127) / 128) * ((N + 127) / 128) < 128) small = true;
   if (force_tile == 64) small = true;
   if (force_tile == 128) small = false;
   p.tile = small ? 64 : 128;
@@ -1492,11 +1497,14 @@ void launch_t(const GemmArgs& g, bool norm, dim3 grid, hipStream_t st, int tile)
 }  // namespace
 
 extern "C" int64_t vae_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K) {
-  const Plan p = make_plan((int)M, (int)N, (int)K);
-  int split = p.split;
-  if (K % 4 == 0 && p.tile == 128) {  // whichever pipeline the operands' alignment selects at run time
-    const DmaPlan d = make_dma_plan((int)M, (int)N, (int)K);
-    if (d.split > split) split = d.split;
+  int split = 1;
+  for (int rule = 0; rule < 2; ++rule) {   // with and without the short-contraction rule (bf16-stored operands: without)
+    const Plan p = make_plan((int)M, (int)N, (int)K, rule != 0);
+    if (p.split > split) split = p.split;
+    if (K % 4 == 0 && p.tile == 128) {  // whichever pipeline the operands' alignment selects at run time
+      const DmaPlan d = make_dma_plan((int)M, (int)N, (int)K);
+      if (d.split > split) split = d.split;
+    }
   }
   return split > 1 ? (int64_t)split * M * N * (int64_t)sizeof(float) : 0;
 }
@@ -1539,7 +1547,7 @@ int gemm_impl(int layout, int precision, int64_t M, int64_t N, int64_t K, const 
   g.vecA = (lda % 4 == 0) && ((io & 1) ? (reinterpret_cast<uintptr_t>(A) & 7u) == 0 : vae_aligned16(A));
   g.vecB = (ldb % 4 == 0) && ((io & 2) ? (reinterpret_cast<uintptr_t>(B) & 7u) == 0 : vae_aligned16(B));
   g.group_m = 0;
-  const Plan plan = make_plan(g.M, g.N, g.K);
+  const Plan plan = make_plan(g.M, g.N, g.K, io == 0);
   static const int no_dma = getenv("VAE_GEMM_NO_DMA") ? atoi(getenv("VAE_GEMM_NO_DMA")) : 0;  // tuning knob
   const bool norm = x_mean != nullptr;
   const bool a_rc = layout == TN, b_rc = layout != NT;
@@ -1828,7 +1836,7 @@ extern "C" int vae_gemm_bf16_storage_ok(int layout, int io, int64_t M, int64_t N
   // combinations with a kernel behind them: NT {A, A+B, C, A+B+C}, NN {A, A+B}, TN {A, B, A+B}
   const bool combo = layout == NT ? (io == 1 || io == 3 || io == 4 || io == 7) : layout == NN ? (io == 1 || io == 3) : (io >= 1 && io <= 3);
   if (!combo) return 0;
-  if (make_plan((int)M, (int)N, (int)K).tile != 128 || K % 4 != 0) return 0;
+  if (make_plan((int)M, (int)N, (int)K, false).tile != 128 || K % 4 != 0) return 0;
   if ((layout == TN && M % 4 != 0) || (layout != NT && N % 4 != 0)) return 0;
   if ((io & 4) && N % 8 != 0) return 0;
   return 1;
