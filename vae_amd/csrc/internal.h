@@ -43,6 +43,10 @@ int vae_gemm_bf16io(int layout, int io, int64_t M, int64_t N, int64_t K, const v
 // bf16 images of up to two dense fp32 arrays (s1 nullable), one launch (gemm.hip)
 int vae_cast_bf16(const float* s0, void* d0, int64_t n0, const float* s1, void* d1, int64_t n1, void* stream);
 // rowmax[b] / rowsum[b] from the `slots` per-slot statistics a GEMM left (epilogue.hip)
+#define VAE_ZERO_MAX_SEGMENTS 48
+struct VaeZeroList { float* ptr[VAE_ZERO_MAX_SEGMENTS]; int64_t n[VAE_ZERO_MAX_SEGMENTS]; int count; };
+int vae_zero_segments(const VaeZeroList& z, void* stream);
+
 // px_r != null: extra workgroups of the same launch build the gene table (vae_gene_table) as well
 int vae_softmax_stats_merge(const float* stat_m, const float* stat_s, int slots, int64_t B, float* rowmax, float* rowsum,
                             const float* px_r, int64_t G, float* table, void* stream);

@@ -476,9 +476,13 @@ extern "C" int vae_elbo_step_backward_events(const vae_step_config* cfg, const v
                          ws + lo.dpre_enc0, k.am(AM_DPRE), k.hb() ? k.h16(lo.dpre16) : nullptr, &cr, stream));
   } else {
     // the unfused kernels ACCUMULATE the LayerNorm / bias gradients with atomics: clear them first
-    auto zero = [&](float* q, int64_t n) {
-      return (q && hipMemsetAsync(q, 0, (size_t)n * sizeof(float), (hipStream_t)stream) != hipSuccess)
-                 ? vae_set_error(VAE_ERR_LAUNCH, "vae_elbo_step_backward: hipMemsetAsync failed") : VAE_OK;
+    VaeZeroList zl;
+    zl.count = 0;
+    auto zero = [&](float* q, int64_t n) {   // collected, cleared by one launch below
+      if (!q || n <= 0) return VAE_OK;
+      if (zl.count >= VAE_ZERO_MAX_SEGMENTS) return vae_set_error(VAE_ERR_ARG, "vae_elbo_step_backward: too many gradient segments");
+      zl.ptr[zl.count] = q; zl.n[zl.count] = n; ++zl.count;
+      return VAE_OK;
     };
     for (int n = 0; n < c.n_layers; ++n) {
       TRY(zero(g->dec_ln_g[n], Hd)); TRY(zero(g->dec_ln_b[n], Hd)); TRY(zero(g->dec_b[n], Hd));
@@ -487,6 +491,7 @@ extern "C" int vae_elbo_step_backward_events(const vae_step_config* cfg, const v
     }
     TRY(zero(g->encl_ln_g, Hl)); TRY(zero(g->encl_ln_b, Hl)); TRY(zero(g->enc_b0, HE));
     TRY(zero(g->hz_b, L + 1)); TRY(zero(g->hl_b, 2));
+    TRY(vae_zero_segments(zl, stream));
     if (k.hb())
       TRY(vae_gemm_bf16io(VAE_NN, VAE_IO_A_BF16 | VAE_IO_B_BF16, B, Hd, NH, logits, NH, k.h16(lo.w_heads16), Hd, ws + lo.dpx, Hd, nullptr,
                           ws + lo.scratch, lo.scratch_floats * 4, nullptr, nullptr, stream));
