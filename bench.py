@@ -338,17 +338,21 @@ def main():
         fopt = FusedAdamW(arena, lr=5e-4, weight_decay=0.1, max_grad_norm=0.5, track_weight_maxima=True)
         step.use_weight_maxima(fopt)
     reducer = GradAllReducer(arena, payload=args.grad_payload) if world > 1 else None
-    head_fn = None
-    if cell_decoder is not None:   # CellDecoder + _cell_loss (modules.py:312-324, task.py:419-451) on z, torch autograd
+    head_fn = heads = None
+    if cell_decoder is not None:   # CellDecoder + _cell_loss (modules.py:312-324, task.py:419-451) on z
+        from vae_amd.step import CellHeads
         from vae_amd.task import cell_loss
         targets = torch.stack([torch.randint(0, len(v["values"]), (B,), generator=gen, device=dev).float() if v["discrete"]
                                else torch.randn(B, generator=gen, device=dev) for v in HEADS.values()], dim=1)
         mask = (torch.rand(B, len(HEADS), generator=gen, device=dev) > 0.1).float()
-        head_fn = lambda z: cell_loss(cell_decoder(z), HEADS, targets, mask)  # noqa: E731
+        if os.environ.get("VAE_BENCH_TORCH_HEADS"):   # A/B: the heads through torch autograd on the (B, L) latent
+            head_fn = lambda z: cell_loss(cell_decoder(z), HEADS, targets, mask)  # noqa: E731
+        else:                                         # linear heads (the reference's shipped setting): native kernels
+            heads = (CellHeads(arena, HEADS, HEADS_GRAD_REVERSE), targets, mask)
 
     def one_step(i):
         xb = x_all[(i % n_batches) * B:(i % n_batches + 1) * B]
-        out = step.run(xb, eps_z, eps_l, cell_head_fn=head_fn, reducer=reducer)
+        out = step.run(xb, eps_z, eps_l, cell_head_fn=head_fn, cell_heads=heads, reducer=reducer)
         if reducer is not None:
             reducer.finish()
         return out

@@ -406,6 +406,31 @@ int vae_elbo_step_backward_events(const vae_step_config* cfg, const vae_step_ten
                                   float* workspace, int64_t workspace_bytes, void* event_heads_ready,
                                   void* event_small_ready, void* stream);
 
+/* ---- cell-property heads ------------------------------------------------------
+ * CellDecoder with linear heads (modules.py:297-324; cell_decoder_hidden_layer = False is the shipped setting,
+ * config.py:67) and LitVAE._cell_loss (task.py:419-451), forward and backward on the (B, L) latent:
+ *   head i: logits = z_i W_i^T + b_i, z_i = z (dz_coeff 1), z detached (stop_grad: dz_coeff 0) or z behind
+ *   GradReverse(lambda) (dz_coeff = -lambda, functional.py:5-22);
+ *   discrete: cross_entropy(logits, int(targets[:, i]), ignore_index = -100, reduction none); else (logits - targets[:, i])^2;
+ *   loss = sum_i mean_b(per_i[b] * mask[b, i])    (the mean runs over ALL cells of the batch).
+ * Writes *loss (unscaled), and -- dz != NULL -- dz (B, L) = d(loss_scale * loss)/dz summed over the heads with their
+ * dz_coeff, dw[i] / db[i] (overwritten).  Two or three launches, fixed summation order.  L <= 64, sum of widths <= 64.  */
+#define VAE_MAX_HEADS 7
+typedef struct {
+  int32_t n_heads;
+  int32_t width[VAE_MAX_HEADS];      /* classes of a discrete head; 1 for a continuous head               */
+  int32_t discrete[VAE_MAX_HEADS];
+  float dz_coeff[VAE_MAX_HEADS];
+  const float* w[VAE_MAX_HEADS];     /* (width, L)                                                        */
+  const float* b[VAE_MAX_HEADS];     /* (width)                                                           */
+  float* dw[VAE_MAX_HEADS];
+  float* db[VAE_MAX_HEADS];
+} vae_cell_heads;
+int64_t vae_cell_heads_workspace_bytes(int64_t B, int64_t L, const vae_cell_heads* heads);
+int vae_cell_heads_step(const vae_cell_heads* heads, const float* z, int64_t B, int64_t L, const float* targets, int64_t ld_t,
+                        const float* mask, int64_t ld_m, float loss_scale, float* dz, float* loss, float* workspace,
+                        int64_t workspace_bytes, void* stream);
+
 /* ---- fused optimiser step ------------------------------------------------------
  * One call = torch.nn.utils.clip_grad_norm_(max_grad_norm) (Trainer(gradient_clip_val=0.5),
  * train.py:54) followed by torch.optim.AdamW.step() (betas, eps, decoupled per-group weight decay,

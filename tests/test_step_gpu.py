@@ -512,3 +512,60 @@ def test_weight_maxima_from_the_optimiser_replace_the_scan():
     arena.flat.mul_(3.0)                             # a change behind the optimiser's back needs a refresh
     opt.refresh_weight_maxima()
     assert float(opt.weight_maxima[1].max()) == float(w_heads.abs().max())
+
+
+@pytest.mark.parametrize("B", [37, 700, 2304])
+def test_native_cell_heads_match_torch_heads(B):
+    """vae_cell_heads_step (linear CellDecoder heads + LitVAE._cell_loss, modules.py:297-324, task.py:419-451) against the
+    torch modules under autograd in fp64: loss, d z and every head's weight / bias gradient -- two discrete heads (one
+    behind a gradient-reversal layer), a stop_grad head that must leave d z alone, a continuous head, ignore_index rows,
+    masked cells, a loss scale; B = 2304 runs the chunked reduction + combine launch."""
+    from oracle import vae_oracle as O
+    from vae_amd.arena import ParamArena
+    from vae_amd.modules import CellDecoder
+    from vae_amd.step import CellHeads
+    from vae_amd.task import cell_loss
+    L = 30
+    props = {"Dx": {"discrete": True, "values": [0, 1, 2], "stop_grad": False},
+             "Adv": {"discrete": True, "values": list(range(7)), "stop_grad": False},
+             "Frozen": {"discrete": True, "values": [0, 1], "stop_grad": True},
+             "Age": {"discrete": False, "values": [-1], "stop_grad": False}}
+    rev = {"Adv": 0.3}
+    p = O.init_params(64, 16, 16, 8, L, 1, seed=21, cell_properties=props)
+    arena = ParamArena(p, 1, "zinb", "cuda")
+    g = torch.Generator().manual_seed(22)
+    z = torch.randn(B, L, generator=g)
+    targets = torch.stack([torch.randint(0, len(v["values"]), (B,), generator=g).float() if v["discrete"] else torch.randn(B, generator=g)
+                           for v in props.values()], dim=1)
+    targets[::5, 1] = -100.0
+    targets[1::9, 0] = -100.0
+    mask = (torch.rand(B, len(props), generator=g) > 0.2).float()
+    scale = 1.7
+    # torch side, fp64
+    dec = CellDecoder(L, props, grad_reverse_dict=rev, use_hidden_layer=False).double()
+    for k in props:
+        dec.cell_mlp[k].weight.data = p[f"cell_decoder.cell_mlp.{k}.weight"].double()
+        dec.cell_mlp[k].bias.data = p[f"cell_decoder.cell_mlp.{k}.bias"].double()
+    z64 = z.double().requires_grad_(True)
+    ref = cell_loss(dec(z64), props, targets.double(), mask.double())
+    (ref * scale).backward()
+    heads = CellHeads(arena, props, rev)
+    dz = torch.full((B, L), float("nan"), device="cuda")
+    loss = heads.run(z.cuda(), targets.cuda(), mask.cuda(), scale, dz)
+    torch.cuda.synchronize()
+    assert abs(float(loss) - float(ref)) < 2e-6 * abs(float(ref))
+    assert rel_err(dz.cpu().numpy(), z64.grad.numpy()) < 1e-5
+    for k in props:
+        for leaf in ("weight", "bias"):
+            got = arena.g(f"cell_decoder.cell_mlp.{k}.{leaf}").cpu().numpy()
+            assert rel_err(got, getattr(dec.cell_mlp[k], leaf).grad.numpy()) < 1e-5, (k, leaf)
+    # forward only: the loss alone, no gradient written
+    before = arena.flat_grad.clone()
+    loss2 = heads.run(z.cuda(), targets.cuda(), mask.cuda())
+    torch.cuda.synchronize()
+    assert abs(float(loss2) - float(ref)) < 2e-6 * abs(float(ref)) and torch.equal(before, arena.flat_grad)
+    # a head with a hidden layer is refused (it runs through cell_head_fn)
+    p2 = dict(p)
+    p2["cell_decoder.cell_mlp.Dx.0.weight"] = p2.pop("cell_decoder.cell_mlp.Dx.weight")
+    with pytest.raises((ValueError, KeyError)):
+        CellHeads(ParamArena(p2, 1, "zinb", "cuda"), props, rev)

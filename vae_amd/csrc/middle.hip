@@ -1063,7 +1063,7 @@ int mid_wave_launch(K kern, const MidWavePlan& p, const A& a, hipStream_t st) {
 // after the other (60 us at B = 4096).  The cells are then cut into nsplit chunks (grid.y), every chunk leaves its
 // partial outputs in `part` ([task][chunk][P][Q]), and small_wgrad_combine_kernel adds them in chunk order.
 // ---------------------------------------------------------------------------------------
-constexpr int MAX_TASKS = 16;
+constexpr int MAX_TASKS = 24;
 constexpr int PT = 8;
 struct WgradTask {
   const float* U; int ldU, P;
@@ -1178,7 +1178,182 @@ __global__ __launch_bounds__(256) void small_wgrad_combine_kernel(WgradBatch wb)
   tk.out[(int64_t)p * tk.sp + (int64_t)q * tk.sq] = v;
 }
 
+// Launches a filled task table (task[], ntask, B, cr_tile0, cr): one pass, or -- from 2048 cells on, when `space`
+// (capacity floats) can hold the chunks' partial outputs -- chunks of 512 cells plus the combine launch.
+int launch_wgrad_batch(WgradBatch& wb, int tiles, int ptotal, float* space, int64_t capacity, void* stream) {
+  const int split_min_b = getenv("VAE_SMALL_WGRAD_SPLIT_MIN_B") ? atoi(getenv("VAE_SMALL_WGRAD_SPLIT_MIN_B")) : 2048;   // A/B knob
+  wb.nsplit = 1; wb.chunk = wb.B; wb.part = nullptr; wb.part_total = ptotal;
+  if (wb.B >= split_min_b && space) {
+    const int ns = (wb.B + 511) / 512;
+    if ((int64_t)ns * ptotal <= capacity) { wb.nsplit = ns; wb.chunk = 512; wb.part = space; }
+  }
+  hipLaunchKernelGGL(small_wgrad_kernel, dim3((unsigned)tiles, (unsigned)wb.nsplit), dim3(TW), 0, (hipStream_t)stream, wb);
+  VAE_CHECK_LAUNCH("small_wgrad");
+  if (wb.nsplit > 1) {
+    hipLaunchKernelGGL(small_wgrad_combine_kernel, dim3((unsigned)((ptotal + 255) / 256)), dim3(256), 0, (hipStream_t)stream, wb);
+    VAE_CHECK_LAUNCH("small_wgrad_combine");
+  }
+  return VAE_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// Cell-property heads on the latent: CellDecoder with linear heads (modules.py:297-324, the shipped
+// cell_decoder_hidden_layer = False, config.py:67) + LitVAE._cell_loss (task.py:419-451) and their backward.
+// One wave per cell: lane j < C (all heads' outputs side by side) forms its logit from the LDS-staged weights, the lanes
+// of a discrete head share a softmax (cross-entropy, ignore_index -100), a continuous head is a squared error; every
+// head's per-cell loss is weighted by its mask and averaged over ALL cells of the batch.  The same wave turns the logit
+// gradients into d z (each head scaled by dz_coeff: 1, 0 for a stop_grad head that sees the latent detached, -lambda
+// behind a gradient-reversal layer) and leaves them as a (B, C) matrix for the weight / bias sums (small_wgrad tasks).
+// ---------------------------------------------------------------------------------------
+struct HeadsArgs {
+  vae_cell_heads h;
+  const float* z; const float* targets; const float* mask;
+  int64_t ld_t, ld_m;
+  int B, L, C;
+  float scale;          // loss_scale / B on the gradients
+  float inv_b;
+  float* dz;            // nullable (forward only)
+  float* dlg;           // (B, C) logit gradients (nullable with dz)
+  float* loss_cell;     // (B)
+};
+// lanes of ONE wave hand values to each other through LDS: order the stores before the loads (no workgroup barrier)
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__global__ __launch_bounds__(256) void cell_heads_kernel(HeadsArgs a) {
+  constexpr int MAXC = 64, MAXL = 64;
+  __shared__ float Ws[MAXC][MAXL + 1];
+  __shared__ float bs[MAXC], coef[MAXC];
+  __shared__ int seg0[MAXC], segn[MAXC], head[MAXC], disc[MAXC];
+  __shared__ float zs[4][MAXL], lg[4][MAXC], dls[4][MAXC];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int L = a.L, C = a.C;
+  if (tid < MAXC) {   // output column -> head
+    int j0 = 0, hh = 0;
+    for (int i = 0; i < a.h.n_heads; ++i) {
+      if (tid >= j0 && tid < j0 + a.h.width[i]) hh = i;
+      j0 += a.h.width[i];
+    }
+    int s0 = 0;
+    for (int i = 0; i < hh; ++i) s0 += a.h.width[i];
+    head[tid] = hh; seg0[tid] = s0; segn[tid] = a.h.width[hh]; disc[tid] = a.h.discrete[hh]; coef[tid] = a.h.dz_coeff[hh];
+    if (tid < C) bs[tid] = a.h.b[hh][tid - s0];
+  }
+  __syncthreads();
+  for (int i = tid; i < C * L; i += 256) {
+    const int j = i / L, l = i - j * L;
+    Ws[j][l] = a.h.w[head[j]][(j - seg0[j]) * L + l];
+  }
+  __syncthreads();
+  const int b = blockIdx.x * 4 + wave;
+  if (b >= a.B) return;   // no barrier below
+  zs[wave][lane] = lane < L ? a.z[(int64_t)b * L + lane] : 0.f;
+  wave_lds_sync();
+  float logit = 0.f;
+  if (lane < C) {
+    logit = bs[lane];
+    for (int l = 0; l < L; ++l) logit = fmaf(Ws[lane][l], zs[wave][l], logit);
+  }
+  lg[wave][lane] = logit;
+  wave_lds_sync();
+  float dl = 0.f, lossc = 0.f;
+  if (lane < C) {
+    const int hh = head[lane], s0 = seg0[lane], n = segn[lane];
+    const float t = a.targets[(int64_t)b * a.ld_t + hh];
+    const float mk = a.mask[(int64_t)b * a.ld_m + hh];
+    if (disc[lane]) {
+      float m = lg[wave][s0];
+      for (int k = 1; k < n; ++k) m = fmaxf(m, lg[wave][s0 + k]);
+      float ssum = 0.f;
+      for (int k = 0; k < n; ++k) ssum += expf(lg[wave][s0 + k] - m);
+      const int ti = (int)t;
+      const bool valid = ti != -100 && ti >= 0 && ti < n;   // ignore_index (task.py:437)
+      if (valid) {
+        const float p = expf(logit - m) / ssum;
+        dl = (p - (lane - s0 == ti ? 1.f : 0.f)) * mk * a.scale;
+        if (lane == s0) lossc = (logf(ssum) + m - lg[wave][s0 + ti]) * mk * a.inv_b;
+      }
+    } else {
+      const float d = logit - t;
+      dl = 2.f * d * mk * a.scale;
+      lossc = d * d * mk * a.inv_b;
+    }
+  }
+  lossc = wave_sum_dpp(lossc);
+  if (lane == 0) a.loss_cell[b] = lossc;
+  if (!a.dz) return;
+  if (lane < C) a.dlg[(int64_t)b * C + lane] = dl;
+  dls[wave][lane] = lane < C ? dl * coef[lane] : 0.f;
+  wave_lds_sync();
+  if (lane < L) {
+    float acc = 0.f;
+    for (int j = 0; j < C; ++j) acc = fmaf(dls[wave][j], Ws[j][lane], acc);
+    a.dz[(int64_t)b * L + lane] = acc;
+  }
+}
+
 }  // namespace
+
+extern "C" int64_t vae_cell_heads_workspace_bytes(int64_t B, int64_t L, const vae_cell_heads* h) {
+  if (!h || B <= 0 || L <= 0 || h->n_heads <= 0 || h->n_heads > VAE_MAX_HEADS) return -1;
+  int64_t C = 0;
+  for (int i = 0; i < h->n_heads; ++i) C += h->width[i];
+  const int64_t ptotal = C * L + C + 1, ns = (B + 511) / 512;
+  return (B * C + B + 8 + ns * ptotal + 8) * (int64_t)sizeof(float);
+}
+
+extern "C" int vae_cell_heads_step(const vae_cell_heads* h, const float* z, int64_t B, int64_t L, const float* targets,
+                                   int64_t ld_t, const float* mask, int64_t ld_m, float loss_scale, float* dz, float* loss,
+                                   float* workspace, int64_t workspace_bytes, void* stream) {
+  VAE_REQUIRE(h && z && targets && mask && loss && workspace, "vae_cell_heads_step: null pointer");
+  VAE_REQUIRE(h->n_heads > 0 && h->n_heads <= VAE_MAX_HEADS, "vae_cell_heads_step: 1..%d heads", VAE_MAX_HEADS);
+  VAE_REQUIRE(B > 0 && B < (1 << 30) && L > 0 && L <= 64, "vae_cell_heads_step: need B > 0 and a latent of at most 64");
+  int C = 0;
+  for (int i = 0; i < h->n_heads; ++i) {
+    VAE_REQUIRE(h->width[i] >= 1 && (h->discrete[i] || h->width[i] == 1), "vae_cell_heads_step: head %d: bad width", i);
+    VAE_REQUIRE(h->w[i] && h->b[i] && (!dz || (h->dw[i] && h->db[i])), "vae_cell_heads_step: head %d: null parameter / gradient", i);
+    C += h->width[i];
+  }
+  VAE_REQUIRE(C <= 64, "vae_cell_heads_step: at most 64 outputs over all heads, got %d", C);
+  VAE_REQUIRE(ld_t >= h->n_heads && ld_m >= h->n_heads, "vae_cell_heads_step: targets / mask need one column per head");
+  VAE_REQUIRE(workspace_bytes >= vae_cell_heads_workspace_bytes(B, L, h) && vae_aligned16(workspace),
+              "vae_cell_heads_step: workspace too small or misaligned (vae_cell_heads_workspace_bytes)");
+  HeadsArgs a;
+  a.h = *h; a.z = z; a.targets = targets; a.mask = mask; a.ld_t = ld_t; a.ld_m = ld_m;
+  a.B = (int)B; a.L = (int)L; a.C = C;
+  a.inv_b = 1.f / (float)B; a.scale = loss_scale / (float)B;
+  a.dz = dz;
+  a.dlg = workspace;
+  a.loss_cell = workspace + ((B * C + 3) & ~(int64_t)3);
+  float* part = a.loss_cell + ((B + 3) & ~(int64_t)3);
+  hipLaunchKernelGGL(cell_heads_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a);
+  VAE_CHECK_LAUNCH("vae_cell_heads_step");
+  // sums over cells: d W_h = dlogits_h^T z, d b_h = column sums, loss = sum of the per-cell losses (fixed order)
+  WgradBatch wb;
+  int n = 0, tiles = 0, ptotal = 0;
+  auto add = [&](const float* U, int ldU, int P, const float* V, int ldV, int Q, float* out, int sp, int sq) {
+    WgradTask& k = wb.task[n++];
+    k.U = U; k.ldU = ldU; k.P = P; k.V = V; k.ldV = ldV; k.Q = Q; k.out = out; k.sp = sp; k.sq = sq;
+    k.tile0 = tiles;
+    k.part0 = ptotal;
+    tiles += ((P + PT - 1) / PT) * ((Q + 63) / 64);
+    ptotal += P * Q;
+  };
+  add(nullptr, 0, 1, a.loss_cell, 1, 1, loss, 0, 1);
+  if (dz) {
+    int s0 = 0;
+    for (int i = 0; i < h->n_heads; ++i) {
+      add(a.dlg + s0, C, h->width[i], z, (int)L, (int)L, h->dw[i], (int)L, 1);
+      add(nullptr, 0, 1, a.dlg + s0, C, h->width[i], h->db[i], 0, 1);
+      s0 += h->width[i];
+    }
+  }
+  wb.ntask = n; wb.B = (int)B; wb.cr_tile0 = tiles; wb.cr = VaeDeferredColreduce{};
+  const int64_t cap = workspace_bytes / 4 - (part - workspace);
+  return launch_wgrad_batch(wb, tiles, ptotal, part, cap, stream);
+}
 
 // ---- internal entry points used by step.hip (not part of the public C ABI) -----------------
 bool vae_mid_supported(const vae_step_config& c) {
@@ -1286,17 +1461,5 @@ int vae_mid_backward(const vae_step_config& c, const vae_step_tensors* p, const 
   }
   // chunks of 512 cells from B = 2048 on; their partial outputs go where the dgrad slabs were (mid_bwd, enqueued above,
   // was their last reader)
-  const int split_min_b = getenv("VAE_SMALL_WGRAD_SPLIT_MIN_B") ? atoi(getenv("VAE_SMALL_WGRAD_SPLIT_MIN_B")) : 2048;   // A/B knob
-  wb.nsplit = 1; wb.chunk = B; wb.part = nullptr; wb.part_total = ptotal;
-  if (B >= split_min_b && nslab > 0) {
-    const int ns = (B + 511) / 512;
-    if ((int64_t)ns * ptotal <= (int64_t)nslab * B * Hd) { wb.nsplit = ns; wb.chunk = 512; wb.part = const_cast<float*>(slabs); }
-  }
-  hipLaunchKernelGGL(small_wgrad_kernel, dim3((unsigned)tiles, (unsigned)wb.nsplit), dim3(TW), 0, (hipStream_t)stream, wb);
-  VAE_CHECK_LAUNCH("vae_elbo_step_backward(small wgrad)");
-  if (wb.nsplit > 1) {
-    hipLaunchKernelGGL(small_wgrad_combine_kernel, dim3((unsigned)((ptotal + 255) / 256)), dim3(256), 0, (hipStream_t)stream, wb);
-    VAE_CHECK_LAUNCH("vae_elbo_step_backward(small wgrad combine)");
-  }
-  return VAE_OK;
+  return launch_wgrad_batch(wb, tiles, ptotal, nslab > 0 ? const_cast<float*>(slabs) : nullptr, (int64_t)nslab * B * Hd, stream);
 }

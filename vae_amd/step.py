@@ -67,6 +67,73 @@ def _tensors(view, cat, n_layers: int, zinb: bool) -> _lib.StepTensors:
     return t
 
 
+class CellHeads:
+    """The cell-property heads on the native path (include/vae_amd.h, ``vae_cell_heads_step``): ``CellDecoder`` with
+    LINEAR heads (modules.py:297-324; ``cell_decoder_hidden_layer=False`` is the shipped setting, config.py:67) and
+    ``LitVAE._cell_loss`` (task.py:419-451) -- logits, masked cross-entropy (ignore_index -100) / squared error averaged
+    over all cells, and the backward: d z (a ``stop_grad`` head contributes nothing, a gradient-reversal head ``-lambda``
+    times its gradient) and the heads' weight / bias gradients, written into the arena.  Heads with a hidden layer stay
+    on ``ElboStep.run(cell_head_fn=...)`` (torch autograd on the (B, L) latent)."""
+
+    def __init__(self, arena: ParamArena, cell_properties: Dict[str, dict], grad_reverse: Optional[Dict[str, float]] = None,
+                 prefix: str = "cell_decoder.cell_mlp."):
+        self.lib = _lib.load()
+        self.arena = arena
+        names = list(cell_properties)
+        if not 0 < len(names) <= _lib.VAE_MAX_HEADS:
+            raise ValueError(f"CellHeads: 1..{_lib.VAE_MAX_HEADS} heads, got {len(names)}")
+        h = _lib.CellHeads()
+        h.n_heads = len(names)
+        self.L = None
+        for i, k in enumerate(names):
+            wk, bk = f"{prefix}{k}.weight", f"{prefix}{k}.bias"
+            if wk not in arena.offsets or bk not in arena.offsets:
+                raise ValueError(f"CellHeads: head {k!r} is not a single Linear layer (hidden-layer heads: use cell_head_fn)")
+            w = arena.p(wk)
+            prop = cell_properties[k]
+            width = len(prop["values"]) if prop["discrete"] else 1
+            if w.dim() != 2 or w.shape[0] != width or (self.L is not None and w.shape[1] != self.L):
+                raise ValueError(f"CellHeads: head {k!r}: weight shape {tuple(w.shape)} does not fit the property")
+            self.L = w.shape[1]
+            h.width[i], h.discrete[i] = width, int(bool(prop["discrete"]))
+            if grad_reverse is not None and k in grad_reverse:          # CellDecoder._view_of_latent (modules.py:317-321)
+                h.dz_coeff[i] = -float(grad_reverse[k])
+            else:
+                h.dz_coeff[i] = 0.0 if prop["stop_grad"] else 1.0
+            h.w[i], h.b[i] = w.data_ptr(), arena.p(bk).data_ptr()
+            h.dw[i], h.db[i] = arena.g(wk).data_ptr(), arena.g(bk).data_ptr()
+        if self.L > 64 or sum(h.width[i] for i in range(len(names))) > 64:
+            raise ValueError("CellHeads: the native heads take a latent of at most 64 and at most 64 outputs in all")
+        self.h, self.n = h, len(names)
+        self._ws: Dict[int, torch.Tensor] = {}
+        self._loss = torch.zeros(1, dtype=torch.float32, device=arena.device)
+
+    def run(self, z: torch.Tensor, targets: torch.Tensor, mask: torch.Tensor, loss_scale: float = 1.0,
+            dz: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """-> the heads' loss (0-dim GPU tensor, overwritten by the next call).  ``dz`` (B, L): receives
+        d(loss_scale * loss)/dz and switches the weight / bias gradients on."""
+        B = z.shape[0]
+        for t, name in ((z, "z"), (targets, "targets"), (mask, "mask")):
+            if not t.is_cuda or t.dtype != torch.float32 or t.dim() != 2 or t.stride(1) != 1 or t.shape[0] != B:
+                raise ValueError(f"CellHeads: {name} must be a 2-D float32 GPU tensor with a contiguous last dim and B rows")
+        if z.shape[1] != self.L or not z.is_contiguous() or targets.shape[1] < self.n or mask.shape[1] < self.n:
+            raise ValueError("CellHeads: z must be contiguous (B, L); targets / mask need one column per head")
+        if dz is not None and (dz.shape != z.shape or not dz.is_contiguous() or dz.dtype != torch.float32 or not dz.is_cuda):
+            raise ValueError("CellHeads: dz must be a contiguous float32 GPU tensor shaped like z")
+        if B not in self._ws:
+            nbytes = self.lib.vae_cell_heads_workspace_bytes(B, self.L, C.byref(self.h))
+            if nbytes <= 0:
+                raise RuntimeError("vae_amd: bad cell-heads configuration")
+            self._ws = {B: torch.empty(nbytes // 4 + 4, dtype=torch.float32, device=z.device)}
+        ws = self._ws[B]
+        rc = self.lib.vae_cell_heads_step(C.byref(self.h), z.data_ptr(), B, self.L, targets.data_ptr(), targets.stride(0),
+                                          mask.data_ptr(), mask.stride(0), float(loss_scale),
+                                          dz.data_ptr() if dz is not None else None, self._loss.data_ptr(), ws.data_ptr(),
+                                          ws.numel() * 4, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        _lib.check(rc, "cell_heads_step")
+        return self._loss[0]
+
+
 class ElboStep:
     """Fused fwd+bwd ELBO step over a ``ParamArena``.
 
@@ -215,12 +282,16 @@ class ElboStep:
     def run(self, x: torch.Tensor, eps_z: torch.Tensor, eps_l: torch.Tensor,
             cell_head_fn: Optional[Callable[[torch.Tensor], torch.Tensor]] = None,
             backward: bool = True, loss_scale: float = 1.0, reducer=None, train: Optional[bool] = None,
-            rng_step: Optional[int] = None, batch_cov: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+            rng_step: Optional[int] = None, batch_cov: Optional[torch.Tensor] = None,
+            cell_heads: Optional[tuple] = None) -> Dict[str, torch.Tensor]:
         """One step.  The returned tensors are VIEWS of the step workspace: they are overwritten by
         the next ``run`` with the same batch size (clone what must survive).
 
         ``train`` (default: ``backward``) switches the dropout masks on; ``rng_step`` picks the mask set
         (default: a counter that advances with every training-mode run).
+
+        ``cell_heads`` = ``(CellHeads, targets (B, P), mask (B, P))``: linear cell-property heads on the native path, instead
+        of ``cell_head_fn``.
 
         ``batch_cov`` (B, n_cov): the masked one-hot batch covariates (``ElboStep.covariates``) of a model built with
         ``batch_properties``; required exactly then."""
@@ -264,7 +335,14 @@ class ElboStep:
 
         # ---------------- cell heads (tiny; torch autograd on z only) ----------------
         use_extra = 0
-        if cell_head_fn is not None:
+        if cell_heads is not None:
+            if cell_head_fn is not None:
+                raise ValueError("ElboStep: give cell_heads or cell_head_fn, not both")
+            heads, t_heads, m_heads = cell_heads
+            out["cell_loss"] = heads.run(v["z"], t_heads, m_heads, loss_scale, v["dz_extra"] if backward else None)
+            out["loss"] = s[4] + out["cell_loss"]
+            use_extra = int(backward)
+        elif cell_head_fn is not None:
             z_leaf = v["z"].detach().clone().requires_grad_(True)
             with torch.enable_grad():
                 cell_loss = cell_head_fn(z_leaf)

@@ -17,7 +17,7 @@ from torch.optim.lr_scheduler import LambdaLR
 from . import ops
 from .arena import ParamArena
 from .distributions import NegativeBinomial, Poisson, ZeroInflatedNegativeBinomial
-from .step import ElboStep
+from .step import CellHeads, ElboStep
 
 
 def cell_loss(cell_pred: Dict[str, torch.Tensor], cell_properties: Dict[str, Any], cell_prop_vals: torch.Tensor,
@@ -309,6 +309,7 @@ class LitVAE(nn.Module):
         self._arena = arena
         self._fused = self._fused_val = None
         self._l1 = None
+        self._native_heads = None
         return arena
 
     def _hidden_dropout(self) -> float:
@@ -354,9 +355,17 @@ class LitVAE(nn.Module):
         if eps_z is None:  # same draw order as the reference: z-encoder noise, then library noise
             eps_z = torch.empty(B, L, device=gene_vals.device).normal_()
             eps_l = torch.empty(B, 1, device=gene_vals.device).normal_()
-        fn = None
+        fn = heads = None
         if self.cell_properties is not None and cell_prop_vals is not None:
-            fn = lambda z: self._cell_loss(self.network.cell_decoder(z), cell_prop_vals, cell_mask, None)  # noqa: E731
+            if getattr(self, "_native_heads", None) is None:   # linear heads (the shipped setting): native kernels
+                try:
+                    self._native_heads = CellHeads(self._arena, self.cell_properties, self.network.cell_decoder.grad_reverse_dict)
+                except ValueError:
+                    self._native_heads = False                  # hidden-layer heads: torch autograd on the (B, L) latent
+            if self._native_heads:
+                heads = (self._native_heads, cell_prop_vals.to(torch.float32), cell_mask.to(torch.float32))
+            else:
+                fn = lambda z: self._cell_loss(self.network.cell_decoder(z), cell_prop_vals, cell_mask, None)  # noqa: E731
         l1 = None
         if self.l1_lambda > 0:   # task.py:491-496; its gradient must be in place before the buckets are reduced
             from .optim import L1Penalty
@@ -368,7 +377,8 @@ class LitVAE(nn.Module):
         cov = None
         if self.batch_properties:   # modules.py:121-130: the masked one-hot block every FCLayers appends to its input
             cov = ElboStep.covariates(batch[3], batch[4], self.network.z_encoder.encoder.batch_dims)
-        out = self._fused.run(gene_vals, eps_z, eps_l, cell_head_fn=fn, loss_scale=loss_scale, reducer=reducer, batch_cov=cov)
+        out = self._fused.run(gene_vals, eps_z, eps_l, cell_head_fn=fn, loss_scale=loss_scale, reducer=reducer, batch_cov=cov,
+                              cell_heads=heads)
         if self.l1_lambda > 0:
             l1 = self._l1.apply(self.l1_lambda * loss_scale)
             out["l1"] = l1
