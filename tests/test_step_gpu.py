@@ -34,16 +34,20 @@ def _cell_head_fn(arena, case, targets, mask):
     return lambda z: cell_loss(dec(z), case["cell_properties"], t, m)
 
 
-def run_step(case, precision=0, backward=True):
+def run_step(case, precision=0, backward=True, native_heads=False):
     from vae_amd.arena import ParamArena
-    from vae_amd.step import ElboStep
+    from vae_amd.step import CellHeads, ElboStep
     case = copy.deepcopy(case)
     params, x, eps_z, eps_l, targets, mask = build_case_inputs(case)
     arena = ParamArena({k: v.float() for k, v in params.items()}, case["n_layers"], case["likelihood"], "cuda")
     step = ElboStep(arena, l_mean=float(np.float32(case["l_mean"])), l_var=float(np.float32(case["l_var"])),
                     kl_weight=case["kl_weight"], gene_loss_coeff=case["gene_loss_coeff"], precision=precision)
-    fn = _cell_head_fn(arena, case, targets, mask) if case["use_cell_loss"] else None
-    out = step.run(x.float().cuda(), eps_z.float().cuda(), eps_l.float().cuda(), cell_head_fn=fn, backward=backward)
+    fn = heads = None
+    if case["use_cell_loss"] and native_heads:   # vae_cell_heads_step instead of torch autograd on the latent
+        heads = (CellHeads(arena, case["cell_properties"], case["grad_reverse"]), targets.float().cuda(), mask.float().cuda())
+    elif case["use_cell_loss"]:
+        fn = _cell_head_fn(arena, case, targets, mask)
+    out = step.run(x.float().cuda(), eps_z.float().cuda(), eps_l.float().cuda(), cell_head_fn=fn, cell_heads=heads, backward=backward)
     torch.cuda.synchronize()
     return case, arena, out
 
@@ -51,11 +55,14 @@ def run_step(case, precision=0, backward=True):
 FP32_MODES = [0, 3]   # ops.FP32 (three bf16 terms, six products) and ops.F16X2 (two scaled f16 terms, three products)
 
 
+@pytest.mark.parametrize("native_heads", [False, True], ids=["torch_heads", "native_heads"])
 @pytest.mark.parametrize("precision", FP32_MODES, ids=["bf16x3", "f16x2"])
 @pytest.mark.parametrize("case", ALL_CASES, ids=[c["name"] for c in ALL_CASES])
-def test_fused_step_matches_reference_goldens(case, precision):
+def test_fused_step_matches_reference_goldens(case, precision, native_heads):
+    if native_heads and not case["use_cell_loss"]:
+        pytest.skip("no cell heads in this case")
     gold = load_golden(f"e2e_{case['name']}.npz")
-    case, arena, out = run_step(case, precision=precision)
+    case, arena, out = run_step(case, precision=precision, native_heads=native_heads)
     G, stride = case["G"], case["sample_stride"]
     for k in ("qz_m", "qz_v", "z", "ql_m", "ql_v", "library", "recon", "kl_z", "kl_l"):
         g = gold[f"f64/out/{k}"]
