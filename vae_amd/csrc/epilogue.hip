@@ -145,6 +145,12 @@ __device__ __forceinline__ int tab_index(float x) {  // 0 for zeros and for coun
   return (x > EPS && xi < KTAB && x == (float)xi) ? xi : 0;
 }
 
+// Count-indexed table entry: base = T + first_row * G + gene (hoisted by the caller), row k < 16: a 24-bit multiply
+// (v_mul_u32_u24, full rate -- the 32-bit v_mul_lo_u32 is a quarter-rate instruction) and an unsigned offset.
+__device__ __forceinline__ float tab_load(const float* __restrict__ base, int k, int G) {
+  return base[__umul24((unsigned)k, (unsigned)G)];
+}
+
 struct Fwd { float ll, a; };
 
 // log(theta + eps) - log(theta + mu + eps) = -log1p(r), r = mu / (theta + eps), evaluated WITHOUT the cancellation of the
@@ -591,10 +597,12 @@ __global__ __launch_bounds__(256) void nbzinb_fwd_tiled_kernel(
   const int g0 = nv > 0 ? g_raw : 0;
   float th[4], lt[4], it[4];
   const float* Tg[4];
+  const float* Tk[4];   // + first row of the count-indexed rows (tab_load)
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int g = min(g0 + j, G - 1);
     Tg[j] = T + g;
+    Tk[j] = T + (int64_t)ROW_LGD * G + g;
     th[j] = T[ROW_TH * G + g];
     lt[j] = T[ROW_LTE * G + g];
     it[j] = T[ROW_ITE * G + g];
@@ -614,13 +622,13 @@ __global__ __launch_bounds__(256) void nbzinb_fwd_tiled_kernel(
   {
     const float xv[4] = {c0.x.x, c0.x.y, c0.x.z, c0.x.w};
 #pragma unroll
-    for (int j = 0; j < 4; ++j) d0[j] = Tg[j][(ROW_LGD + tab_index(xv[j])) * G];
+    for (int j = 0; j < 4; ++j) d0[j] = tab_load(Tk[j], tab_index(xv[j]), G);
   }
   for (int b = b0; b < b1; ++b) {
     if (b + 1 < b1) {
       const float xv[4] = {c1.x.x, c1.x.y, c1.x.z, c1.x.w};
 #pragma unroll
-      for (int j = 0; j < 4; ++j) d1[j] = Tg[j][(ROW_LGD + tab_index(xv[j])) * G];
+      for (int j = 0; j < 4; ++j) d1[j] = tab_load(Tk[j], tab_index(xv[j]), G);
     }
     RowInF c2 = c1;
     if (b + 2 < b1) c2 = load(b + 2);
@@ -737,10 +745,12 @@ __global__ __launch_bounds__(256) void nbzinb_bwd_kernel(
   const int nv = min(4, G - g0);  // valid columns of this thread
   float th[4], lt[4], it[4], acc_t[4], acc_s[4], acc_p[4];
   const float* Tg[4];
+  const float* Tk[4];   // + first row of the count-indexed rows (tab_load)
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int g = min(g0 + j, G - 1);
     Tg[j] = T + g;
+    Tk[j] = T + (int64_t)ROW_DGD * G + g;
     th[j] = T[ROW_TH * G + g]; lt[j] = T[ROW_LTE * G + g]; it[j] = T[ROW_ITE * G + g];
     acc_t[j] = acc_s[j] = acc_p[j] = 0.f;
   }
@@ -755,14 +765,14 @@ __global__ __launch_bounds__(256) void nbzinb_bwd_kernel(
   {
     const float xv[4] = {c0.x.x, c0.x.y, c0.x.z, c0.x.w};
 #pragma unroll
-    for (int j = 0; j < 4; ++j) d0[j] = Tg[j][(ROW_DGD + tab_index(xv[j])) * G];
+    for (int j = 0; j < 4; ++j) d0[j] = tab_load(Tk[j], tab_index(xv[j]), G);
   }
   for (int b = b0; b < b1; ++b) {
     // vmcnt retires in issue order: table loads of cell b+1 FIRST, HBM loads of cell b+2 after them
     if (b + 1 < b1) {
       const float xv[4] = {c1.x.x, c1.x.y, c1.x.z, c1.x.w};
 #pragma unroll
-      for (int j = 0; j < 4; ++j) d1[j] = Tg[j][(ROW_DGD + tab_index(xv[j])) * G];
+      for (int j = 0; j < 4; ++j) d1[j] = tab_load(Tk[j], tab_index(xv[j]), G);
     }
     RowIn c2 = c1;
     if (b + 2 < b1) c2 = load_row<ZINB, VEC, XT, LT>(ls, ld_s, lp, ld_p, x, ld_x, b + 2, g0, G);
