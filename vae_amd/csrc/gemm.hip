@@ -1554,7 +1554,9 @@ int gemm_impl(int layout, int precision, int64_t M, int64_t N, int64_t K, const 
   static const int x3_on = getenv("VAE_GEMM_X3") ? atoi(getenv("VAE_GEMM_X3")) : 1;
   // the split-precision pipeline takes any K % 4 == 0 (zero-filled last K step); the fp32 LDS-DMA one needs K % 32 == 0
   const bool k_ok = (x3_on || precision == 1 || f16x2) ? (K % 4 == 0) : (K % BK == 0);
-  const bool dma_ok = precision <= 1 && !norm && plan.tile == 128 && !no_dma && k_ok && g.vecA && g.vecB &&
+  // (the tile kernels address a tile's rows with 32-bit byte offsets from its origin: 160 rows x ld x 4 B < 2^32)
+  const bool ld_ok = lda < (1 << 22) && ldb < (1 << 22);
+  const bool dma_ok = precision <= 1 && !norm && plan.tile == 128 && !no_dma && k_ok && g.vecA && g.vecB && ld_ok &&
                       (!a_rc || M % 4 == 0) && (!b_rc || N % 4 == 0) && M >= 4 && N >= 4;
   int bm = plan.tile, bn = plan.tile, split = plan.split;
   if (dma_ok) {
