@@ -65,6 +65,26 @@ def test_argument_validation_without_gpu():
     assert rc == 1 and b"in-place" in lib.vae_last_error()
     rc = lib.vae_mixup_counts(fake, 3, 8, 4, 8, fake, fake, C.c_void_p(8192), 8, None)
     assert rc == 1 and b"x_dtype" in lib.vae_last_error()
+    # cell-property heads (row a13): head count, widths, latent size, workspace -- all checked before any launch
+    h = _lib.CellHeads()
+    assert lib.vae_cell_heads_workspace_bytes(64, 30, C.byref(h)) == -1            # no heads
+    h.n_heads = 2
+    h.width[0], h.discrete[0], h.width[1], h.discrete[1] = 3, 1, 1, 0
+    n = lib.vae_cell_heads_workspace_bytes(2048, 30, C.byref(h))
+    assert n >= (2048 * 4 + 2048) * 4                                              # logit gradients + per-cell losses at least
+    rc = lib.vae_cell_heads_step(C.byref(h), fake, 64, 30, fake, 2, fake, 2, 1.0, None, fake, fake, n, None)
+    assert rc == 1 and b"null parameter" in lib.vae_last_error()                   # head weights missing
+    for i in range(2):
+        h.w[i], h.b[i] = 4096, 4096
+    rc = lib.vae_cell_heads_step(C.byref(h), fake, 64, 65, fake, 2, fake, 2, 1.0, None, fake, fake, n, None)
+    assert rc == 1 and b"latent" in lib.vae_last_error()
+    rc = lib.vae_cell_heads_step(C.byref(h), fake, 64, 30, fake, 1, fake, 2, 1.0, None, fake, fake, n, None)
+    assert rc == 1 and b"one column per head" in lib.vae_last_error()
+    rc = lib.vae_cell_heads_step(C.byref(h), fake, 64, 30, fake, 2, fake, 2, 1.0, None, fake, fake, 16, None)
+    assert rc == 1 and b"workspace" in lib.vae_last_error()
+    h.width[1] = 2                                                                  # a continuous head has one output
+    rc = lib.vae_cell_heads_step(C.byref(h), fake, 64, 30, fake, 2, fake, 2, 1.0, None, fake, fake, n, None)
+    assert rc == 1 and b"bad width" in lib.vae_last_error()
 
 
 def test_workspace_queries():
