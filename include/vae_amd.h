@@ -414,7 +414,8 @@ int vae_elbo_step_backward_events(const vae_step_config* cfg, const vae_step_ten
  *   discrete: cross_entropy(logits, int(targets[:, i]), ignore_index = -100, reduction none); else (logits - targets[:, i])^2;
  *   loss = sum_i mean_b(per_i[b] * mask[b, i])    (the mean runs over ALL cells of the batch).
  * Writes *loss (unscaled), and -- dz != NULL -- dz (B, L) = d(loss_scale * loss)/dz summed over the heads with their
- * dz_coeff, dw[i] / db[i] (overwritten).  Two or three launches, fixed summation order.  L <= 64, sum of widths <= 64.  */
+ * dz_coeff, dw[i] / db[i] (overwritten).  Two or three launches, fixed summation order.  L <= 64, sum of widths <= 64.
+ * A discrete target outside [0, width) is treated like ignore_index (no loss, no gradient; torch raises there).        */
 #define VAE_MAX_HEADS 7
 typedef struct {
   int32_t n_heads;
