@@ -43,6 +43,22 @@ int vae_gemm_bf16io(int layout, int io, int64_t M, int64_t N, int64_t K, const v
 // bf16 images of up to two dense fp32 arrays (s1 nullable), one launch (gemm.hip)
 int vae_cast_bf16(const float* s0, void* d0, int64_t n0, const float* s1, void* d1, int64_t n1, void* stream);
 // rowmax[b] / rowsum[b] from the `slots` per-slot statistics a GEMM left (epilogue.hip)
+// Atomic-free column sums of the unfused backward: the row kernels leave per-workgroup partial sums, one launch adds them
+#define VAE_COLPART_MAX 40
+struct VaeColPartList {
+  const float* part[VAE_COLPART_MAX]; float* out[VAE_COLPART_MAX];
+  int blocks[VAE_COLPART_MAX], width[VAE_COLPART_MAX], block0[VAE_COLPART_MAX]; int64_t stride[VAE_COLPART_MAX];
+  int count;
+};
+int vae_colpart_blocks(int64_t B);
+int vae_colpart_reduce(VaeColPartList& z, void* stream);
+int vae_gelu_ln_bwd_part(const float* dout, int64_t ld_dout, const float* pre, int64_t ld_pre, const float* mean,
+                         const float* rstd, const float* gamma, int64_t B, int64_t W, float* dpre, int64_t ld_dpre,
+                         float* dgamma, float* dbeta, float* dbias, float* part, int* blocks_out, void* stream);
+int vae_reparam_kl_bwd_part(const float* dz, int64_t ld_dz, const float* g_kl, float g_kl_scalar, const float* heads,
+                            int64_t ld_heads, const float* eps, int64_t ld_eps, const float* qv, int64_t B, int64_t L,
+                            float prior_mean, float prior_var, float* dheads, int64_t ld_dheads, float* dbias, float* part,
+                            int* blocks_out, void* stream);
 #define VAE_ZERO_MAX_SEGMENTS 48
 struct VaeZeroList { float* ptr[VAE_ZERO_MAX_SEGMENTS]; int64_t n[VAE_ZERO_MAX_SEGMENTS]; int count; };
 int vae_zero_segments(const VaeZeroList& z, void* stream);

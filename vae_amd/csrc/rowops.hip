@@ -189,7 +189,10 @@ __global__ __launch_bounds__(256) void gelu_ln_bwd_kernel(const float* dout, int
                                                           const float* __restrict__ mean, const float* __restrict__ rstd,
                                                           const float* __restrict__ gamma, int B, int W, float* dpre,
                                                           int64_t ld_dpre, float* __restrict__ dgamma,
-                                                          float* __restrict__ dbeta, float* __restrict__ dbias) {
+                                                          float* __restrict__ dbeta, float* __restrict__ dbias,
+                                                          float* __restrict__ part) {
+  // part != null: the workgroup's three column sums go to part[(block * 3 + k) * W + c] (k = 0 dgamma, 1 dbeta, 2 dbias)
+  // for a reduction in block order (vae_colpart_reduce: deterministic, no atomics); else float atomics on the outputs.
   __shared__ float comb[3][4][WAVE];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float ag[NPL], ab[NPL], ap[NPL], gam[NPL];
@@ -267,7 +270,8 @@ __global__ __launch_bounds__(256) void gelu_ln_bwd_kernel(const float* dout, int
       if (c < W) {
         const float v = comb[wave][0][lane] + comb[wave][1][lane] + comb[wave][2][lane] + comb[wave][3][lane];
         float* dst = wave == 0 ? dgamma : (wave == 1 ? dbeta : dbias);
-        if (dst) atomicAdd(dst + c, v);
+        if (part) part[((int64_t)blockIdx.x * 3 + wave) * W + c] = v;
+        else if (dst) atomicAdd(dst + c, v);
       }
     }
   }
@@ -317,7 +321,7 @@ __global__ __launch_bounds__(256) void reparam_kl_bwd_kernel(const float* __rest
                                                              const float* __restrict__ eps, int64_t ld_e,
                                                              const float* __restrict__ qv, int B, int L, float prior_mean,
                                                              float prior_var, float* __restrict__ dheads, int64_t ld_dh,
-                                                             float* __restrict__ dbias) {
+                                                             float* __restrict__ dbias, float* __restrict__ part) {
   __shared__ float comb[4][WAVE + 1];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float col = 0.f, colv = 0.f;  // column sums: lane j < L -> dq_m[j]; colv (lane 0) -> d var pre-activation
@@ -343,13 +347,20 @@ __global__ __launch_bounds__(256) void reparam_kl_bwd_kernel(const float* __rest
       colv += o;
     }
   }
-  if (dbias) {
+  if (dbias || part) {   // part != null: this workgroup's L + 1 column sums, for vae_colpart_reduce
     comb[wave][lane] = col;
     if (lane == 0) comb[wave][WAVE] = colv;
     __syncthreads();
     if (wave == 0) {
-      if (lane < L) atomicAdd(dbias + lane, comb[0][lane] + comb[1][lane] + comb[2][lane] + comb[3][lane]);
-      if (lane == 0) atomicAdd(dbias + L, comb[0][WAVE] + comb[1][WAVE] + comb[2][WAVE] + comb[3][WAVE]);
+      const float a = comb[0][lane] + comb[1][lane] + comb[2][lane] + comb[3][lane];
+      const float v = comb[0][WAVE] + comb[1][WAVE] + comb[2][WAVE] + comb[3][WAVE];
+      if (part) {
+        if (lane < L) part[(int64_t)blockIdx.x * (L + 1) + lane] = a;
+        if (lane == 0) part[(int64_t)blockIdx.x * (L + 1) + L] = v;
+      } else {
+        if (lane < L) atomicAdd(dbias + lane, a);
+        if (lane == 0) atomicAdd(dbias + L, v);
+      }
     }
   }
 }
@@ -637,14 +648,24 @@ extern "C" int vae_gelu_ln_fwd(const float* pre, int64_t ld_pre, const float* ga
 extern "C" int vae_gelu_ln_bwd(const float* dout, int64_t ld_dout, const float* pre, int64_t ld_pre, const float* mean,
                                const float* rstd, const float* gamma, int64_t B, int64_t W, float* dpre, int64_t ld_dpre,
                                float* dgamma, float* dbeta, float* dbias, void* stream) {
+  return vae_gelu_ln_bwd_part(dout, ld_dout, pre, ld_pre, mean, rstd, gamma, B, W, dpre, ld_dpre, dgamma, dbeta, dbias, nullptr,
+                              nullptr, stream);
+}
+int vae_colpart_blocks(int64_t B) { return (int)(((B + 3) / 4) < 256 ? ((B + 3) / 4) : 256); }
+// part != null: no atomics; the (*blocks_out, 3, W) partial column sums are left in `part` (>= 256 * 3 * W floats)
+int vae_gelu_ln_bwd_part(const float* dout, int64_t ld_dout, const float* pre, int64_t ld_pre, const float* mean,
+                         const float* rstd, const float* gamma, int64_t B, int64_t W, float* dpre, int64_t ld_dpre,
+                         float* dgamma, float* dbeta, float* dbias, float* part, int* blocks_out, void* stream) {
   VAE_REQUIRE(dout && pre && mean && rstd && gamma && dpre, "vae_gelu_ln_bwd: null pointer");
   VAE_REQUIRE(B > 0 && W > 0 && W <= MAXW, "vae_gelu_ln_bwd: width %lld not in [1, %d]", (long long)W, MAXW);
   VAE_REQUIRE(ld_dout >= W && ld_pre >= W && ld_dpre >= W, "vae_gelu_ln_bwd: leading dimension too small");
   int blocks = (int)((B + 3) / 4);
   static const int cap = getenv("VAE_LN_BWD_BLOCKS") ? atoi(getenv("VAE_LN_BWD_BLOCKS")) : 256;   // tuning knob
   if (blocks > cap) blocks = cap;
+  if (part) blocks = vae_colpart_blocks(B);
+  if (blocks_out) *blocks_out = blocks;
 #define VAE_LN_BWD(N) hipLaunchKernelGGL(gelu_ln_bwd_kernel<N>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dout, ld_dout, pre, \
-                                         ld_pre, mean, rstd, gamma, (int)B, (int)W, dpre, ld_dpre, dgamma, dbeta, dbias)
+                                         ld_pre, mean, rstd, gamma, (int)B, (int)W, dpre, ld_dpre, dgamma, dbeta, dbias, part)
   if (W <= 2 * WAVE) VAE_LN_BWD(2);
   else if (W <= 4 * WAVE) VAE_LN_BWD(4);
   else if (W <= 8 * WAVE) VAE_LN_BWD(8);
@@ -671,15 +692,25 @@ extern "C" int vae_reparam_kl_bwd(const float* dz, int64_t ld_dz, const float* g
                                   const float* heads, int64_t ld_heads, const float* eps, int64_t ld_eps,
                                   const float* qv, int64_t B, int64_t L, float prior_mean, float prior_var,
                                   float* dheads, int64_t ld_dheads, float* dbias, void* stream) {
+  return vae_reparam_kl_bwd_part(dz, ld_dz, g_kl, g_kl_scalar, heads, ld_heads, eps, ld_eps, qv, B, L, prior_mean, prior_var, dheads,
+                                 ld_dheads, dbias, nullptr, nullptr, stream);
+}
+// part != null: no atomics; the (*blocks_out, L + 1) partial column sums are left in `part` (>= 256 * (L + 1) floats)
+int vae_reparam_kl_bwd_part(const float* dz, int64_t ld_dz, const float* g_kl, float g_kl_scalar, const float* heads,
+                            int64_t ld_heads, const float* eps, int64_t ld_eps, const float* qv, int64_t B, int64_t L,
+                            float prior_mean, float prior_var, float* dheads, int64_t ld_dheads, float* dbias, float* part,
+                            int* blocks_out, void* stream) {
   VAE_REQUIRE(dz && heads && eps && qv && dheads, "vae_reparam_kl_bwd: null pointer");
   VAE_REQUIRE(B > 0 && L > 0 && L <= WAVE && ld_heads >= L + 1 && ld_eps >= L && ld_dz >= L && ld_dheads >= L + 1,
               "vae_reparam_kl_bwd: bad shape");
   int blocks = (int)((B + 3) / 4);
   static const int cap = getenv("VAE_REPARAM_BWD_BLOCKS") ? atoi(getenv("VAE_REPARAM_BWD_BLOCKS")) : 256;   // tuning knob
   if (blocks > cap) blocks = cap;  // few workgroups: one float atomic per column per workgroup
+  if (part) blocks = vae_colpart_blocks(B);
+  if (blocks_out) *blocks_out = blocks;
   hipLaunchKernelGGL(reparam_kl_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dz, ld_dz, g_kl,
                      g_kl_scalar, heads, ld_heads, eps, ld_eps, qv, (int)B, (int)L, prior_mean, prior_var, dheads,
-                     ld_dheads, dbias);
+                     ld_dheads, dbias, part);
   VAE_CHECK_LAUNCH("vae_reparam_kl_bwd");
   return VAE_OK;
 }
@@ -735,6 +766,37 @@ extern "C" int vae_dropout_apply(float* x, int64_t ld, int64_t B, int64_t W, flo
   hipLaunchKernelGGL(dropout_apply_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, ld, B, (int)W,
                      vae_make_dropout(p, seed, step), site);
   VAE_CHECK_LAUNCH("vae_dropout_apply");
+  return VAE_OK;
+}
+
+// out[c] = sum over blocks of part[b * stride + c], in block order: the column sums the unfused backward's row kernels
+// leave per workgroup (gelu_ln_bwd / reparam_kl_bwd with `part`), every entry of the list in ONE launch
+namespace {
+__global__ __launch_bounds__(256) void colpart_reduce_kernel(VaeColPartList z) {
+  int e = 0;
+#pragma unroll
+  for (int i = 1; i < VAE_COLPART_MAX; ++i) e += (i < z.count && (int)blockIdx.x >= z.block0[i]) ? 1 : 0;
+  const int c = ((int)blockIdx.x - z.block0[e]) * 256 + threadIdx.x;
+  if (c >= z.width[e] || !z.out[e]) return;
+  const float* p = z.part[e] + c;
+  const int64_t st = z.stride[e];
+  float s = 0.f;
+  int b = 0;
+  for (; b + 4 <= z.blocks[e]; b += 4) {
+    const float a0 = p[b * st], a1 = p[(b + 1) * st], a2 = p[(b + 2) * st], a3 = p[(b + 3) * st];
+    s = (((s + a0) + a1) + a2) + a3;
+  }
+  for (; b < z.blocks[e]; ++b) s += p[b * st];
+  z.out[e][c] = s;
+}
+}  // namespace
+int vae_colpart_reduce(VaeColPartList& z, void* stream) {
+  if (z.count <= 0) return VAE_OK;
+  VAE_REQUIRE(z.count <= VAE_COLPART_MAX, "vae_colpart_reduce: too many entries");
+  int blocks = 0;
+  for (int i = 0; i < z.count; ++i) { z.block0[i] = blocks; blocks += (z.width[i] + 255) / 256; }
+  hipLaunchKernelGGL(colpart_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, z);
+  VAE_CHECK_LAUNCH("vae_colpart_reduce");
   return VAE_OK;
 }
 

@@ -34,6 +34,8 @@ struct Layout {
   int64_t bwd_slabs;      // column-sum slabs of the epilogue backward (kept until the last launch of the backward)
   int64_t scratch;        // split-K slabs (shared, used by one launch at a time)
   int64_t scratch_floats;
+  int64_t colpart;        // unfused backward only: per-workgroup column sums of its row kernels, added by one launch
+  int64_t colpart_floats;
   int64_t total;
 };
 
@@ -137,6 +139,12 @@ bool make_layout(const vae_step_config& c, Layout* lo) {
   lo->bwd_slabs = take(vae_nbzinb_bwd_workspace_bytes(B, G) / 4 + 4);
   lo->scratch_floats = up4(s / 4 + 4);
   lo->scratch = take(lo->scratch_floats);
+  lo->colpart = -1; lo->colpart_floats = 0;
+  if (!vae_mid_supported(c)) {   // per-workgroup column sums of the unfused backward's row kernels (vae_colpart_reduce)
+    const int64_t nb = vae_colpart_blocks(B);
+    lo->colpart_floats = nb * 3 * (c.n_layers * Hd + (c.n_layers - 1) * H + H + Hl) + nb * (L + 1) + nb * 2;
+    lo->colpart = take(lo->colpart_floats);
+  }
   lo->total = off;
   return true;
 }
@@ -475,23 +483,36 @@ extern "C" int vae_elbo_step_backward_events(const vae_step_config* cfg, const v
                          ws + lo.dpx, ws + lo.dheads_z, ws + lo.dheads_l, ws + lo.dbet_e, ws + lo.dgam_e,
                          ws + lo.dpre_enc0, k.am(AM_DPRE), k.hb() ? k.h16(lo.dpre16) : nullptr, &cr, stream));
   } else {
-    // the unfused kernels ACCUMULATE the LayerNorm / bias gradients with atomics: clear them first
-    VaeZeroList zl;
-    zl.count = 0;
-    auto zero = [&](float* q, int64_t n) {   // collected, cleared by one launch below
-      if (!q || n <= 0) return VAE_OK;
-      if (zl.count >= VAE_ZERO_MAX_SEGMENTS) return vae_set_error(VAE_ERR_ARG, "vae_elbo_step_backward: too many gradient segments");
-      zl.ptr[zl.count] = q; zl.n[zl.count] = n; ++zl.count;
+    // The row kernels of the unfused backward leave their LayerNorm / bias column sums per workgroup in lo.colpart; ONE
+    // launch at the end adds them in workgroup order and overwrites the gradients: no float atomics, no clearing, and the
+    // same bits on every run.
+    VaeColPartList cp;
+    cp.count = 0;
+    int64_t cp_used = 0;
+    float* cp_cur = nullptr;
+    int cp_blocks = 0;
+    auto cp_take = [&](int64_t floats) {   // the next partial buffer (capacity is what make_layout summed)
+      cp_cur = cp_used + floats <= lo.colpart_floats ? ws + lo.colpart + cp_used : nullptr;
+      cp_used += floats;
+      return cp_cur ? VAE_OK : vae_set_error(VAE_ERR_ARG, "vae_elbo_step_backward: column-sum workspace too small");
+    };
+    auto cp_add = [&](int64_t first, int64_t width, int64_t stride, float* out) {
+      if (!out) return VAE_OK;
+      if (cp.count >= VAE_COLPART_MAX) return vae_set_error(VAE_ERR_ARG, "vae_elbo_step_backward: too many gradient segments");
+      cp.part[cp.count] = cp_cur + first; cp.out[cp.count] = out; cp.blocks[cp.count] = cp_blocks;
+      cp.width[cp.count] = (int)width; cp.stride[cp.count] = stride; ++cp.count;
       return VAE_OK;
     };
-    for (int n = 0; n < c.n_layers; ++n) {
-      TRY(zero(g->dec_ln_g[n], Hd)); TRY(zero(g->dec_ln_b[n], Hd)); TRY(zero(g->dec_b[n], Hd));
-      TRY(zero(g->encz_ln_g[n], H)); TRY(zero(g->encz_ln_b[n], H));
-      if (n > 0) TRY(zero(g->encz_b[n], H));
-    }
-    TRY(zero(g->encl_ln_g, Hl)); TRY(zero(g->encl_ln_b, Hl)); TRY(zero(g->enc_b0, HE));
-    TRY(zero(g->hz_b, L + 1)); TRY(zero(g->hl_b, 2));
-    TRY(vae_zero_segments(zl, stream));
+    const int64_t cp_nb = vae_colpart_blocks(B);
+    // GELU/LayerNorm backward of one layer: dgamma / dbeta / dbias through the partial buffer
+    auto ln_bwd = [&](const float* dout, int64_t ld_dout, const float* pre, int64_t ld_pre, const float* mean, const float* rstd,
+                      const float* gamma, int64_t W, float* dpre, int64_t ld_dpre, float* dgamma, float* dbeta, float* dbias) {
+      TRY(cp_take(cp_nb * 3 * W));
+      TRY(vae_gelu_ln_bwd_part(dout, ld_dout, pre, ld_pre, mean, rstd, gamma, B, W, dpre, ld_dpre, dgamma, dbeta, dbias, cp_cur,
+                               &cp_blocks, stream));
+      TRY(cp_add(0, W, 3 * W, dgamma)); TRY(cp_add(W, W, 3 * W, dbeta)); TRY(cp_add(2 * W, W, 3 * W, dbias));
+      return VAE_OK;
+    };
     if (k.hb())
       TRY(vae_gemm_bf16io(VAE_NN, VAE_IO_A_BF16 | VAE_IO_B_BF16, B, Hd, NH, logits, NH, k.h16(lo.w_heads16), Hd, ws + lo.dpx, Hd, nullptr,
                           ws + lo.scratch, lo.scratch_floats * 4, nullptr, nullptr, stream));
@@ -504,8 +525,8 @@ extern "C" int vae_elbo_step_backward_events(const vae_step_config* cfg, const v
       const float* inp = n == 0 ? ws + lo.z : ws + lo.dec_h[n - 1];
       const int64_t kin = n == 0 ? L : Hd;
       TRY(k.drop(dcur, Hd, Hd, VAE_SITE_DEC(n)));
-      TRY(vae_gelu_ln_bwd(dcur, Hd, ws + lo.dec_pre[n], Hd, ws + lo.ln_md[n], ws + lo.ln_rd[n], p->dec_ln_g[n], B, Hd, dcur,
-                          Hd, g->dec_ln_g[n], g->dec_ln_b[n], g->dec_b[n], stream));
+      TRY(ln_bwd(dcur, Hd, ws + lo.dec_pre[n], Hd, ws + lo.ln_md[n], ws + lo.ln_rd[n], p->dec_ln_g[n], Hd, dcur, Hd,
+                 g->dec_ln_g[n], g->dec_ln_b[n], g->dec_b[n]));
       const int64_t ldwd = n == 0 ? ld_dec_w0(c) : Hd;
       TRY(k.gemm(VAE_TN, Hd, kin, B, dcur, Hd, inp, kin, g->dec_w[n], ldwd, nullptr, nullptr, 0));
       if (n == 0 && k.cov())   // gradient of the covariate columns: dpre^T cov
@@ -522,10 +543,14 @@ extern "C" int vae_elbo_step_backward_events(const vae_step_config* cfg, const v
     // reparameterisation / KL backward (cell-head gradient enters through dz_extra)
     const float* dz = ws + lo.dz;
     if (use_dz_extra) TRY(vae_add_inplace(ws + lo.dz_extra, ws + lo.dz, B * L, stream));
-    TRY(vae_reparam_kl_bwd(dz, L, nullptr, g_kl, ws + lo.heads_z, L + 1, eps_z, L, ws + lo.qz_v, B, L, 0.f, 1.f,
-                           ws + lo.dheads_z, L + 1, g->hz_b, stream));
-    TRY(vae_reparam_kl_bwd(ws + lo.dlibrary, 1, nullptr, g_kl, ws + lo.heads_l, 2, eps_l, 1, ws + lo.ql_v, B, 1, c.l_mean,
-                           c.l_var, ws + lo.dheads_l, 2, g->hl_b, stream));
+    TRY(cp_take(cp_nb * (L + 1)));
+    TRY(vae_reparam_kl_bwd_part(dz, L, nullptr, g_kl, ws + lo.heads_z, L + 1, eps_z, L, ws + lo.qz_v, B, L, 0.f, 1.f,
+                                ws + lo.dheads_z, L + 1, g->hz_b, cp_cur, &cp_blocks, stream));
+    TRY(cp_add(0, L + 1, L + 1, g->hz_b));
+    TRY(cp_take(cp_nb * 2));
+    TRY(vae_reparam_kl_bwd_part(ws + lo.dlibrary, 1, nullptr, g_kl, ws + lo.heads_l, 2, eps_l, 1, ws + lo.ql_v, B, 1, c.l_mean,
+                                c.l_var, ws + lo.dheads_l, 2, g->hl_b, cp_cur, &cp_blocks, stream));
+    TRY(cp_add(0, 2, 2, g->hl_b));
     const float* hz = c.n_layers > 1 ? ws + lo.encz_h[c.n_layers - 1] : ws + lo.h_enc0;
     const int64_t ld_hz = c.n_layers > 1 ? H : HE;
     TRY(k.gemm(VAE_TN, L + 1, H, B, ws + lo.dheads_z, L + 1, hz, ld_hz, g->hz_w, H, nullptr, nullptr, 0));
@@ -539,8 +564,8 @@ extern "C" int vae_elbo_step_backward_events(const vae_step_config* cfg, const v
       const float* inp = n == 1 ? ws + lo.h_enc0 : ws + lo.encz_h[n - 1];
       const int64_t ld_in = n == 1 ? HE : H;
       TRY(k.drop(dh, H, H, VAE_SITE_ENC_Z(n)));
-      TRY(vae_gelu_ln_bwd(dh, H, ws + lo.encz_pre[n], H, ws + lo.ln_mz[n], ws + lo.ln_rz[n], p->encz_ln_g[n], B, H, dh, H,
-                          g->encz_ln_g[n], g->encz_ln_b[n], g->encz_b[n], stream));
+      TRY(ln_bwd(dh, H, ws + lo.encz_pre[n], H, ws + lo.ln_mz[n], ws + lo.ln_rz[n], p->encz_ln_g[n], H, dh, H, g->encz_ln_g[n],
+                 g->encz_ln_b[n], g->encz_b[n]));
       TRY(k.gemm(VAE_TN, H, H, B, dh, H, inp, ld_in, g->encz_w[n], H, nullptr, nullptr, 0));
       float* nxt = ws + lo.encz_pre[n];  // free from here on
       TRY(k.gemm(VAE_NN, B, H, H, dh, H, p->encz_w[n], H, nxt, H, nullptr, nullptr, 0));
@@ -548,10 +573,11 @@ extern "C" int vae_elbo_step_backward_events(const vae_step_config* cfg, const v
     }
     // first encoder layer: GELU/LayerNorm backward of both halves, then ONE wgrad over the counts
     TRY(k.drop(dh, H, H, VAE_SITE_ENC_Z(0)));
-    TRY(vae_gelu_ln_bwd(dh, H, ws + lo.pre_enc0, HE, ws + lo.ln_mz[0], ws + lo.ln_rz[0], p->encz_ln_g[0], B, H,
-                        ws + lo.dpre_enc0, HE, g->encz_ln_g[0], g->encz_ln_b[0], g->enc_b0, stream));
-    TRY(vae_gelu_ln_bwd(ws + lo.dpre_enc0 + H, HE, ws + lo.pre_enc0 + H, HE, ws + lo.ln_ml, ws + lo.ln_rl, p->encl_ln_g, B,
-                        Hl, ws + lo.dpre_enc0 + H, HE, g->encl_ln_g, g->encl_ln_b, g->enc_b0 + H, stream));
+    TRY(ln_bwd(dh, H, ws + lo.pre_enc0, HE, ws + lo.ln_mz[0], ws + lo.ln_rz[0], p->encz_ln_g[0], H, ws + lo.dpre_enc0, HE,
+               g->encz_ln_g[0], g->encz_ln_b[0], g->enc_b0));
+    TRY(ln_bwd(ws + lo.dpre_enc0 + H, HE, ws + lo.pre_enc0 + H, HE, ws + lo.ln_ml, ws + lo.ln_rl, p->encl_ln_g, Hl,
+               ws + lo.dpre_enc0 + H, HE, g->encl_ln_g, g->encl_ln_b, g->enc_b0 ? g->enc_b0 + H : nullptr));
+    TRY(vae_colpart_reduce(cp, stream));
     if (k.fx()) {
       TRY(vae_absmax_partials(ws + lo.dpre_enc0, B, HE, HE, k.am(AM_DPRE), stream));
     }
