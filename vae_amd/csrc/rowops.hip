@@ -772,29 +772,40 @@ extern "C" int vae_dropout_apply(float* x, int64_t ld, int64_t B, int64_t W, flo
 // out[c] = sum over blocks of part[b * stride + c], in block order: the column sums the unfused backward's row kernels
 // leave per workgroup (gelu_ln_bwd / reparam_kl_bwd with `part`), every entry of the list in ONE launch
 namespace {
+// A workgroup owns 64 columns of one entry; its four waves each add a quarter of the partial rows (16 loads in flight:
+// the walk is one load latency per batch) and wave 0 adds the four quarters in order.
 __global__ __launch_bounds__(256) void colpart_reduce_kernel(VaeColPartList z) {
+  __shared__ float quarter[4][WAVE];
   int e = 0;
 #pragma unroll
   for (int i = 1; i < VAE_COLPART_MAX; ++i) e += (i < z.count && (int)blockIdx.x >= z.block0[i]) ? 1 : 0;
-  const int c = ((int)blockIdx.x - z.block0[e]) * 256 + threadIdx.x;
-  if (c >= z.width[e] || !z.out[e]) return;
-  const float* p = z.part[e] + c;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = ((int)blockIdx.x - z.block0[e]) * WAVE + lane;
+  const bool ok = c < z.width[e];
+  const float* p = z.part[e] + (ok ? c : 0);
   const int64_t st = z.stride[e];
+  const int per = (z.blocks[e] + 3) / 4;
+  const int b0 = wave * per, b1 = min(z.blocks[e], b0 + per);
   float s = 0.f;
-  int b = 0;
-  for (; b + 4 <= z.blocks[e]; b += 4) {
-    const float a0 = p[b * st], a1 = p[(b + 1) * st], a2 = p[(b + 2) * st], a3 = p[(b + 3) * st];
-    s = (((s + a0) + a1) + a2) + a3;
+  int b = b0;
+  for (; b + 16 <= b1; b += 16) {
+    float a[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) a[j] = p[(b + j) * st];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) s += a[j];
   }
-  for (; b < z.blocks[e]; ++b) s += p[b * st];
-  z.out[e][c] = s;
+  for (; b < b1; ++b) s += p[b * st];
+  quarter[wave][lane] = s;
+  __syncthreads();
+  if (wave == 0 && ok) z.out[e][c] = ((quarter[0][lane] + quarter[1][lane]) + quarter[2][lane]) + quarter[3][lane];
 }
 }  // namespace
 int vae_colpart_reduce(VaeColPartList& z, void* stream) {
   if (z.count <= 0) return VAE_OK;
   VAE_REQUIRE(z.count <= VAE_COLPART_MAX, "vae_colpart_reduce: too many entries");
   int blocks = 0;
-  for (int i = 0; i < z.count; ++i) { z.block0[i] = blocks; blocks += (z.width[i] + 255) / 256; }
+  for (int i = 0; i < z.count; ++i) { z.block0[i] = blocks; blocks += (z.width[i] + WAVE - 1) / WAVE; }
   hipLaunchKernelGGL(colpart_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, z);
   VAE_CHECK_LAUNCH("vae_colpart_reduce");
   return VAE_OK;
