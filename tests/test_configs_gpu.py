@@ -272,19 +272,20 @@ def test_per_gene_row_gradient_accuracy_over_24_octaves(precision):
               {a: (f"{b:.2e}" if isinstance(b, float) else b) for a, b in val.items()})
 
 
-@pytest.mark.parametrize("counts", ["f32", "u8"])
-def test_bf16_storage_with_gene_dropout_and_inference(counts):
+@pytest.mark.parametrize("counts,n_layers", [("f32", 1), ("u8", 1), ("f32", 2)])
+def test_bf16_storage_with_gene_dropout_and_inference(counts, n_layers):
     """A bf16-mode step whose shapes are on the tile pipeline keeps xn, the logits and their gradients as bf16:
     with GeneDropout (one encoder product per encoder, the masked xn also bf16) and hidden dropout vs the bf16 oracle fed
-    the host-regenerated masks; then the inference step's px_rate (vae_elbo_step_px_rate reads the bf16 logits)."""
+    the host-regenerated masks; then the inference step's px_rate (vae_elbo_step_px_rate reads the bf16 logits).  Two layers:
+    the launch sequence, where the bf16 images of px / dpre come from the dropout and LayerNorm launches."""
     from oracle import vae_oracle as O
     from vae_amd.arena import ParamArena
     from vae_amd.step import ElboStep
     from helpers import dropout_multiplier, gene_dropout_keep
     B, G, H, Hd, Hl, L = 256, 4000, 128, 128, 128, 10
     p_in, p_hid, alpha, seed = 0.5, 0.25, 0.95, 777
-    p = O.init_params(G, H, Hd, Hl, L, 1, seed=19)
-    arena = ParamArena(p, 1, "zinb", "cuda")
+    p = O.init_params(G, H, Hd, Hl, L, n_layers, seed=19)
+    arena = ParamArena(p, n_layers, "zinb", "cuda")
     gen = torch.Generator().manual_seed(20)
     step = ElboStep(arena, l_mean=5.0, l_var=1.5, dropout_rate=p_hid, seed=seed, input_dropout_rate=p_in,
                     input_dropout_alpha=alpha, precision=1)
@@ -297,11 +298,11 @@ def test_bf16_storage_with_gene_dropout_and_inference(counts):
     thr = out["gene_threshold"].cpu().numpy().view(np.uint32)
     keep = gene_dropout_keep(thr, seed, 5, B)
     x_z = x * torch.from_numpy(keep).float()
-    masks = {"z_encoder": [torch.from_numpy(dropout_multiplier(p_hid, seed, 5, 0, B, H)).float()],
-             "decoder": [torch.from_numpy(dropout_multiplier(p_hid, seed, 5, 2, B, Hd)).float()]}
-    kw = dict(n_layers=1, likelihood="zinb", l_mean=5.0, l_var=1.5, gemm_dtype=torch.bfloat16, logits_bf16=True)
+    masks = {"z_encoder": [torch.from_numpy(dropout_multiplier(p_hid, seed, 5, 4 * n, B, H)).float() for n in range(n_layers)],
+             "decoder": [torch.from_numpy(dropout_multiplier(p_hid, seed, 5, 4 * n + 2, B, Hd)).float() for n in range(n_layers)]}
+    kw = dict(n_layers=n_layers, likelihood="zinb", l_mean=5.0, l_var=1.5, gemm_dtype=torch.bfloat16, logits_bf16=True)
     o_out, o_grads = O.training_step_with_grads(p, x, eps_z, eps_l, drop_masks=masks, x_z=x_z, **kw)
-    _check(o_out, o_grads, out, arena, TOL_CELL_BF16, TOL_GRAD_BF16, 20)
+    _check(o_out, o_grads, out, arena, TOL_CELL_BF16, TOL_GRAD_BF16, 20 if n_layers == 1 else 28)
     # inference: forward only, no masks; the exported mean is the one the likelihood used
     ev = step.infer(xd, eps_z.cuda(), eps_l.cuda(), want_px_rate=True)
     o_plain = O.training_step(p, x, eps_z, eps_l, **kw)

@@ -54,7 +54,12 @@ int vae_colpart_blocks(int64_t B);
 int vae_colpart_reduce(VaeColPartList& z, void* stream);
 int vae_gelu_ln_bwd_part(const float* dout, int64_t ld_dout, const float* pre, int64_t ld_pre, const float* mean,
                          const float* rstd, const float* gamma, int64_t B, int64_t W, float* dpre, int64_t ld_dpre,
-                         float* dgamma, float* dbeta, float* dbias, float* part, int* blocks_out, void* stream);
+                         float* dgamma, float* dbeta, float* dbias, float* part, int* blocks_out, uint16_t* dpre16, int64_t ld16,
+                         void* stream);
+int vae_gelu_ln_fwd_ex(const float* pre, int64_t ld_pre, const float* gamma, const float* beta, int64_t B, int64_t W, float* out,
+                       int64_t ld_out, float* mean, float* rstd, uint16_t* out16, int64_t ld16, void* stream);
+int vae_dropout_apply_ex(float* x, int64_t ld, int64_t B, int64_t W, float p, uint64_t seed, uint32_t step, uint32_t site,
+                         uint16_t* x16, int64_t ld16, void* stream);
 int vae_reparam_kl_bwd_part(const float* dz, int64_t ld_dz, const float* g_kl, float g_kl_scalar, const float* heads,
                             int64_t ld_heads, const float* eps, int64_t ld_eps, const float* qv, int64_t B, int64_t L,
                             float prior_mean, float prior_var, float* dheads, int64_t ld_dheads, float* dbias, float* part,

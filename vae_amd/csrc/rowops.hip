@@ -135,6 +135,10 @@ __global__ __launch_bounds__(256) void normalize_rows_kernel(const XT* __restric
 // GELU(erf) -> LayerNorm(eps 1e-5, affine) forward (FCLayers, modules.py:112-114).
 // `pre` = Linear output incl. bias.  Saves mean / rstd of the GELU output per row.
 // ---------------------------------------------------------------------------------------
+__device__ __forceinline__ uint16_t bf16_bits(float v) {   // nearest even, as vae_cast_bf16
+  const __bf16 h = (__bf16)v;
+  return __builtin_bit_cast(uint16_t, h);
+}
 __device__ __forceinline__ float gelu_f(float v) { return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f)); }
 __device__ __forceinline__ float gelu_grad(float v) {
   const float cdf = 0.5f * (1.f + erff(v * 0.70710678118654752440f));
@@ -146,7 +150,9 @@ template <int NPL>
 __global__ __launch_bounds__(256) void gelu_ln_fwd_kernel(const float* __restrict__ pre, int64_t ld_pre,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           int B, int W, float* __restrict__ out, int64_t ld_out,
-                                                          float* __restrict__ mean, float* __restrict__ rstd) {
+                                                          float* __restrict__ mean, float* __restrict__ rstd,
+                                                          uint16_t* __restrict__ out16, int64_t ld16) {
+  // out16 != null: the output again as bf16 (nearest even), for a bf16-storage product that reads it next
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= B) return;
@@ -172,7 +178,11 @@ __global__ __launch_bounds__(256) void gelu_ln_fwd_kernel(const float* __restric
 #pragma unroll
   for (int j = 0; j < NPL; ++j) {
     const int c = lane + j * WAVE;
-    if (c < W) o[c] = (g[j] - mu) * rs * gamma[c] + beta[c];
+    if (c < W) {
+      const float v = (g[j] - mu) * rs * gamma[c] + beta[c];
+      o[c] = v;
+      if (out16) out16[(int64_t)row * ld16 + c] = bf16_bits(v);
+    }
   }
   if (lane == 0) {
     mean[row] = mu;
@@ -190,7 +200,9 @@ __global__ __launch_bounds__(256) void gelu_ln_bwd_kernel(const float* dout, int
                                                           const float* __restrict__ gamma, int B, int W, float* dpre,
                                                           int64_t ld_dpre, float* __restrict__ dgamma,
                                                           float* __restrict__ dbeta, float* __restrict__ dbias,
-                                                          float* __restrict__ part) {
+                                                          float* __restrict__ part, uint16_t* __restrict__ dpre16,
+                                                          int64_t ld16) {
+  // dpre16 != null: dpre again as bf16 (nearest even), for the bf16-storage weight-gradient product
   // part != null: the workgroup's three column sums go to part[(block * 3 + k) * W + c] (k = 0 dgamma, 1 dbeta, 2 dbias)
   // for a reduction in block order (vae_colpart_reduce: deterministic, no atomics); else float atomics on the outputs.
   __shared__ float comb[3][4][WAVE];
@@ -251,6 +263,7 @@ __global__ __launch_bounds__(256) void gelu_ln_bwd_kernel(const float* dout, int
         const float dg = rs * (dx[j] - s1 - xh[j] * s2);
         const float v = dg * gelu_grad(pv[j]);
         o[c] = v;
+        if (dpre16) dpre16[(int64_t)row * ld16 + c] = bf16_bits(v);
         ap[j] += v;
       }
     }
@@ -631,11 +644,17 @@ extern "C" int vae_normalize_rows_u8(const uint8_t* x, int64_t ldx, int64_t B, i
 
 extern "C" int vae_gelu_ln_fwd(const float* pre, int64_t ld_pre, const float* gamma, const float* beta, int64_t B,
                                int64_t W, float* out, int64_t ld_out, float* mean, float* rstd, void* stream) {
+  return vae_gelu_ln_fwd_ex(pre, ld_pre, gamma, beta, B, W, out, ld_out, mean, rstd, nullptr, 0, stream);
+}
+// out16 != null: the output again as bf16 with row stride ld16
+int vae_gelu_ln_fwd_ex(const float* pre, int64_t ld_pre, const float* gamma, const float* beta, int64_t B, int64_t W, float* out,
+                       int64_t ld_out, float* mean, float* rstd, uint16_t* out16, int64_t ld16, void* stream) {
+  VAE_REQUIRE(!out16 || ld16 >= W, "vae_gelu_ln_fwd: bf16 leading dimension too small");
   VAE_REQUIRE(pre && gamma && beta && out && mean && rstd, "vae_gelu_ln_fwd: null pointer");
   VAE_REQUIRE(B > 0 && W > 0 && W <= MAXW, "vae_gelu_ln_fwd: width %lld not in [1, %d]", (long long)W, MAXW);
   VAE_REQUIRE(ld_pre >= W && ld_out >= W, "vae_gelu_ln_fwd: leading dimension too small");
 #define VAE_LN_FWD(N) hipLaunchKernelGGL(gelu_ln_fwd_kernel<N>, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, (hipStream_t)stream, pre, \
-                                         ld_pre, gamma, beta, (int)B, (int)W, out, ld_out, mean, rstd)
+                                         ld_pre, gamma, beta, (int)B, (int)W, out, ld_out, mean, rstd, out16, ld16)
   if (W <= 2 * WAVE) VAE_LN_FWD(2);
   else if (W <= 4 * WAVE) VAE_LN_FWD(4);
   else if (W <= 8 * WAVE) VAE_LN_FWD(8);
@@ -649,13 +668,16 @@ extern "C" int vae_gelu_ln_bwd(const float* dout, int64_t ld_dout, const float* 
                                const float* rstd, const float* gamma, int64_t B, int64_t W, float* dpre, int64_t ld_dpre,
                                float* dgamma, float* dbeta, float* dbias, void* stream) {
   return vae_gelu_ln_bwd_part(dout, ld_dout, pre, ld_pre, mean, rstd, gamma, B, W, dpre, ld_dpre, dgamma, dbeta, dbias, nullptr,
-                              nullptr, stream);
+                              nullptr, nullptr, 0, stream);
 }
 int vae_colpart_blocks(int64_t B) { return (int)(((B + 3) / 4) < 256 ? ((B + 3) / 4) : 256); }
 // part != null: no atomics; the (*blocks_out, 3, W) partial column sums are left in `part` (>= 256 * 3 * W floats)
+// dpre16 != null: dpre again as bf16 with row stride ld16
 int vae_gelu_ln_bwd_part(const float* dout, int64_t ld_dout, const float* pre, int64_t ld_pre, const float* mean,
                          const float* rstd, const float* gamma, int64_t B, int64_t W, float* dpre, int64_t ld_dpre,
-                         float* dgamma, float* dbeta, float* dbias, float* part, int* blocks_out, void* stream) {
+                         float* dgamma, float* dbeta, float* dbias, float* part, int* blocks_out, uint16_t* dpre16, int64_t ld16,
+                         void* stream) {
+  VAE_REQUIRE(!dpre16 || ld16 >= W, "vae_gelu_ln_bwd: bf16 leading dimension too small");
   VAE_REQUIRE(dout && pre && mean && rstd && gamma && dpre, "vae_gelu_ln_bwd: null pointer");
   VAE_REQUIRE(B > 0 && W > 0 && W <= MAXW, "vae_gelu_ln_bwd: width %lld not in [1, %d]", (long long)W, MAXW);
   VAE_REQUIRE(ld_dout >= W && ld_pre >= W && ld_dpre >= W, "vae_gelu_ln_bwd: leading dimension too small");
@@ -665,7 +687,7 @@ int vae_gelu_ln_bwd_part(const float* dout, int64_t ld_dout, const float* pre, i
   if (part) blocks = vae_colpart_blocks(B);
   if (blocks_out) *blocks_out = blocks;
 #define VAE_LN_BWD(N) hipLaunchKernelGGL(gelu_ln_bwd_kernel<N>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dout, ld_dout, pre, \
-                                         ld_pre, mean, rstd, gamma, (int)B, (int)W, dpre, ld_dpre, dgamma, dbeta, dbias, part)
+                                         ld_pre, mean, rstd, gamma, (int)B, (int)W, dpre, ld_dpre, dgamma, dbeta, dbias, part, dpre16, ld16)
   if (W <= 2 * WAVE) VAE_LN_BWD(2);
   else if (W <= 4 * WAVE) VAE_LN_BWD(4);
   else if (W <= 8 * WAVE) VAE_LN_BWD(8);
@@ -747,24 +769,32 @@ int vae_elbo_reduce_parts(const float* part, int strips, float* ll, float* S, co
 // x[b, c] *= keep(b, c) / (1 - p): nn.Dropout (modules.py:115) with the mask of philox.h.  Applied to an
 // activation in the forward pass and to the gradient arriving at the same place in the backward pass.
 __global__ __launch_bounds__(256) void dropout_apply_kernel(float* __restrict__ x, int64_t ld, int64_t B, int W, VaeDropout d,
-                                                            uint32_t site) {
+                                                            uint32_t site, uint16_t* __restrict__ x16, int64_t ld16) {
   const int64_t total = B * W;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
     const int64_t b = i / W;
     const int c = (int)(i - b * W);
-    x[b * ld + c] *= d.mult(site, b, W, c);
+    const float v = x[b * ld + c] * d.mult(site, b, W, c);
+    x[b * ld + c] = v;
+    if (x16) x16[b * ld16 + c] = bf16_bits(v);   // the result again as bf16
   }
 }
 
 extern "C" int vae_dropout_apply(float* x, int64_t ld, int64_t B, int64_t W, float p, uint64_t seed, uint32_t step,
                                  uint32_t site, void* stream) {
+  return vae_dropout_apply_ex(x, ld, B, W, p, seed, step, site, nullptr, 0, stream);
+}
+// x16 != null (and p > 0): the result again as bf16 with row stride ld16; p == 0 launches nothing and writes nothing
+int vae_dropout_apply_ex(float* x, int64_t ld, int64_t B, int64_t W, float p, uint64_t seed, uint32_t step, uint32_t site,
+                         uint16_t* x16, int64_t ld16, void* stream) {
+  VAE_REQUIRE(!x16 || ld16 >= W, "vae_dropout_apply: bf16 leading dimension too small");
   VAE_REQUIRE(x && B > 0 && W > 0 && W < (1 << 30) && ld >= W, "vae_dropout_apply: bad arguments");
   VAE_REQUIRE(p >= 0.f && p < 1.f, "vae_dropout_apply: p must be in [0, 1), got %g", (double)p);
   if (p == 0.f) return VAE_OK;
   int blocks = (int)((B * W + 255) / 256);
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(dropout_apply_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, ld, B, (int)W,
-                     vae_make_dropout(p, seed, step), site);
+                     vae_make_dropout(p, seed, step), site, x16, ld16);
   VAE_CHECK_LAUNCH("vae_dropout_apply");
   return VAE_OK;
 }

@@ -362,9 +362,13 @@ extern "C" int vae_elbo_step_forward(const vae_step_config* cfg, const vae_step_
       TRY(k.gemm(VAE_NT, B, Hd, kin, px, kin, p->dec_w[n], ldwd, ws + lo.dec_pre[n], Hd, p->dec_b[n], nullptr, 0));
       if (n == 0 && k.cov())   // the decoder's covariate columns (modules.py:400,130)
         TRY(k.gemm(VAE_NT, B, Hd, c.n_cov, c.batch_cov, c.ld_cov, p->dec_w[0] + L, ldwd, ws + lo.dec_pre[0], Hd, nullptr, nullptr, 1));
-      TRY(vae_gelu_ln_fwd(ws + lo.dec_pre[n], Hd, p->dec_ln_g[n], p->dec_ln_b[n], B, Hd, ws + lo.dec_h[n], Hd,
-                          ws + lo.ln_md[n], ws + lo.ln_rd[n], stream));
-      TRY(k.drop(ws + lo.dec_h[n], Hd, Hd, VAE_SITE_DEC(n)));
+      // the last layer's output again as bf16 for the decoder-head product of a bf16-storage step: written by the dropout
+      // launch when there is one, else by the LayerNorm kernel
+      uint16_t* px16 = (k.hb() && n == c.n_layers - 1) ? k.h16(lo.px16) : nullptr;
+      const bool dropped = c.dropout_rate > 0.f;
+      TRY(vae_gelu_ln_fwd_ex(ws + lo.dec_pre[n], Hd, p->dec_ln_g[n], p->dec_ln_b[n], B, Hd, ws + lo.dec_h[n], Hd,
+                             ws + lo.ln_md[n], ws + lo.ln_rd[n], dropped ? nullptr : px16, Hd, stream));
+      TRY(vae_dropout_apply_ex(ws + lo.dec_h[n], Hd, B, Hd, c.dropout_rate, c.rng_seed, c.rng_step, VAE_SITE_DEC(n), px16, Hd, stream));
       px = ws + lo.dec_h[n];
       kin = Hd;
     }
@@ -376,8 +380,7 @@ extern "C" int vae_elbo_step_forward(const vae_step_config* cfg, const vae_step_
   VaeGemmRowStats rs{ws + lo.stat_m, ws + lo.stat_s, (int)G, lo.stat_cap, 0};
   static const bool no_gemm_stats = getenv("VAE_NO_GEMM_STATS") != nullptr;   // A/B knob
   if (k.hb()) {
-    if (!vae_mid_supported(c))   // (the fused middle writes the bf16 image of its output itself)
-      TRY(vae_cast_bf16(px, k.h16(lo.px16), B * Hd, nullptr, nullptr, 0, stream));
+    // (px16, the bf16 image of px: left by the fused middle or by the last hidden layer's LayerNorm / dropout launch)
     TRY(vae_gemm_bf16io(VAE_NT, VAE_IO_A_BF16 | VAE_IO_B_BF16 | VAE_IO_C_BF16, B, NH, Hd, k.h16(lo.px16), Hd, k.h16(lo.w_heads16), Hd,
                         ws + lo.logits, NH, p->heads_b, ws + lo.scratch, lo.scratch_floats * 4, nullptr, no_gemm_stats ? nullptr : &rs,
                         stream));
@@ -506,10 +509,11 @@ extern "C" int vae_elbo_step_backward_events(const vae_step_config* cfg, const v
     const int64_t cp_nb = vae_colpart_blocks(B);
     // GELU/LayerNorm backward of one layer: dgamma / dbeta / dbias through the partial buffer
     auto ln_bwd = [&](const float* dout, int64_t ld_dout, const float* pre, int64_t ld_pre, const float* mean, const float* rstd,
-                      const float* gamma, int64_t W, float* dpre, int64_t ld_dpre, float* dgamma, float* dbeta, float* dbias) {
+                      const float* gamma, int64_t W, float* dpre, int64_t ld_dpre, float* dgamma, float* dbeta, float* dbias,
+                      uint16_t* dpre16 = nullptr, int64_t ld16 = 0) {
       TRY(cp_take(cp_nb * 3 * W));
       TRY(vae_gelu_ln_bwd_part(dout, ld_dout, pre, ld_pre, mean, rstd, gamma, B, W, dpre, ld_dpre, dgamma, dbeta, dbias, cp_cur,
-                               &cp_blocks, stream));
+                               &cp_blocks, dpre16, ld16, stream));
       TRY(cp_add(0, W, 3 * W, dgamma)); TRY(cp_add(W, W, 3 * W, dbeta)); TRY(cp_add(2 * W, W, 3 * W, dbias));
       return VAE_OK;
     };
@@ -573,10 +577,12 @@ extern "C" int vae_elbo_step_backward_events(const vae_step_config* cfg, const v
     }
     // first encoder layer: GELU/LayerNorm backward of both halves, then ONE wgrad over the counts
     TRY(k.drop(dh, H, H, VAE_SITE_ENC_Z(0)));
+    // (a bf16-storage step: dpre again as bf16 for the weight-gradient product over the counts)
+    uint16_t* d16 = k.hb() ? k.h16(lo.dpre16) : nullptr;
     TRY(ln_bwd(dh, H, ws + lo.pre_enc0, HE, ws + lo.ln_mz[0], ws + lo.ln_rz[0], p->encz_ln_g[0], H, ws + lo.dpre_enc0, HE,
-               g->encz_ln_g[0], g->encz_ln_b[0], g->enc_b0));
+               g->encz_ln_g[0], g->encz_ln_b[0], g->enc_b0, d16, HE));
     TRY(ln_bwd(ws + lo.dpre_enc0 + H, HE, ws + lo.pre_enc0 + H, HE, ws + lo.ln_ml, ws + lo.ln_rl, p->encl_ln_g, Hl,
-               ws + lo.dpre_enc0 + H, HE, g->encl_ln_g, g->encl_ln_b, g->enc_b0 ? g->enc_b0 + H : nullptr));
+               ws + lo.dpre_enc0 + H, HE, g->encl_ln_g, g->encl_ln_b, g->enc_b0 ? g->enc_b0 + H : nullptr, d16 ? d16 + H : nullptr, HE));
     TRY(vae_colpart_reduce(cp, stream));
     if (k.fx()) {
       TRY(vae_absmax_partials(ws + lo.dpre_enc0, B, HE, HE, k.am(AM_DPRE), stream));
@@ -590,8 +596,7 @@ extern "C" int vae_elbo_step_backward_events(const vae_step_config* cfg, const v
   if (k.cov())   // covariate columns of both encoders' first-layer weight gradient: dpre^T cov (small; before the release point
                  // it would delay -- the whole enc_w0 slice travels last anyway)
     TRY(k.gemm(VAE_TN, HE, c.n_cov, B, ws + lo.dpre_enc0, HE, c.batch_cov, c.ld_cov, g->enc_w0 + G, k.ldw(), nullptr, nullptr, 0));
-  if (k.hb() && !vae_mid_supported(c))   // (the fused middle writes the bf16 image of dpre itself)
-    TRY(vae_cast_bf16(ws + lo.dpre_enc0, k.h16(lo.dpre16), B * HE, nullptr, nullptr, 0, stream));
+  // (dpre16, the bf16 image of dpre: left by the fused middle or by the first layer's LayerNorm backward launches)
   if (c.input_dropout_rate > 0.f) {  // GeneDropout: each encoder's weight gradient over its own input
     TRY(k.enc_wgrad(H, ws + lo.dpre_enc0, HE, ws + lo.xn_z, AM_XNZ, g->enc_w0));
     TRY(k.enc_wgrad(Hl, ws + lo.dpre_enc0 + H, HE, ws + lo.xn, AM_XN, g->enc_w0 + H * k.ldw()));
