@@ -3,7 +3,7 @@ CFG=${CFG:-cfg2}; TAG=${TAG:-p}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_r2${TAG}_$CFG -o k -- python bench.py --config $CFG --steps ${STEPS:-50} --warmup 10 --no-cpu-baseline --no-breakdown ${BENCH_ARGS:-} > gpurun_out/r2_prof_${TAG}_$CFG.log 2>&1 || exit 6
-tail -1 gpurun_out/r2_prof_${TAG}_$CFG.log | python -c "import json,sys; r=json.loads(sys.stdin.read()); print('ms/step under the profiler', r['ms_per_step'])"
+grep "^{" gpurun_out/r2_prof_${TAG}_$CFG.log | tail -1 | python -c "import json,sys; r=json.loads(sys.stdin.read()); print('ms/step under the profiler', r['ms_per_step'])"
 f=$(find gpurun_out/prof_r2${TAG}_$CFG -name "*kernel_stats.csv" | head -1)
 python - "$f" <<'PY'
 import csv, sys
