@@ -244,8 +244,9 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend; gloo only to rehearse the N>1 path on a box with fewer GPUs than ranks")
     ap.add_argument("--scan-weights", action="store_true",
-                    help="let every forward scan the two weight matrices for its GEMM operand scales (72 MB, ~15 us) instead "
-                         "of taking the maxima the fused optimiser maintains while it writes the weights")
+                    help="let every forward scan the two weight matrices for its GEMM operand scales (72 MB, ~15 us; bf16 mode: "
+                         "cast them to bf16) instead of taking the maxima / bf16 images the fused optimiser maintains while it "
+                         "writes the weights")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-breakdown", action="store_true")
     args = ap.parse_args()
@@ -337,6 +338,10 @@ def main():
         from vae_amd.optim import FusedAdamW
         fopt = FusedAdamW(arena, lr=5e-4, weight_decay=0.1, max_grad_norm=0.5, track_weight_maxima=True)
         step.use_weight_maxima(fopt)
+    if precision == ops.BF16 and G % 8 == 0 and not args.scan_weights:   # bf16 mode: the optimiser keeps the bf16 images
+        from vae_amd.optim import FusedAdamW
+        fopt = FusedAdamW(arena, lr=5e-4, weight_decay=0.1, max_grad_norm=0.5, track_bf16_images=True)
+        step.use_weight_images(fopt)
     reducer = GradAllReducer(arena, payload=args.grad_payload) if world > 1 else None
     head_fn = heads = None
     if cell_decoder is not None:   # CellDecoder + _cell_loss (modules.py:312-324, task.py:419-451) on z
@@ -365,11 +370,27 @@ def main():
     for i in range(args.warmup):
         one_step(i)
     fence()
+    host_trace = [] if os.environ.get("VAE_BENCH_TRACE_HOST") else None   # diagnostic: when the host returned from each step
+    # A full collection of the interpreter's garbage collector stalls the host for tens of milliseconds -- more than the
+    # launches queued ahead cover -- at a step that moves with every unrelated allocation of the process (measured at cfg5:
+    # one 40 ms hole somewhere in steps 50-120).  Collect now, keep the collector off inside the timed region.
+    import gc
+    gc.collect()
+    gc_was_on = gc.isenabled()
+    gc.disable()
     t0 = time.perf_counter()
     for i in range(args.steps):
         out = one_step(args.warmup + i)
+        if host_trace is not None:
+            host_trace.append(time.perf_counter() - t0)
     fence()
     elapsed = time.perf_counter() - t0
+    if gc_was_on:
+        gc.enable()
+    if host_trace is not None and rank == 0:
+        gaps = sorted(((host_trace[i] - (host_trace[i - 1] if i else 0.0)) * 1e3, i) for i in range(len(host_trace)))[-5:]
+        print("host trace: last step returned at %.1f ms of %.1f; longest host steps (ms, index): %s"
+              % (host_trace[-1] * 1e3, elapsed * 1e3, [(round(g, 2), i) for g, i in gaps]), file=sys.stderr)
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -391,8 +412,9 @@ def main():
                        "genes": G, "likelihood": cfg["likelihood"], "n_layers": cfg["n_layers"],
                        "parallelism": f"dp{world}", "grad_payload": args.grad_payload if world > 1 else None,
                        "counts": args.counts, "bf16_activations": bf16_st,
-                       "weight_operand_scales": "maxima kept by the fused optimiser (vae_adamw_step_wmax)" if fopt is not None
-                       else "scanned by every forward"},
+                       "weight_operand_scales": ("scanned by every forward" if fopt is None else
+                                                 "maxima kept by the fused optimiser (vae_adamw_step_wmax)" if fopt.weight_maxima is not None
+                                                 else "bf16 images kept by the fused optimiser (vae_adamw_step_bf16)")},
             "final_loss": loss,
         }
     if rank == 0 and not args.no_breakdown:

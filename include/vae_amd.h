@@ -350,6 +350,12 @@ typedef struct {
   const float* batch_cov;     /* (B, n_cov) device, row stride ld_cov                                    */
   int64_t ld_cov;
   int64_t ld_enc_w;
+  /* VAE_BF16 steps that keep bf16 storage (vae_elbo_step_bf16_storage), optional: bf16 images (nearest even) of enc_w0 --
+   * all (H + Hl) * ld_enc_w elements, padding included -- and of heads_w, 16-byte aligned, kept current by whoever
+   * updates the weights: vae_adamw_step_bf16 writes them while it stores the updated weights.  With both set the
+   * forward skips its own cast of the two matrices (one launch, 6 bytes per weight) and every product streams these. */
+  const void* weight_bf16_enc;
+  const void* weight_bf16_heads;
 } vae_step_config;
 
 typedef struct {
@@ -458,6 +464,15 @@ int vae_adamw_step_wmax(float* params, const float* grads, float* exp_avg, float
                         const vae_adamw_segment* segments, int n_segments, double lr, double beta1, double beta2, double eps,
                         int64_t step, double max_grad_norm, double grad_scale, float* workspace, int64_t workspace_bytes,
                         float* grad_norm_out, const int64_t* max_ranges, float* wmax_out, void* stream);
+
+/* The same step that also leaves bf16 images (nearest even) of the UPDATED params of the two element ranges
+ * [img_ranges[0], img_ranges[1]) and [img_ranges[2], img_ranges[3]) (ends multiples of 4) in img0 / img1 (8-byte aligned,
+ * range-length elements each): what vae_step_config.weight_bf16_enc / weight_bf16_heads take.  2 more bytes written per
+ * tracked weight in the update pass instead of 6 moved by a cast launch in every step.                                    */
+int vae_adamw_step_bf16(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
+                        const vae_adamw_segment* segments, int n_segments, double lr, double beta1, double beta2, double eps,
+                        int64_t step, double max_grad_norm, double grad_scale, float* workspace, int64_t workspace_bytes,
+                        float* grad_norm_out, const int64_t* img_ranges, void* img0, void* img1, void* stream);
 
 /* L1 penalty of LitVAE.training_step (task.py:491-496): sum_out[0] = sum of |p| over the segments (their
  * weight_decay field is ignored) and, when grads is not null, grads += grad_coeff * sign(p) -- the gradient of

@@ -556,6 +556,59 @@ def test_weight_maxima_from_the_optimiser_replace_the_scan():
     assert float(opt.weight_maxima[1].max()) == float(w_heads.abs().max())
 
 
+@pytest.mark.parametrize("n_layers,n_cov", [(1, 0), (2, 0), (1, 5)])
+def test_bf16_weight_images_from_the_optimiser_replace_the_cast(n_layers, n_cov):
+    """The bf16-mode twin of the test above: vae_adamw_step_bf16 leaves bf16 images (nearest even) of the two gene-sized
+    weight matrices while it stores the updated weights; a bf16-storage step then skips its own cast launch.  The images
+    must equal torch's bf16 rounding of the updated weights bit for bit -- row padding of a covariate model included in the
+    layout -- the update itself must be the plain vae_adamw_step's, and the step must give the SAME BITS with either source."""
+    from oracle import vae_oracle as O
+    from vae_amd.arena import ParamArena, _enc
+    from vae_amd.optim import FusedAdamW
+    from vae_amd.step import ElboStep
+    B, G, H, Hd, Hl, L = 256, 4000, 128, 128, 64, 10
+    p = O.init_params(G, H, Hd, Hl, L, n_layers, seed=23)
+    cov = None
+    if n_cov:
+        gc = torch.Generator().manual_seed(7)
+        for k in ("z_encoder.encoder.fc_layers.0.weight", "l_encoder.encoder.fc_layers.0.weight", "decoder.px_decoder.fc_layers.0.weight"):
+            p[k] = torch.cat((p[k], torch.randn(p[k].shape[0], n_cov, generator=gc) * 0.05), dim=1).contiguous()
+        cov = torch.zeros(B, n_cov)
+        cov[torch.arange(B), torch.randint(0, n_cov, (B,), generator=gc)] = 1.0
+        cov = cov.cuda()
+    x = O.synthetic_counts(B, G, seed=23, zero_inflate=0.3).cuda()
+    g = torch.Generator().manual_seed(24)
+    ez, el = torch.randn(B, L, generator=g).cuda(), torch.randn(B, 1, generator=g).cuda()
+    arena, twin = ParamArena(p, n_layers, "zinb", "cuda"), ParamArena(p, n_layers, "zinb", "cuda")
+    step = ElboStep(arena, l_mean=6.0, l_var=1.0, precision=1)
+    assert step.bf16_activations(B)
+    opt = FusedAdamW(arena, lr=1e-2, weight_decay=0.1, max_grad_norm=0.5, track_bf16_images=True)
+    plain = FusedAdamW(twin, lr=1e-2, weight_decay=0.1, max_grad_norm=0.5)
+    spans = opt._max_spans
+    assert spans[0][1] - spans[0][0] == (H + Hl) * arena.ld_enc_w and spans[1][1] - spans[1][0] == 2 * G * Hd
+    with pytest.raises(ValueError):
+        FusedAdamW(arena, track_weight_maxima=True, track_bf16_images=True)
+    with pytest.raises(ValueError):
+        step.use_weight_images((opt.weight_images[0], opt.weight_images[1][:-8]))
+    for it in range(3):
+        for img, (b, e) in zip(opt.weight_images, spans):
+            assert torch.equal(img.view(torch.int16), arena.flat[b:e].to(torch.bfloat16).view(torch.int16)), it
+        step.use_weight_images(None)
+        a = step.run(x, ez, el, batch_cov=cov)
+        la, ga = a["loss"].clone(), arena.flat_grad.clone()
+        step.use_weight_images(opt)
+        b_ = step.run(x, ez, el, batch_cov=cov)
+        assert torch.equal(la, b_["loss"]) and torch.equal(ga[:arena.used_end], arena.flat_grad[:arena.used_end]), it
+        twin.flat_grad.copy_(arena.flat_grad)
+        opt.step()                                   # lr 1e-2: the weights -- and their images -- really move
+        plain.step()
+        assert torch.equal(arena.flat, twin.flat), it
+    arena.flat.mul_(3.0)                             # a change behind the optimiser's back needs a refresh
+    opt.refresh_weight_images()
+    b, e = spans[1]
+    assert torch.equal(opt.weight_images[1].view(torch.int16), arena.flat[b:e].to(torch.bfloat16).view(torch.int16))
+
+
 @pytest.mark.parametrize("B", [37, 700, 2304])
 def test_native_cell_heads_match_torch_heads(B):
     """vae_cell_heads_step (linear CellDecoder heads + LitVAE._cell_loss, modules.py:297-324, task.py:419-451) against the

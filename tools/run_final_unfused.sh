@@ -1,7 +1,7 @@
 # Bench lines, kernel summaries and the counter table of the multi-layer configurations on ONE box (profiles/r02_zb_*)
 set -o pipefail
 mkdir -p gpurun_out/zb
-for cfg in cfg4 cfg5; do
+for cfg in ${CFGS:-cfg3 cfg4 cfg5}; do
   timeout -k 10 300 python bench.py --config $cfg --steps 30 --warmup 8 --no-cpu-baseline > gpurun_out/zb/${cfg}_bench.log 2>&1 || exit 6
   tail -1 gpurun_out/zb/${cfg}_bench.log > gpurun_out/zb/${cfg}_bench.json
   python -c "import json; r=json.load(open('gpurun_out/zb/${cfg}_bench.json')); print('$cfg', r['ms_per_step'], r['value'])"

@@ -89,6 +89,8 @@ SIGNATURES = {
     "vae_adamw_wmax_partials": (_i64, []),
     "vae_adamw_step_wmax": (_i32, [_ptr, _ptr, _ptr, _ptr, _i64, _ptr, _i32, C.c_double, C.c_double, C.c_double, C.c_double,
                                    _i64, C.c_double, C.c_double, _ptr, _i64, _ptr, _ptr, _ptr, _ptr]),
+    "vae_adamw_step_bf16": (_i32, [_ptr, _ptr, _ptr, _ptr, _i64, _ptr, _i32, C.c_double, C.c_double, C.c_double, C.c_double,
+                                   _i64, C.c_double, C.c_double, _ptr, _i64, _ptr, _ptr, _ptr, _ptr, _ptr]),
     "vae_cell_heads_workspace_bytes": (_i64, [_i64, _i64, _ptr]),
     "vae_cell_heads_step": (_i32, [_ptr, _ptr, _i64, _i64, _ptr, _i64, _ptr, _i64, _f32, _ptr, _ptr, _ptr, _i64, _ptr]),
     "vae_loglik_elem_fwd": (_i32, [_i32, _ptr, _i64, _ptr, _i64, _ptr, _i64, _ptr, _i64, _i64, _i64, _ptr, _i64, _ptr]),
@@ -112,7 +114,8 @@ class StepConfig(C.Structure):
                 ("x_dtype", C.c_int32), ("dropout_rate", _f32), ("rng_step", C.c_uint32), ("rng_seed", C.c_uint64),
                 ("input_dropout_rate", _f32), ("input_dropout_alpha", _f32), ("gene_running", _ptr),
                 ("weight_max_enc", _ptr), ("weight_max_heads", _ptr), ("weight_max_n", C.c_int32),
-                ("n_cov", C.c_int32), ("batch_cov", _ptr), ("ld_cov", _i64), ("ld_enc_w", _i64)]
+                ("n_cov", C.c_int32), ("batch_cov", _ptr), ("ld_cov", _i64), ("ld_enc_w", _i64),
+                ("weight_bf16_enc", _ptr), ("weight_bf16_heads", _ptr)]
 
 
 VAE_MAX_HEADS = 7

@@ -63,7 +63,10 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
                                                     float gscale, float beta1, float beta2, float eps, float step_size,
                                                     float bc2_sqrt, float max_norm, const float* __restrict__ partial,
                                                     int npartial, float* __restrict__ norm_out, int64_t r0b, int64_t r0e,
-                                                    int64_t r1b, int64_t r1e, float* __restrict__ wmax) {
+                                                    int64_t r1b, int64_t r1e, float* __restrict__ wmax,
+                                                    uint16_t* __restrict__ img0, uint16_t* __restrict__ img1) {
+  // img0 / img1 != null: bf16 images (nearest even) of the updated parameters of the two tracked ranges
+  auto bf = [](float v) { const __bf16 h = (__bf16)v; return __builtin_bit_cast(uint16_t, h); };
   __shared__ float red[4];
   float wm0 = 0.f, wm1 = 0.f;   // max |updated parameter| of this workgroup inside the two tracked ranges (wmax != null)
   // clip coefficient: every workgroup sums the same partials in the same order
@@ -122,6 +125,15 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
           if (e >= r0b && e < r0e) wm0 = fmaxf(wm0, mx);          // range ends are multiples of 4: a chunk is in or out
           else if (e >= r1b && e < r1e) wm1 = fmaxf(wm1, mx);
         }
+        if (img0) {   // (img1 is set with it) 8-byte store of the chunk's four images
+          const int64_t e = idx[u] << 2;
+          uint16_t* d = (e >= r0b && e < r0e) ? img0 + (e - r0b) : ((e >= r1b && e < r1e) ? img1 + (e - r1b) : nullptr);
+          if (d) {
+            const uint2 o = make_uint2((uint32_t)bf(pv[u].x) | ((uint32_t)bf(pv[u].y) << 16),
+                                       (uint32_t)bf(pv[u].z) | ((uint32_t)bf(pv[u].w) << 16));
+            *reinterpret_cast<uint2*>(d) = o;
+          }
+        }
       } else if (kk[u] == -1) {
         const int64_t e = idx[u] << 2;
 #pragma unroll
@@ -131,6 +143,8 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
             upd(p[e + j], g[e + j], m[e + j], v[e + j], s.decay[k]);
             if (wmax && e + j >= r0b && e + j < r0e) wm0 = fmaxf(wm0, fabsf(p[e + j]));
             if (wmax && e + j >= r1b && e + j < r1e) wm1 = fmaxf(wm1, fabsf(p[e + j]));
+            if (img0 && e + j >= r0b && e + j < r0e) img0[e + j - r0b] = bf(p[e + j]);
+            if (img0 && e + j >= r1b && e + j < r1e) img1[e + j - r1b] = bf(p[e + j]);
           }
         }
       }
@@ -139,7 +153,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
   if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
     const int64_t e = (n4 << 2) + threadIdx.x;
     const int k = seg_of(s, e);
-    if (k >= 0) upd(p[e], g[e], m[e], v[e], s.decay[k]);
+    if (k >= 0) upd(p[e], g[e], m[e], v[e], s.decay[k]);   // (past every tracked range: their ends are multiples of 4)
   }
   if (wmax) {   // plain stores, every entry every step: nothing to clear (the tracked ranges are 16-byte aligned multiples of 4)
     wm0 = block_max<4>(wm0, red);
@@ -224,7 +238,8 @@ __global__ __launch_bounds__(2 * WMAX_OUT) void wmax_finish_kernel(const float* 
 static int adamw_impl(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
                       const vae_adamw_segment* segments, int n_segments, double lr, double beta1, double beta2,
                       double eps, int64_t step, double max_grad_norm, double grad_scale, float* workspace,
-                      int64_t workspace_bytes, float* grad_norm_out, const int64_t* max_ranges, float* wmax, void* stream);
+                      int64_t workspace_bytes, float* grad_norm_out, const int64_t* max_ranges, float* wmax, void* stream,
+                      uint16_t* img0 = nullptr, uint16_t* img1 = nullptr);
 
 extern "C" int vae_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
                               const vae_adamw_segment* segments, int n_segments, double lr, double beta1, double beta2,
@@ -249,10 +264,29 @@ extern "C" int vae_adamw_step_wmax(float* params, const float* grads, float* exp
                     grad_scale, workspace, workspace_bytes, grad_norm_out, max_ranges, wmax_out, stream);
 }
 
+extern "C" int vae_adamw_step_bf16(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
+                                   const vae_adamw_segment* segments, int n_segments, double lr, double beta1, double beta2,
+                                   double eps, int64_t step, double max_grad_norm, double grad_scale, float* workspace,
+                                   int64_t workspace_bytes, float* grad_norm_out, const int64_t* img_ranges, void* img0, void* img1,
+                                   void* stream) {
+  VAE_REQUIRE(img_ranges && img0 && img1, "vae_adamw_step_bf16: null img_ranges / img0 / img1");
+  VAE_REQUIRE((reinterpret_cast<uintptr_t>(img0) & 7u) == 0 && (reinterpret_cast<uintptr_t>(img1) & 7u) == 0,
+              "vae_adamw_step_bf16: the images must be 8-byte aligned");
+  for (int r = 0; r < 2; ++r)
+    VAE_REQUIRE(img_ranges[2 * r] >= 0 && img_ranges[2 * r] <= img_ranges[2 * r + 1] && img_ranges[2 * r + 1] <= n &&
+                    img_ranges[2 * r] % 4 == 0 && img_ranges[2 * r + 1] % 4 == 0,
+                "vae_adamw_step_bf16: tracked range %d must lie in the arena with both ends multiples of 4", r);
+  VAE_REQUIRE(img_ranges[1] <= img_ranges[2] || img_ranges[3] <= img_ranges[0], "vae_adamw_step_bf16: the two ranges overlap");
+  return adamw_impl(params, grads, exp_avg, exp_avg_sq, n, segments, n_segments, lr, beta1, beta2, eps, step, max_grad_norm,
+                    grad_scale, workspace, workspace_bytes, grad_norm_out, img_ranges, nullptr, stream, (uint16_t*)img0,
+                    (uint16_t*)img1);
+}
+
 static int adamw_impl(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
                       const vae_adamw_segment* segments, int n_segments, double lr, double beta1, double beta2,
                       double eps, int64_t step, double max_grad_norm, double grad_scale, float* workspace,
-                      int64_t workspace_bytes, float* grad_norm_out, const int64_t* max_ranges, float* wmax, void* stream) {
+                      int64_t workspace_bytes, float* grad_norm_out, const int64_t* max_ranges, float* wmax, void* stream,
+                      uint16_t* img0, uint16_t* img1) {
   VAE_REQUIRE(params && grads && exp_avg && exp_avg_sq && n > 0, "vae_adamw_step: null pointer or empty arena");
   VAE_REQUIRE(segments && n_segments > 0 && n_segments <= MAX_SEG, "vae_adamw_step: 1..%d segments, got %d", MAX_SEG, n_segments);
   VAE_REQUIRE(step >= 1, "vae_adamw_step: step counts from 1");
@@ -286,7 +320,8 @@ static int adamw_impl(float* params, const float* grads, float* exp_avg, float* 
   hipLaunchKernelGGL(adamw_kernel, dim3(blocks), dim3(256), 0, st, params, grads, exp_avg, exp_avg_sq, n, s,
                      (float)grad_scale, (float)beta1, (float)beta2, (float)eps, step_size, bc2_sqrt, (float)max_grad_norm,
                      workspace, nblocks, grad_norm_out, max_ranges ? max_ranges[0] : 0, max_ranges ? max_ranges[1] : 0,
-                     max_ranges ? max_ranges[2] : 0, max_ranges ? max_ranges[3] : 0, wmax ? workspace + NORM_BLOCKS : nullptr);
+                     max_ranges ? max_ranges[2] : 0, max_ranges ? max_ranges[3] : 0, wmax ? workspace + NORM_BLOCKS : nullptr, img0,
+                     img1);
   VAE_CHECK_LAUNCH("vae_adamw_step");
   if (wmax) {
     hipLaunchKernelGGL(wmax_finish_kernel, dim3(1), dim3(2 * WMAX_OUT), 0, st, workspace + NORM_BLOCKS, blocks, wmax);

@@ -172,6 +172,10 @@ struct Ctx {
   bool cov() const { return c.n_cov > 0; }
   // the two weight matrices' maxima may come from outside (vae_step_config.weight_max_*: the optimiser keeps them)
   bool wext() const { return c.weight_max_enc && c.weight_max_heads && c.weight_max_n > 0; }
+  // ... and so may their bf16 images (vae_step_config.weight_bf16_*); else the forward casts them into the workspace
+  bool wimg() const { return c.weight_bf16_enc && c.weight_bf16_heads; }
+  const uint16_t* w_enc16() const { return wimg() ? (const uint16_t*)c.weight_bf16_enc : h16(lo.w_enc16); }
+  const uint16_t* w_heads16() const { return wimg() ? (const uint16_t*)c.weight_bf16_heads : h16(lo.w_heads16); }
   float* am(int slot) const {
     if (!fx()) return nullptr;
     if (wext() && slot == AM_WENC) return const_cast<float*>(c.weight_max_enc);
@@ -197,7 +201,7 @@ struct Ctx {
   // the two products over the normalised counts (xn: fp32, or bf16 when hb()): forward NT (xn = A), weight gradient TN (xn = B)
   int enc_fwd(int64_t N, const float* xn, int slot_x, const float* W, float* C, int64_t ldc, const float* bias, int* slabs_out) const {
     if (hb())   // bf16 xn x the bf16 image of the weight rows
-      return vae_gemm_bf16io(VAE_NT, VAE_IO_A_BF16 | VAE_IO_B_BF16, c.B, N, c.G, xn, lo.ld_xn, h16(lo.w_enc16) + (W - par->enc_w0), ldw(), C,
+      return vae_gemm_bf16io(VAE_NT, VAE_IO_A_BF16 | VAE_IO_B_BF16, c.B, N, c.G, xn, lo.ld_xn, w_enc16() + (W - par->enc_w0), ldw(), C,
                              ldc, bias, ws + lo.scratch, lo.scratch_floats * 4, slabs_out, nullptr, st);
     return big(VAE_NT, c.B, N, c.G, xn, lo.ld_xn, slot_x, W, ldw(), AM_WENC, C, ldc, bias, slabs_out);
   }
@@ -296,8 +300,12 @@ extern "C" int vae_elbo_step_forward(const vae_step_config* cfg, const vae_step_
                           stream));
     table_built = true;
   }
-  if (k.hb())   // bf16 images of the two gene-sized weight matrices: every product of this step streams those
+  if (k.hb() && k.wimg()) {   // the caller keeps the bf16 images of the two gene-sized weight matrices current
+    if (!vae_aligned16(c.weight_bf16_enc) || !vae_aligned16(c.weight_bf16_heads))
+      return vae_set_error(VAE_ERR_ARG, "vae_elbo_step_forward: weight_bf16_* must be 16-byte aligned");
+  } else if (k.hb()) {        // bf16 images of the two gene-sized weight matrices: every product of this step streams those
     TRY(vae_cast_bf16(p->enc_w0, k.h16(lo.w_enc16), HE * k.ldw(), p->heads_w, k.h16(lo.w_heads16), NH * Hd, stream));
+  }
   // encoders: x/mean-1 -> Linear(G, H+Hl) -> GELU -> LayerNorm (z and library halves)
   TRY(vae_normalize_rows_ex(xv, c.x_dtype, ldx, B, G, ws + lo.mean, ws + lo.xn, k.hb(), lo.ld_xn, k.am(AM_XN), stream));
   // GeneDropout (training): the z-encoder reads its own masked + normalised counts, the library encoder xn
@@ -381,7 +389,7 @@ extern "C" int vae_elbo_step_forward(const vae_step_config* cfg, const vae_step_
   static const bool no_gemm_stats = getenv("VAE_NO_GEMM_STATS") != nullptr;   // A/B knob
   if (k.hb()) {
     // (px16, the bf16 image of px: left by the fused middle or by the last hidden layer's LayerNorm / dropout launch)
-    TRY(vae_gemm_bf16io(VAE_NT, VAE_IO_A_BF16 | VAE_IO_B_BF16 | VAE_IO_C_BF16, B, NH, Hd, k.h16(lo.px16), Hd, k.h16(lo.w_heads16), Hd,
+    TRY(vae_gemm_bf16io(VAE_NT, VAE_IO_A_BF16 | VAE_IO_B_BF16 | VAE_IO_C_BF16, B, NH, Hd, k.h16(lo.px16), Hd, k.w_heads16(), Hd,
                         ws + lo.logits, NH, p->heads_b, ws + lo.scratch, lo.scratch_floats * 4, nullptr, no_gemm_stats ? nullptr : &rs,
                         stream));
   }
@@ -475,7 +483,7 @@ extern "C" int vae_elbo_step_backward_events(const vae_step_config* cfg, const v
   if (vae_mid_supported(c)) {
     int nslab = 0;
     if (k.hb())
-      TRY(vae_gemm_bf16io(VAE_NN, VAE_IO_A_BF16 | VAE_IO_B_BF16, B, Hd, NH, logits, NH, k.h16(lo.w_heads16), Hd, nullptr, Hd, nullptr,
+      TRY(vae_gemm_bf16io(VAE_NN, VAE_IO_A_BF16 | VAE_IO_B_BF16, B, Hd, NH, logits, NH, k.w_heads16(), Hd, nullptr, Hd, nullptr,
                           ws + lo.scratch, lo.scratch_floats * 4, &nslab, nullptr, stream));
     else
       TRY(k.big(VAE_NN, B, Hd, NH, logits, NH, AM_DLOGITS, p->heads_w, Hd, AM_WHEADS, nullptr, Hd, nullptr, &nslab));
@@ -518,7 +526,7 @@ extern "C" int vae_elbo_step_backward_events(const vae_step_config* cfg, const v
       return VAE_OK;
     };
     if (k.hb())
-      TRY(vae_gemm_bf16io(VAE_NN, VAE_IO_A_BF16 | VAE_IO_B_BF16, B, Hd, NH, logits, NH, k.h16(lo.w_heads16), Hd, ws + lo.dpx, Hd, nullptr,
+      TRY(vae_gemm_bf16io(VAE_NN, VAE_IO_A_BF16 | VAE_IO_B_BF16, B, Hd, NH, logits, NH, k.w_heads16(), Hd, ws + lo.dpx, Hd, nullptr,
                           ws + lo.scratch, lo.scratch_floats * 4, nullptr, nullptr, stream));
     else
       TRY(k.big(VAE_NN, B, Hd, NH, logits, NH, AM_DLOGITS, p->heads_w, Hd, AM_WHEADS, ws + lo.dpx, Hd, nullptr, nullptr));

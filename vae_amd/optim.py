@@ -29,7 +29,7 @@ class FusedAdamW:
                  weight_decay: float = 0.0, max_grad_norm: float = 0.5,
                  decay_of: Callable[[str, float], float] = reference_weight_decay,
                  lr_lambda: Optional[Callable[[int], float]] = None, skip: Iterable[str] = (),
-                 track_weight_maxima: bool = False):
+                 track_weight_maxima: bool = False, track_bf16_images: bool = False):
         """``skip``: parameter names that receive no gradient in this run (e.g. the cell heads when no
         cell loss is used) in addition to ``arena.no_grad``: torch leaves grad=None parameters alone.
 
@@ -37,7 +37,12 @@ class FusedAdamW:
         (first-layer encoder weights, decoder-head weights) in ``self.weight_maxima`` (2, P) while it stores the updated
         weights; ``ElboStep.use_weight_maxima(opt)`` then skips the step's own 72 MB scan for the two-f16-term GEMM
         scales.  Anything else that changes those weights (loading a checkpoint, a broadcast) must call
-        ``refresh_weight_maxima()``."""
+        ``refresh_weight_maxima()``.
+
+        ``track_bf16_images``: the bf16-mode counterpart -- every step also leaves bf16 images (nearest even) of the same
+        two matrices in ``self.weight_images`` while it stores the updated weights; ``ElboStep.use_weight_images(opt)``
+        then skips the step's own cast launch (6 bytes per weight per step).  Same rule: ``refresh_weight_images()`` after
+        anything else changed the weights.  One of the two options at a time (they belong to different precision modes)."""
         if not arena.flat.is_cuda:
             raise RuntimeError("vae_amd: FusedAdamW needs the arena on a GPU (there is no CPU fallback)")
         self.lib = _lib.load()
@@ -83,7 +88,10 @@ class FusedAdamW:
         self.ranges = merged
         self._segs = (_lib.AdamWSegment * len(merged))(*[_lib.AdamWSegment(b, e, wd) for b, e, wd in merged])
         self.weight_maxima = None
-        if track_weight_maxima:
+        self.weight_images = None
+        if track_weight_maxima and track_bf16_images:
+            raise ValueError("vae_amd: FusedAdamW: track_weight_maxima (two-f16-term mode) or track_bf16_images (bf16 mode), not both")
+        if track_weight_maxima or track_bf16_images:
             from .arena import _enc
             def span(first, last):
                 b = arena.offsets[first][0]
@@ -93,11 +101,23 @@ class FusedAdamW:
             heads = span("decoder.px_scale_decoder.0.weight",
                          "decoder.px_dropout_decoder.weight" if arena.likelihood == "zinb" else "decoder.px_scale_decoder.0.weight")
             if any(v % 4 for v in enc + heads):
-                raise RuntimeError("vae_amd: FusedAdamW(track_weight_maxima): the weight matrices are not 16-byte multiples")
+                raise RuntimeError("vae_amd: FusedAdamW(track_weight_maxima / track_bf16_images): the weight matrices are "
+                                   "not 16-byte multiples")
             self._max_ranges = (C.c_int64 * 4)(enc[0], enc[1], heads[0], heads[1])
             self._max_spans = (enc, heads)
+        if track_weight_maxima:
             self.weight_maxima = torch.zeros(2, int(self.lib.vae_adamw_wmax_partials()), dtype=torch.float32, device=arena.device)
             self.refresh_weight_maxima()
+        if track_bf16_images:
+            self.weight_images = tuple(torch.empty(e - b, dtype=torch.bfloat16, device=arena.device) for b, e in self._max_spans)
+            self.refresh_weight_images()
+
+    def refresh_weight_images(self) -> None:
+        """Recompute the bf16 images from the weights as they are now (after anything but ``step()`` changed them)."""
+        if self.weight_images is None:
+            return
+        for img, (b, e) in zip(self.weight_images, self._max_spans):
+            img.copy_(self.arena.flat[b:e])          # torch rounds to nearest even, as the kernels do
 
     def refresh_weight_maxima(self) -> None:
         """Recompute the tracked maxima from the weights as they are now (after anything but ``step()`` changed them)."""
@@ -124,6 +144,15 @@ class FusedAdamW:
                                               self._max_ranges, self.weight_maxima.data_ptr(),
                                               C.c_void_p(torch.cuda.current_stream().cuda_stream))
             _lib.check(rc, "adamw_step_wmax")
+            return
+        if self.weight_images is not None:
+            rc = self.lib.vae_adamw_step_bf16(a.flat.data_ptr(), a.flat_grad.data_ptr(), self.exp_avg.data_ptr(),
+                                              self.exp_avg_sq.data_ptr(), a.total, self._segs, len(self.ranges), lr, self.betas[0],
+                                              self.betas[1], self.eps, self.steps, self.max_grad_norm, float(grad_scale),
+                                              self._ws.data_ptr(), self._ws.numel() * 4, self.grad_norm.data_ptr(),
+                                              self._max_ranges, self.weight_images[0].data_ptr(), self.weight_images[1].data_ptr(),
+                                              C.c_void_p(torch.cuda.current_stream().cuda_stream))
+            _lib.check(rc, "adamw_step_bf16")
             return
         rc = self.lib.vae_adamw_step(a.flat.data_ptr(), a.flat_grad.data_ptr(), self.exp_avg.data_ptr(),
                                      self.exp_avg_sq.data_ptr(), a.total, self._segs, len(self.ranges), lr, self.betas[0],

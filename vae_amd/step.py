@@ -194,6 +194,7 @@ class ElboStep:
         self.params = _tensors(a.p, a.pcat, self.n_layers, self.zinb)
         self.grads = _tensors(a.g, a.gcat, self.n_layers, self.zinb)
         self.weight_maxima = None
+        self.weight_images = None
         self._plans: Dict[int, tuple] = {}
         self.max_plans = 4          # distinct (batch size, training) workspaces kept alive (train, validation, two tails)
         self._ev_heads = self._ev_small = None
@@ -209,6 +210,22 @@ class ElboStep:
                               or not t.is_cuda or not t.is_contiguous() or t.shape[1] % 4):
             raise ValueError("ElboStep.use_weight_maxima: need a contiguous (2, P) float32 GPU tensor, P a multiple of 4")
         self.weight_maxima = t
+
+    def use_weight_images(self, source) -> None:
+        """Take the bf16 images of the two gene-sized weight matrices from ``source`` (a ``FusedAdamW`` built with
+        ``track_bf16_images=True``, or a pair of contiguous bfloat16 GPU tensors kept current by the caller: the first-layer
+        encoder weights as stored in the arena, row padding included, and the decoder-head weights; ``None`` = cast again)
+        instead of casting them at the start of every bf16-storage forward.  Other precision modes ignore them."""
+        t = getattr(source, "weight_images", source)
+        if t is not None:
+            want = ((self.H + self.Hl) * self.a.ld_enc_w, (2 if self.zinb else 1) * self.G * self.Hd)
+            ok = isinstance(t, (tuple, list)) and len(t) == 2 and all(
+                torch.is_tensor(q) and q.dtype == torch.bfloat16 and q.is_cuda and q.is_contiguous() and q.numel() == n
+                for q, n in zip(t, want))
+            if not ok:
+                raise ValueError(f"ElboStep.use_weight_images: need two contiguous bfloat16 GPU tensors of {want} elements")
+            t = tuple(t)
+        self.weight_images = t
 
     def bf16_activations(self, B: int, train: bool = False) -> bool:
         """Whether a step of batch size B keeps the logits / logit gradients as bf16 (include/vae_amd.h,
@@ -266,6 +283,9 @@ class ElboStep:
         cfg.weight_max_enc = wm[0].data_ptr() if wm is not None else None
         cfg.weight_max_heads = wm[1].data_ptr() if wm is not None else None
         cfg.weight_max_n = wm.shape[1] if wm is not None else 0
+        wi = self.weight_images
+        cfg.weight_bf16_enc = wi[0].data_ptr() if wi is not None else None
+        cfg.weight_bf16_heads = wi[1].data_ptr() if wi is not None else None
         cfg.x_dtype = 0
         return cfg, ws, nbytes, v
 

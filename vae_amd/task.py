@@ -98,7 +98,9 @@ class LitVAE(nn.Module):
         self._fused: Optional[ElboStep] = None
         self._fused_val: Optional[ElboStep] = None
         self._l1 = None
-        self.weight_maxima_source = None   # a FusedAdamW(track_weight_maxima=True): the fused step then skips its weight scan
+        # a FusedAdamW(track_weight_maxima=True) or (track_bf16_images=True): the fused step then skips its weight scan /
+        # its cast of the two gene-sized weight matrices
+        self.weight_maxima_source = None
         self._create_results_dict()
         if use_gdro:
             raise NotImplementedError("vae_amd: GroupDRO re-weighting (off in the shipped config) is not wired in")
@@ -269,7 +271,7 @@ class LitVAE(nn.Module):
         if eps_z is None:
             eps_z = torch.empty(B, L, device=gene_vals.device).normal_()
             eps_l = torch.empty(B, 1, device=gene_vals.device).normal_()
-        self._fused_val.use_weight_maxima(self.weight_maxima_source)
+        self._use_weight_side_products(self._fused_val)
         self._fused_val.kl_weight = self.kl_weight      # KL warm-up: a field of the step's config, not a new step
         cov = None
         if self.batch_properties:
@@ -293,6 +295,11 @@ class LitVAE(nn.Module):
         return done
 
     # -- fused fast path ------------------------------------------------------------------------
+    def _use_weight_side_products(self, step: ElboStep) -> None:
+        src = self.weight_maxima_source
+        step.use_weight_maxima(src if getattr(src, "weight_maxima", None) is not None else None)
+        step.use_weight_images(src if getattr(src, "weight_images", None) is not None else None)
+
     def attach_arena(self, device="cuda") -> ParamArena:
         """Re-home every parameter of the network into the flat arena (data and .grad become
         views), so the fused step, the module-API path, the optimiser and the gradient
@@ -349,7 +356,7 @@ class LitVAE(nn.Module):
                                    precision=self.precision, dropout_rate=p_drop, seed=self.dropout_seed,
                                    input_dropout_rate=p_in, input_dropout_alpha=float(gdrop.alpha), gene_running=running)
             self._fused.rng_step = self.train_step
-        self._fused.use_weight_maxima(self.weight_maxima_source)
+        self._use_weight_side_products(self._fused)
         gene_vals, cell_prop_vals, cell_mask = batch[0], batch[1], batch[2]
         B, L = gene_vals.shape[0], self.network.n_latent
         if eps_z is None:  # same draw order as the reference: z-encoder noise, then library noise

@@ -80,8 +80,9 @@ def main(train_idx: List[int], test_idx: List[int], cell_class: str, additional_
                                max_grad_norm=rcfg["grad_clip_value"],
                                lr_lambda=lambda s: (warm ** 0.5) * min((s + 1) ** -0.5, (s + 1) * warm ** -1.5),
                                skip=() if use_heads else [k for k in arena.offsets if k.startswith("cell_decoder")],
-                               track_weight_maxima=precision == ops.F16X2 and x_all.shape[1] % 4 == 0)
-        task.weight_maxima_source = fused_opt    # the optimiser keeps the GEMM operand scales of the weights current
+                               track_weight_maxima=precision == ops.F16X2 and x_all.shape[1] % 4 == 0,
+                               track_bf16_images=precision == ops.BF16 and x_all.shape[1] % 8 == 0)
+        task.weight_maxima_source = fused_opt    # the optimiser keeps the GEMM operand scales / bf16 images of the weights current
     else:
         opt_cfg = task.configure_optimizers()
         opt, sched = opt_cfg["optimizer"], opt_cfg["lr_scheduler"]["scheduler"]
@@ -141,7 +142,8 @@ def _main_datamodule(dm, model_cfg, task_cfg, trainer_cfg, max_steps, log_every,
                          max_grad_norm=rcfg["grad_clip_value"],
                          lr_lambda=lambda s: (warm ** 0.5) * min((s + 1) ** -0.5, (s + 1) * warm ** -1.5),
                          skip=() if use_heads else [k for k in arena.offsets if k.startswith("cell_decoder")],
-                         track_weight_maxima=precision == ops.F16X2 and ds.n_genes % 4 == 0)
+                         track_weight_maxima=precision == ops.F16X2 and ds.n_genes % 4 == 0,
+                         track_bf16_images=precision == ops.BF16 and ds.n_genes % 8 == 0)
         task.weight_maxima_source = opt
         sched = None
     else:
