@@ -85,6 +85,18 @@ def test_argument_validation_without_gpu():
     h.width[1] = 2                                                                  # a continuous head has one output
     rc = lib.vae_cell_heads_step(C.byref(h), fake, 64, 30, fake, 2, fake, 2, 1.0, None, fake, fake, n, None)
     assert rc == 1 and b"bad width" in lib.vae_last_error()
+    # the optimiser entry point that keeps bf16 weight images: ranges and image pointers are checked before any launch
+    seg = (_lib.AdamWSegment * 1)(_lib.AdamWSegment(0, 64, 0.0))
+    rng = (C.c_int64 * 4)(0, 16, 16, 64)
+    args = (fake, fake, fake, fake, 64, seg, 1, 1e-3, 0.9, 0.999, 1e-8, 1, 0.0, 1.0, None, 0, None)
+    rc = lib.vae_adamw_step_bf16(*args, rng, None, fake, None)
+    assert rc == 1 and b"null img_ranges" in lib.vae_last_error()
+    rc = lib.vae_adamw_step_bf16(*args, rng, C.c_void_p(4100), fake, None)
+    assert rc == 1 and b"8-byte aligned" in lib.vae_last_error()
+    rc = lib.vae_adamw_step_bf16(*args, (C.c_int64 * 4)(0, 18, 20, 64), fake, fake, None)
+    assert rc == 1 and b"multiples of 4" in lib.vae_last_error()
+    rc = lib.vae_adamw_step_bf16(*args, (C.c_int64 * 4)(0, 32, 16, 64), fake, fake, None)
+    assert rc == 1 and b"overlap" in lib.vae_last_error()
 
 
 def test_workspace_queries():
