@@ -230,8 +230,10 @@ def cpu_baseline(cfg, threads):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    # defaults long enough to leave the load-onset transient of the board behind (the first ~40 steps after
+    # any idle gap run 3-10 % slower); still 0.15 s of timed work
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the config's)")
     ap.add_argument("--precision", default="", choices=["", "fp32", "fp32x3", "bf16"],
@@ -367,22 +369,26 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # A full collection of the interpreter's garbage collector stalls the host for tens of milliseconds -- more than the
+    # launches queued ahead cover -- at a step that moves with every unrelated allocation of the process (measured at cfg5:
+    # one 40 ms hole somewhere in steps 50-120).  Collect now, keep the collector off until the timed region ends.
+    import gc
+    gc.collect()                     # (before the warm-up: nothing but the fence sits between warm-up and timed steps)
+    gc_was_on = gc.isenabled()
+    gc.disable()
     for i in range(args.warmup):
         one_step(i)
     fence()
     host_trace = [] if os.environ.get("VAE_BENCH_TRACE_HOST") else None   # diagnostic: when the host returned from each step
-    # A full collection of the interpreter's garbage collector stalls the host for tens of milliseconds -- more than the
-    # launches queued ahead cover -- at a step that moves with every unrelated allocation of the process (measured at cfg5:
-    # one 40 ms hole somewhere in steps 50-120).  Collect now, keep the collector off inside the timed region.
-    import gc
-    gc.collect()
-    gc_was_on = gc.isenabled()
-    gc.disable()
+    gpu_trace = []                                                        # ... and an event behind each step
     t0 = time.perf_counter()
     for i in range(args.steps):
         out = one_step(args.warmup + i)
         if host_trace is not None:
             host_trace.append(time.perf_counter() - t0)
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            gpu_trace.append(ev)
     fence()
     elapsed = time.perf_counter() - t0
     if gc_was_on:
@@ -391,6 +397,8 @@ def main():
         gaps = sorted(((host_trace[i] - (host_trace[i - 1] if i else 0.0)) * 1e3, i) for i in range(len(host_trace)))[-5:]
         print("host trace: last step returned at %.1f ms of %.1f; longest host steps (ms, index): %s"
               % (host_trace[-1] * 1e3, elapsed * 1e3, [(round(g, 2), i) for g, i in gaps]), file=sys.stderr)
+        per = [gpu_trace[i - 1].elapsed_time(gpu_trace[i]) for i in range(1, len(gpu_trace))]
+        print("gpu trace (ms between the events behind consecutive steps): " + " ".join("%.3f" % v for v in per), file=sys.stderr)
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
