@@ -64,9 +64,6 @@ int vae_reparam_kl_bwd_part(const float* dz, int64_t ld_dz, const float* g_kl, f
                             int64_t ld_heads, const float* eps, int64_t ld_eps, const float* qv, int64_t B, int64_t L,
                             float prior_mean, float prior_var, float* dheads, int64_t ld_dheads, float* dbias, float* part,
                             int* blocks_out, void* stream);
-#define VAE_ZERO_MAX_SEGMENTS 48
-struct VaeZeroList { float* ptr[VAE_ZERO_MAX_SEGMENTS]; int64_t n[VAE_ZERO_MAX_SEGMENTS]; int count; };
-int vae_zero_segments(const VaeZeroList& z, void* stream);
 
 // px_r != null: extra workgroups of the same launch build the gene table (vae_gene_table) as well
 int vae_softmax_stats_merge(const float* stat_m, const float* stat_s, int slots, int64_t B, float* rowmax, float* rowsum,

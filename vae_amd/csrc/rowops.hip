@@ -841,23 +841,6 @@ int vae_colpart_reduce(VaeColPartList& z, void* stream) {
   return VAE_OK;
 }
 
-// Clears up to VAE_ZERO_MAX_SEGMENTS short float arrays in ONE launch (workgroup i clears segment i): the unfused
-// backward accumulates ~17 small gradients with atomics and cleared each with its own memset node (4.8 us apiece).
-namespace {
-__global__ __launch_bounds__(256) void zero_segments_kernel(VaeZeroList z) {
-  float* p = z.ptr[blockIdx.x];
-  const int64_t n = z.n[blockIdx.x];
-  for (int64_t i = threadIdx.x; i < n; i += 256) p[i] = 0.f;
-}
-}  // namespace
-int vae_zero_segments(const VaeZeroList& z, void* stream) {
-  if (z.count <= 0) return VAE_OK;
-  VAE_REQUIRE(z.count <= VAE_ZERO_MAX_SEGMENTS, "vae_zero_segments: too many segments");
-  hipLaunchKernelGGL(zero_segments_kernel, dim3((unsigned)z.count), dim3(256), 0, (hipStream_t)stream, z);
-  VAE_CHECK_LAUNCH("vae_zero_segments");
-  return VAE_OK;
-}
-
 extern "C" int vae_add_inplace(const float* src, float* dst, int64_t n, void* stream) {
   VAE_REQUIRE(src && dst && n > 0, "vae_add_inplace: bad arguments");
   int blocks = (int)((n + 255) / 256);
