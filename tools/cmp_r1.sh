@@ -1,4 +1,7 @@
 # same-box comparison with the end-of-round-1 tree (copied to gpurun_in_r1/, not committed): short and long runs
+#   git worktree add /tmp/r1tree dea417deba67 && make -C /tmp/r1tree/vae_amd/csrc -j8
+#   mkdir gpurun_in_r1 && (cd /tmp/r1tree && cp -r bench.py vae_amd oracle include tools __graft_entry__.py $OLDPWD/gpurun_in_r1/)
+#   gpurun -- 'bash tools/cmp_r1.sh'        (gpurun_in_r1/ is git-ignored; remove it and the worktree afterwards)
 for rep in 1 2; do
   for sw in "20 5" "300 50"; do
     set -- $sw
