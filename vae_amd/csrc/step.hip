@@ -497,6 +497,7 @@ extern "C" int vae_elbo_step_backward_events(const vae_step_config* cfg, const v
     // The row kernels of the unfused backward leave their LayerNorm / bias column sums per workgroup in lo.colpart; ONE
     // launch at the end adds them in workgroup order and overwrites the gradients: no float atomics, no clearing, and the
     // same bits on every run.
+    static_assert(3 * (2 * VAE_MAX_LAYERS + 1) + 2 <= VAE_COLPART_MAX, "one entry per LayerNorm / bias vector of the deepest model");
     VaeColPartList cp;
     cp.count = 0;
     int64_t cp_used = 0;
