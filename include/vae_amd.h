@@ -64,8 +64,12 @@ int vae_gemm(int layout, int precision, int64_t M, int64_t N, int64_t K, const f
  * for bit) as vae_gemm without the workspace pair: the split-K slabs go to a static device array of
  * vae_gemm_noalloc_max_bytes() = 40 MiB that every GPU the library runs on holds until the process ends; shapes whose
  * vae_gemm_workspace_bytes exceeds it are rejected with VAE_ERR_ARG.  Calls no hipMalloc / hipFree.  All calls on one
- * GPU share that GPU's array: calls that overlap on one GPU (different streams, or threads) race -- serialise them. */
+ * GPU share that GPU's array: calls that overlap on one GPU (different streams, or threads) race -- serialise them.
+ * The per-device address of the array is looked up on the first call on a device (hipGetSymbolAddress, a runtime query
+ * that must not happen inside a graph capture): call vae_gemm_noalloc_init() once per device, with that device
+ * current, before capturing.  `stream` must belong to the current device.                                          */
 int64_t vae_gemm_noalloc_max_bytes(void);
+int vae_gemm_noalloc_init(void);
 int vae_gemm_noalloc(int layout, int precision, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
                      const float* B, int64_t ldb, float* C, int64_t ldc, const float* bias, const float* x_mean,
                      int accumulate, void* stream);
@@ -94,6 +98,20 @@ int vae_gemm_scaled(int layout, int64_t M, int64_t N, int64_t K, const float* A,
 int vae_gemm_scaled_slabs(int layout, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* scale_a,
                           const float* B, int64_t ldb, const float* scale_b, float* workspace, int64_t workspace_bytes,
                           int* n_slabs, void* stream);
+
+/* The weight-gradient product C (M, N) = A^T B (A stored (K, M), B stored (K, N): layout VAE_TN; dW = dy^T x of an
+ * nn.Linear, modules.py:361-369) on two f16 terms with ONE POWER-OF-TWO SCALE PER OUTPUT ROW m instead of one for all of A:
+ * the decoder-head weight gradient of the training step, where column m of A = dlogits is gene m's gradient and its
+ * magnitude follows the gene's softmax mass (> 2^20 across genes), so that a single scale would leave quiet genes' rows
+ * with few correct bits.  col_max: (n_chunks, ld_max >= M) maxima of |A[k, m]| over chunks of the K rows (any partition;
+ * the step's backward epilogue leaves one row per cell chunk); row m's scale comes from their maximum and is removed
+ * from the output row again -- both exact.  b_max: n_b_max > 0 partial maxima of |B| (16-byte aligned).  Needs a shape
+ * on the 128-wide tile pipeline (vae_gemm_rowscaled_ok: M, N >= 4, M % 4 == N % 4 == K % 4 == 0, enough work for 128-wide
+ * tiles) and 16-byte aligned rows; VAE_ERR_ARG otherwise (use vae_gemm).                                                  */
+int vae_gemm_rowscaled_ok(int64_t M, int64_t N, int64_t K);
+int vae_gemm_rowscaled(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* col_max, int64_t n_chunks,
+                       int64_t ld_max, const float* B, int64_t ldb, const float* b_max, int64_t n_b_max, float* C, int64_t ldc,
+                       float* workspace, int64_t workspace_bytes, void* stream);
 
 /* VAE_BF16 products with operands and / or the output stored as bf16 in HBM (io = VAE_IO_* bits; the other matrices
  * fp32).  This is the reference's autocast(bfloat16) storage (config.py:87: nn.Linear outputs are bf16 tensors,
@@ -421,7 +439,10 @@ int vae_elbo_step_backward_events(const vae_step_config* cfg, const vae_step_ten
  *   loss = sum_i mean_b(per_i[b] * mask[b, i])    (the mean runs over ALL cells of the batch).
  * Writes *loss (unscaled), and -- dz != NULL -- dz (B, L) = d(loss_scale * loss)/dz summed over the heads with their
  * dz_coeff, dw[i] / db[i] (overwritten).  Two or three launches, fixed summation order.  L <= 64, sum of widths <= 64.
- * A discrete target outside [0, width) is treated like ignore_index (no loss, no gradient; torch raises there).        */
+ * A discrete target outside [0, width) is treated like ignore_index (no loss, no gradient; torch raises there).
+ * class_weight[i] (nullable; discrete heads only): `width` per-class weights of the head's cross-entropy, as
+ * nn.CrossEntropyLoss(weight=clip(1/freq, 0.1, 10), reduction="none") under balance_classes (task.py:129-132): cell b's
+ * loss and logit gradient are multiplied by class_weight[i][target_b].                                                  */
 #define VAE_MAX_HEADS 7
 typedef struct {
   int32_t n_heads;
@@ -432,6 +453,7 @@ typedef struct {
   const float* b[VAE_MAX_HEADS];     /* (width)                                                           */
   float* dw[VAE_MAX_HEADS];
   float* db[VAE_MAX_HEADS];
+  const float* class_weight[VAE_MAX_HEADS];   /* (width) or NULL = unweighted                              */
 } vae_cell_heads;
 int64_t vae_cell_heads_workspace_bytes(int64_t B, int64_t L, const vae_cell_heads* heads);
 int vae_cell_heads_step(const vae_cell_heads* heads, const float* z, int64_t B, int64_t L, const float* targets, int64_t ld_t,

@@ -104,7 +104,7 @@ def test_workspace_queries():
     lib = _lib.load()
     assert lib.vae_gemm_workspace_bytes(4096, 40000, 256) == 0          # enough tiles: no split-K
     assert lib.vae_gemm_workspace_bytes(512, 384, 20000) > 0            # skinny: split over genes
-    assert lib.vae_nbzinb_bwd_workspace_bytes(512, 20000) % (3 * 20000 * 4) == 0
+    assert lib.vae_nbzinb_bwd_workspace_bytes(512, 20000) % (5 * 20000 * 4) == 0       # slabs [chunk][3 sums + 2 maxima][G]
     cfg = _lib.StepConfig(B=512, G=20000, H=256, Hl=128, L=30, Hd=256, n_layers=1, zinb=1, precision=0, l_mean=0.0,
                           l_var=1.0, kl_weight=1.0, gene_loss_coeff=5e-3, loss_scale=1.0)
     n = lib.vae_elbo_step_workspace_bytes(C.byref(cfg))

@@ -27,7 +27,8 @@ HEADS = {   # bench.py's cfg5 heads: two discrete, one adversarial (gradient rev
 GRAD_REVERSE = {"Sex": 0.2}
 
 
-def _run_both(B, G, H, Hd, Hl, L, n_layers, precision, *, heads=False, seed=43, likelihood="zinb", tweak=None, cov_sizes=None):
+def _run_both(B, G, H, Hd, Hl, L, n_layers, precision, *, heads=False, seed=43, likelihood="zinb", tweak=None, cov_sizes=None,
+              native_heads=False):
     """-> (oracle outputs, oracle grads, step outputs, arena).  precision: 0 / 3 fp32-grade (oracle in fp64), 1 bf16
     (oracle in fp32 with bf16-rounded GEMM operands).  cov_sizes: class counts of batch properties -- the model gets
     the covariate columns of modules.py:102-107 and the step the masked one-hot block."""
@@ -75,8 +76,11 @@ def _run_both(B, G, H, Hd, Hl, L, n_layers, precision, *, heads=False, seed=43, 
         assert step.bf16_activations(B) == (B > 64 and G % 8 == 0)
         kw.update(gemm_dtype=torch.bfloat16, logits_bf16=step.bf16_activations(B))
     o_out, o_grads = O.training_step_with_grads({k: cast(v) for k, v in p.items()}, cast(x), cast(eps_z), cast(eps_l), **kw)
-    fn = None
-    if heads:
+    fn = nh = None
+    if heads and native_heads:   # vae_cell_heads_step (what bench.py's cfg5 line runs)
+        from vae_amd.step import CellHeads
+        nh = (CellHeads(arena, HEADS, GRAD_REVERSE), targets.cuda(), mask.cuda())
+    elif heads:
         from vae_amd.modules import CellDecoder
         from vae_amd.task import cell_loss
         dec = CellDecoder(L, HEADS, grad_reverse_dict=GRAD_REVERSE, use_hidden_layer=False).cuda()
@@ -91,7 +95,7 @@ def _run_both(B, G, H, Hd, Hl, L, n_layers, precision, *, heads=False, seed=43, 
         lab = labels.clone().cuda()
         bc = ElboStep.covariates(lab, cmask.cuda(), cov_sizes)
         assert int(lab.min()) == 0 and torch.equal(bc.cpu(), cov.float())      # clamped in place, as the reference does
-    out = step.run(x.cuda(), eps_z.cuda(), eps_l.cuda(), cell_head_fn=fn, batch_cov=bc)
+    out = step.run(x.cuda(), eps_z.cuda(), eps_l.cuda(), cell_head_fn=fn, cell_heads=nh, batch_cov=bc)
     torch.cuda.synchronize()
     return o_out, o_grads, out, arena
 
@@ -137,6 +141,23 @@ def test_cfg5_shape_multitask_heads(precision):
     bf16 = precision == 1
     _check(o_out, o_grads, out, arena, TOL_CELL_BF16 if bf16 else TOL_CELL, TOL_GRAD_BF16 if bf16 else TOL_GRAD, 41)
     # the heads themselves run in fp32 torch ops here; the bf16 oracle rounds their operands too (autocast would)
+    assert abs(float(out["cell_loss"]) - float(o_out["cell_loss"])) < (1e-2 if bf16 else 1e-5) * abs(float(o_out["cell_loss"]))
+
+
+@pytest.mark.parametrize("n_layers", [1, 2])
+@pytest.mark.parametrize("precision", [0, 3, 1], ids=["bf16x3", "f16x2", "bf16"])
+def test_bench_batch_composition_against_oracle(precision, n_layers):
+    """the bench lines of cfg3 / cfg4 / cfg5 run B = 4096 / 2048 per GPU, where the step takes branches
+    no smaller batch reaches -- step.hip's B > 1024 ELBO path (vae_nbzinb_fwd_finish + vae_elbo_reduce), the chunked
+    small_wgrad reduction with its combine launch (B >= 2048, default threshold), the wave-per-cell middle (B >= 768), the
+    grouped tile raster of the decoder-head products (>= 16 row tiles AND >= 16 column tiles) and the chunked reductions of
+    the native cell heads.  B = 2304 (18 row tiles), 4096 genes (keeps the fp64 oracle cheap), the bench widths, four
+    native heads, every precision mode, one composition against the oracle."""
+    o_out, o_grads, out, arena = _run_both(2304, 4096, 256, 256, 128, 30, n_layers, precision=precision, heads=True, seed=31,
+                                           native_heads=True)
+    bf16 = precision == 1
+    _check(o_out, o_grads, out, arena, TOL_CELL_BF16 if bf16 else TOL_CELL, TOL_GRAD_BF16 if bf16 else TOL_GRAD,
+           33 if n_layers == 1 else 41)
     assert abs(float(out["cell_loss"]) - float(o_out["cell_loss"])) < (1e-2 if bf16 else 1e-5) * abs(float(o_out["cell_loss"]))
 
 

@@ -80,6 +80,33 @@ def test_gemm_slabs_sum_to_the_product(ops, layout, shape):
     assert rel_err(slabs.double().sum(0).cpu().numpy(), (a64 @ b64).numpy()) < 2e-6 * max(1, np.sqrt(K) / 8)
 
 
+@pytest.mark.parametrize("shape", [(40000, 256, 512), (8192, 256, 2304), (1280, 384, 512), (2048, 256, 512)])
+def test_gemm_rowscaled_keeps_every_row_fp32_grade(ops, shape):
+    """vae_gemm_rowscaled (the step's decoder-head weight gradient, dW = dlogits^T px): two f16 terms with one power-of-two
+    scale per OUTPUT ROW.  Columns of A span 2^-40 .. 1 (a gene's dlogits column follows its softmax mass): every row of
+    the product is held to fp64 relative to that row's own sum |a||b| -- a single operand scale (vae_gemm_scaled) would lose
+    the quiet rows entirely.  Column maxima arrive per chunk of the K rows (3 chunks; the epilogue backward leaves one per
+    cell chunk); 160 x 128, 128 x 160 and 128 x 128 tile shapes."""
+    M, N, K = shape
+    g = torch.Generator().manual_seed(51)
+    col_scale = torch.exp2(torch.randint(-40, 1, (1, M), generator=g).double())
+    a64 = _rand((K, M), 18) * col_scale
+    b64 = _rand((K, N), 19, 0.7)
+    A, Bm = a64.float().cuda(), b64.float().cuda()
+    a64, b64 = A.double().cpu(), Bm.double().cpu()          # the operands as the kernel sees them
+    ref = (a64.t() @ b64).numpy()
+    mag = (a64.abs().t() @ b64.abs()).numpy()
+    bounds = [0, K // 3, 2 * K // 3, K]
+    col_max = torch.stack([A[bounds[i]:bounds[i + 1]].abs().amax(dim=0) for i in range(3)])
+    out = ops.gemm_rowscaled(A, Bm, col_max, Bm.abs().amax().expand(8).contiguous()).double().cpu().numpy()
+    err = np.max(np.abs(out - ref) / mag, axis=1)
+    assert err.max() < 4e-7 * max(1.0, np.sqrt(K) / 16), (err.max(), int(err.argmax()))
+    out1 = ops.gemm_rowscaled(A, Bm).double().cpu().numpy()                      # default maxima: the same product
+    assert np.array_equal(out, out1)
+    with pytest.raises(ValueError):
+        ops.gemm_rowscaled(A[:, :30].contiguous(), Bm)                           # outside the tile pipeline
+
+
 @pytest.mark.parametrize("layout", [0, 1, 2])
 @pytest.mark.parametrize("shape", [(132, 260, 4096), (640, 1280, 256), (512, 384, 2048), (260, 136, 4100), (96, 257, 4101)])
 def test_gemm_two_f16_terms(ops, layout, shape):

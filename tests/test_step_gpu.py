@@ -551,9 +551,13 @@ def test_weight_maxima_from_the_optimiser_replace_the_scan():
         b = step.run(x, ez, el)
         assert torch.equal(la, b["loss"]) and torch.equal(ga[:arena.used_end], arena.flat_grad[:arena.used_end]), it
         opt.step()                                   # lr 1e-2: the weights -- and their maxima -- really move
-    arena.flat.mul_(3.0)                             # a change behind the optimiser's back needs a refresh
-    opt.refresh_weight_maxima()
+    arena.flat.mul_(3.0)                             # a change behind the optimiser's back ...
+    arena.touch()                                    # ... is announced (broadcast_parameters / the load hook do), and the
+    step.run(x, ez, el)                              # next step that consumes the maxima refreshes them
     assert float(opt.weight_maxima[1].max()) == float(w_heads.abs().max())
+    arena.flat.mul_(0.5)
+    opt.refresh_weight_maxima()                      # or explicitly
+    assert float(opt.weight_maxima[0].max()) == float(w_enc.abs().max())
 
 
 @pytest.mark.parametrize("n_layers,n_cov", [(1, 0), (2, 0), (1, 5)])
@@ -609,23 +613,28 @@ def test_bf16_weight_images_from_the_optimiser_replace_the_cast(n_layers, n_cov)
     assert torch.equal(opt.weight_images[1].view(torch.int16), arena.flat[b:e].to(torch.bfloat16).view(torch.int16))
 
 
+@pytest.mark.parametrize("balanced", [False, True], ids=["plain", "balance_classes"])
 @pytest.mark.parametrize("B", [37, 700, 2304])
-def test_native_cell_heads_match_torch_heads(B):
+def test_native_cell_heads_match_torch_heads(B, balanced):
     """vae_cell_heads_step (linear CellDecoder heads + LitVAE._cell_loss, modules.py:297-324, task.py:419-451) against the
     torch modules under autograd in fp64: loss, d z and every head's weight / bias gradient -- two discrete heads (one
     behind a gradient-reversal layer), a stop_grad head that must leave d z alone, a continuous head, ignore_index rows,
-    masked cells, a loss scale; B = 2304 runs the chunked reduction + combine launch."""
+    masked cells, a loss scale; B = 2304 runs the chunked reduction + combine launch.  balance_classes: per-class
+    cross-entropy weights clip(1 / freq, 0.1, 10) (task.py:129-132) on the discrete heads."""
     from oracle import vae_oracle as O
     from vae_amd.arena import ParamArena
     from vae_amd.modules import CellDecoder
     from vae_amd.step import CellHeads
-    from vae_amd.task import cell_loss
+    from vae_amd.task import cell_loss, class_balance_weights
     L = 30
-    props = {"Dx": {"discrete": True, "values": [0, 1, 2], "stop_grad": False},
-             "Adv": {"discrete": True, "values": list(range(7)), "stop_grad": False},
-             "Frozen": {"discrete": True, "values": [0, 1], "stop_grad": True},
+    props = {"Dx": {"discrete": True, "values": [0, 1, 2], "stop_grad": False, "freq": [0.7, 0.25, 0.05]},
+             "Adv": {"discrete": True, "values": list(range(7)), "stop_grad": False, "freq": [0.02, 0.3, 0.2, 0.2, 0.1, 0.1, 0.08]},
+             "Frozen": {"discrete": True, "values": [0, 1], "stop_grad": True, "freq": [0.5, 0.5]},
              "Age": {"discrete": False, "values": [-1], "stop_grad": False}}
     rev = {"Adv": 0.3}
+    cw = class_balance_weights(props) if balanced else None
+    if balanced:   # 1 / 0.02 = 50 clips to 10; 1 / 0.7 = 1.43 stays
+        assert float(cw["Adv"][0]) == 10.0 and abs(float(cw["Dx"][0]) - 1 / 0.7) < 1e-6 and "Age" not in cw
     p = O.init_params(64, 16, 16, 8, L, 1, seed=21, cell_properties=props)
     arena = ParamArena(p, 1, "zinb", "cuda")
     g = torch.Generator().manual_seed(22)
@@ -642,9 +651,9 @@ def test_native_cell_heads_match_torch_heads(B):
         dec.cell_mlp[k].weight.data = p[f"cell_decoder.cell_mlp.{k}.weight"].double()
         dec.cell_mlp[k].bias.data = p[f"cell_decoder.cell_mlp.{k}.bias"].double()
     z64 = z.double().requires_grad_(True)
-    ref = cell_loss(dec(z64), props, targets.double(), mask.double())
+    ref = cell_loss(dec(z64), props, targets.double(), mask.double(), class_weights=cw)
     (ref * scale).backward()
-    heads = CellHeads(arena, props, rev)
+    heads = CellHeads(arena, props, rev, class_weights=cw)
     dz = torch.full((B, L), float("nan"), device="cuda")
     loss = heads.run(z.cuda(), targets.cuda(), mask.cuda(), scale, dz)
     torch.cuda.synchronize()

@@ -40,6 +40,7 @@ def test_noalloc_gemm_matches_vae_gemm_twice_then_smaller():
     from vae_amd import _lib
     lib = _lib.load()
     assert lib.vae_gemm_noalloc_max_bytes() == 40 << 20
+    assert lib.vae_gemm_noalloc_init() == 0 and lib.vae_gemm_noalloc_init() == 0      # eager address lookup, idempotent
     # 1) the encoder forward of BASELINE configs[1]: 42 split-K slabs of 512 x 384 (33 MB of scratch), fp32-grade
     need, ref, out, A, Bm, bias = _both(lib, 0, 0, 512, 384, 20000, seed=1)
     assert need > 30 << 20

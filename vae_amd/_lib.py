@@ -24,6 +24,7 @@ SIGNATURES = {
     "vae_gemm_workspace_bytes": (_i64, [_i64, _i64, _i64]),
     "vae_gemm": (_i32, [_i32, _i32, _i64, _i64, _i64, _ptr, _i64, _ptr, _i64, _ptr, _i64, _ptr, _ptr, _i32, _ptr, _i64, _ptr]),
     "vae_gemm_noalloc_max_bytes": (_i64, []),
+    "vae_gemm_noalloc_init": (_i32, []),
     "vae_gemm_noalloc": (_i32, [_i32, _i32, _i64, _i64, _i64, _ptr, _i64, _ptr, _i64, _ptr, _i64, _ptr, _ptr, _i32, _ptr]),
     "vae_elbo_step_bf16_activations": (_i32, [_ptr]),
     "vae_gemm_bf16_storage_ok": (_i32, [_i32, _i32, _i64, _i64, _i64]),
@@ -47,6 +48,8 @@ SIGNATURES = {
                                _ptr]),
     "vae_gemm_scaled_slabs": (_i32, [_i32, _i64, _i64, _i64, _ptr, _i64, _ptr, _ptr, _i64, _ptr, _ptr, _i64,
                                      C.POINTER(C.c_int), _ptr]),
+    "vae_gemm_rowscaled_ok": (_i32, [_i64, _i64, _i64]),
+    "vae_gemm_rowscaled": (_i32, [_i64, _i64, _i64, _ptr, _i64, _ptr, _i64, _i64, _ptr, _i64, _ptr, _i64, _ptr, _i64, _ptr, _i64, _ptr]),
     "vae_row_mean": (_i32, [_ptr, _i64, _i64, _i64, _ptr, _ptr]),
     "vae_normalize_rows": (_i32, [_ptr, _i64, _i64, _i64, _ptr, _ptr, _i64, _ptr]),
     "vae_normalize_rows_u8": (_i32, [_ptr, _i64, _i64, _i64, _ptr, _ptr, _i64, _ptr]),
@@ -125,7 +128,7 @@ class CellHeads(C.Structure):
     """vae_cell_heads of include/vae_amd.h"""
     _I, _F, _P = C.c_int32 * VAE_MAX_HEADS, C.c_float * VAE_MAX_HEADS, _ptr * VAE_MAX_HEADS
     _fields_ = [("n_heads", C.c_int32), ("width", _I), ("discrete", _I), ("dz_coeff", _F), ("w", _P), ("b", _P), ("dw", _P),
-                ("db", _P)]
+                ("db", _P), ("class_weight", _P)]
 
 
 class StepTensors(C.Structure):

@@ -42,6 +42,7 @@ class ParamArena:
         self.n_layers = n_layers
         self.likelihood = likelihood
         self.device = torch.device(device)
+        self.version = 0          # bumped by touch(): the parameters were written behind the fused optimiser's back
         names = set(params.keys())
         cell = sorted(k for k in names if k.startswith("cell_decoder."))
         # groups = runs of parameters that the kernels address as ONE stacked matrix / vector;
@@ -102,6 +103,12 @@ class ParamArena:
             self.no_grad |= {"decoder.px_dropout_decoder.weight", "decoder.px_dropout_decoder.bias"}
 
     # -- views ---------------------------------------------------------------------------
+    def touch(self) -> None:
+        """Tell dependants that the parameters were written from OUTSIDE the fused optimiser (a checkpoint load, a
+        broadcast, a manual re-initialisation): side products kept by ``FusedAdamW`` (weight maxima, bf16 weight images)
+        are refreshed before the next step uses them."""
+        self.version += 1
+
     def extent(self, k: str) -> int:
         """Floats the parameter occupies in the arena (rows x row stride for a padded matrix)."""
         _, shape = self.offsets[k]

@@ -38,12 +38,16 @@ __device__ __forceinline__ void vae_wave_absmax_store(float* entry, float v) {
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
   if ((threadIdx.x & 63) == 0) *entry = v;
 }
-// Column g of out_k = sum over `chunks` slabs of slab[c][k][g] (slab layout [chunk][3][G]), in chunk order -- the
+// Slabs of the epilogue backward: [chunk][VAE_SLAB_ROWS][G] = per-chunk column SUMS (rows 0..2: d px_r, d bias_scale,
+// d bias_dropout) and per-chunk column MAXIMA of |dlogit_scale|, |dlogit_dropout| (rows 3, 4: the per-gene scales of the
+// two-f16-term decoder weight gradient).
+#define VAE_SLAB_ROWS 5
+// Column g of out_k = sum over `chunks` slabs of slab[c][k][g], in chunk order -- the
 // deterministic reduction of the epilogue backward's per-chunk column sums (four loads in flight).
 __device__ __forceinline__ void vae_colreduce_column(const float* __restrict__ slab, int chunks, int G, int k, int g,
                                                      float* __restrict__ o, int overwrite) {
   const float* p = slab + (int64_t)k * G + g;
-  const int64_t st = (int64_t)3 * G;
+  const int64_t st = (int64_t)VAE_SLAB_ROWS * G;
   float s = 0.f;
   int c = 0;
   for (; c + 4 <= chunks; c += 4) {

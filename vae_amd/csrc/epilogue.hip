@@ -743,7 +743,7 @@ __global__ __launch_bounds__(256) void nbzinb_bwd_kernel(
   __syncthreads();
   if (g0 >= G) return;
   const int nv = min(4, G - g0);  // valid columns of this thread
-  float th[4], lt[4], it[4], acc_t[4], acc_s[4], acc_p[4];
+  float th[4], lt[4], it[4], acc_t[4], acc_s[4], acc_p[4], max_s[4], max_p[4];
   const float* Tg[4];
   const float* Tk[4];   // + first row of the count-indexed rows (tab_load)
 #pragma unroll
@@ -752,7 +752,7 @@ __global__ __launch_bounds__(256) void nbzinb_bwd_kernel(
     Tg[j] = T + g;
     Tk[j] = T + (int64_t)ROW_DGD * G + g;
     th[j] = T[ROW_TH * G + g]; lt[j] = T[ROW_LTE * G + g]; it[j] = T[ROW_ITE * G + g];
-    acc_t[j] = acc_s[j] = acc_p[j] = 0.f;
+    acc_t[j] = acc_s[j] = acc_p[j] = max_s[j] = max_p[j] = 0.f;
   }
   // 3-stage software pipeline over the cells of the chunk:
   //   stage A (cell b+2): HBM loads of (logit_scale, logit_dropout, x)
@@ -795,6 +795,10 @@ __global__ __launch_bounds__(256) void nbzinb_bwd_kernel(
       acc_t[j] += ot.x; acc_t[j + 1] += ot.y;
       acc_s[j] += os.x; acc_s[j + 1] += os.y;
       acc_p[j] += op.x; acc_p[j + 1] += op.y;
+      if (SLAB) {   // per-gene maxima of the gradients this chunk writes (AS STORED: a bf16 store rounds first)
+        max_s[j] = fmaxf(max_s[j], fabsf(os.x)); max_s[j + 1] = fmaxf(max_s[j + 1], fabsf(os.y));
+        max_p[j] = fmaxf(max_p[j], fabsf(op.x)); max_p[j + 1] = fmaxf(max_p[j + 1], fabsf(op.y));
+      }
     }
     LT* w_s = dls + (int64_t)b * ld_ds + g0;
     LT* w_p = ZINB ? dlp + (int64_t)b * ld_dp + g0 : nullptr;
@@ -822,13 +826,14 @@ __global__ __launch_bounds__(256) void nbzinb_bwd_kernel(
   if (SLAB) {
     // partial column sums of this cell chunk: plain coalesced stores into slab[chunk][3][G];
     // colreduce_kernel adds them up in chunk order (deterministic, no float atomics)
-    float* sl = slab + (int64_t)blockIdx.y * 3 * G + g0;
+    float* sl = slab + (int64_t)blockIdx.y * VAE_SLAB_ROWS * G + g0;
 #pragma unroll
     for (int j = 0; j < 4; ++j)
       if (j < nv) {
         sl[j] = acc_t[j];
         sl[G + j] = acc_s[j];
-        if (ZINB) sl[2 * G + j] = acc_p[j];
+        sl[3 * G + j] = max_s[j];
+        if (ZINB) { sl[2 * G + j] = acc_p[j]; sl[4 * G + j] = max_p[j]; }
       }
   } else {
 #pragma unroll
@@ -1001,7 +1006,13 @@ void bwd_grid(int64_t B, int64_t G, int* strips, int* chunks, int* rows_per_bloc
 extern "C" int64_t vae_nbzinb_bwd_workspace_bytes(int64_t B, int64_t G) {
   int strips, chunks, rpb;
   bwd_grid(B, G, &strips, &chunks, &rpb);
-  return (int64_t)chunks * 3 * G * (int64_t)sizeof(float);
+  return (int64_t)chunks * VAE_SLAB_ROWS * G * (int64_t)sizeof(float);
+}
+
+int vae_nbzinb_bwd_chunks(int64_t B, int64_t G) {
+  int strips, chunks, rpb;
+  bwd_grid(B, G, &strips, &chunks, &rpb);
+  return chunks;
 }
 
 int64_t vae_nbzinb_bwd_workgroups(int64_t B, int64_t G) {
@@ -1022,7 +1033,7 @@ static int nbzinb_bwd_impl(int zinb, const LT* logit_scale, int64_t ld_s, const 
   VAE_REQUIRE(logit_scale && x && library && gene_table && rowmax && rowsum && S && dlogit_scale && dpx_r,
               "vae_nbzinb_bwd: null pointer");
   VAE_REQUIRE(!zinb || (logit_dropout && dlogit_dropout), "vae_nbzinb_bwd: ZINB needs the dropout logits and their gradient");
-  VAE_REQUIRE(B > 0 && G > 0, "vae_nbzinb_bwd: bad shape");
+  VAE_REQUIRE(B > 0 && G > 0 && G < (1 << 24), "vae_nbzinb_bwd: bad shape (the gene table is addressed with 24-bit multiplies: G < 2^24)");
   VAE_REQUIRE(ld_s >= G && ld_x >= G && ld_ds >= G && (!zinb || (ld_p >= G && ld_dp >= G)),
               "vae_nbzinb_bwd: leading dimension too small");
   constexpr bool U8 = sizeof(XT) == 1;
@@ -1150,7 +1161,7 @@ int vae_nbzinb_fwd_tiled_ex(int x_dtype, int l_dtype, int zinb, const void* logi
   VAE_REQUIRE(logit_scale && x && library && gene_table && rowmax && rowsum && workspace, "vae_nbzinb_fwd_ws: null pointer");
   VAE_REQUIRE((ll == nullptr) == (S == nullptr), "vae_nbzinb_fwd_ws: ll and S go together");
   VAE_REQUIRE(!zinb || logit_dropout, "vae_nbzinb_fwd_ws: ZINB needs logit_dropout");
-  VAE_REQUIRE(B > 0 && G > 0 && B < (1 << 30) && G < (1 << 30), "vae_nbzinb_fwd_ws: bad shape");
+  VAE_REQUIRE(B > 0 && G > 0 && B < (1 << 30) && G < (1 << 24), "vae_nbzinb_fwd_ws: bad shape (G < 2^24: 24-bit table addressing)");
   VAE_REQUIRE(ld_s >= G && ld_x >= G && (!zinb || ld_p >= G), "vae_nbzinb_fwd_ws: leading dimension too small");
   VAE_REQUIRE(x_dtype == VAE_X_F32 || x_dtype == VAE_X_U8, "vae_nbzinb_fwd_ws: bad x_dtype");
   VAE_REQUIRE(workspace_bytes >= vae_nbzinb_fwd_workspace_bytes(B, G), "vae_nbzinb_fwd_ws: workspace too small");

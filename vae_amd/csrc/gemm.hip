@@ -63,6 +63,13 @@ struct GemmArgs {
   float* stat_m;
   float* stat_s;
   int stat_cols;
+  // gemm_x3_kernel<TN, 128, 128, 2, 2, 0, ROWSC = true>: one power-of-two scale PER ROW m of the product (per column of
+  // the k-major A operand) instead of one for all of A, derived from per-chunk column maxima of |A|: max over c < rmax_chunks
+  // of (m < rmax_split ? rmax0[c * rmax_stride + m] : rmax1[c * rmax_stride + m - rmax_split])
+  const float* rmax0;
+  const float* rmax1;
+  int rmax_split, rmax_chunks;
+  int64_t rmax_stride;
 };
 
 // ---- global -> register tile loaders (R*8/256 float4 per thread per operand, R = 64 or 128) ----
@@ -646,7 +653,8 @@ typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
 // LDS (operand storage, dead by now; at least 4 * 32 * 40 floats when PATCHED); every thread of the workgroup calls it.
 template <int LAYOUT, int BM, int BN, int WAVES_M, int NP, bool CBF, bool PATCHED>
 __device__ __forceinline__ void x3_epilogue(const GemmArgs& g, f32x16 (&acc)[BM / (32 * WAVES_M)][BN / (32 * (4 / WAVES_M))],
-                                            void* smem, int m0, int n0, int tn, int s, float scA, float scB) {
+                                            void* smem, int m0, int n0, int tn, int s, float scA, float scB,
+                                            const float* row_inv = nullptr) {   // LDS: 1 / (row scale) of the tile's BM rows
   constexpr int WAVES_N = 4 / WAVES_M;
   constexpr int TM = BM / (32 * WAVES_M), TNN = BN / (32 * WAVES_N);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -737,8 +745,11 @@ __device__ __forceinline__ void x3_epilogue(const GemmArgs& g, f32x16 (&acc)[BM 
       }
       if (vec_out && nb + 32 <= g.N) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-          patch[((r & 3) + 8 * (r >> 2) + 4 * h) * 40 + l31] = (NP == 2 ? acc[mi][ni][r] * inv_sc : acc[mi][ni][r]) + bv;
+        for (int r = 0; r < 16; ++r) {
+          const int rl = (r & 3) + 8 * (r >> 2) + 4 * h;
+          const float is = row_inv ? inv_sc * row_inv[wm * (32 * TM) + mi * 32 + rl] : inv_sc;
+          patch[rl * 40 + l31] = (NP == 2 ? acc[mi][ni][r] * is : acc[mi][ni][r]) + bv;
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int row = (lane >> 3) + 8 * i;
@@ -774,7 +785,8 @@ __device__ __forceinline__ void x3_epilogue(const GemmArgs& g, f32x16 (&acc)[BM 
         const int m = m0 + wm * (32 * TM) + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
         if (m < g.M) {
           float* p = out + (int64_t)m * ldc + n;
-          float v = (NP == 2 ? acc[mi][ni][r] * inv_sc : acc[mi][ni][r]) + bv;
+          const float is = row_inv ? inv_sc * row_inv[m - m0] : inv_sc;
+          float v = (NP == 2 ? acc[mi][ni][r] * is : acc[mi][ni][r]) + bv;
           if (g.split == 1 && g.accumulate) v += *p;
           *p = v;
         }
@@ -821,9 +833,12 @@ __device__ __forceinline__ void x3_epilogue(const GemmArgs& g, f32x16 (&acc)[BM 
 #ifndef VAE_X3_SCHEDB
 #define VAE_X3_SCHEDB 0
 #endif
-template <int LAYOUT, int BM, int BN, int WAVES_M, int NP, int IO = 0>
-__global__ __launch_bounds__(256, ((VAE_X3_PIPE && NP <= 2 && BM == 128 && BN == 128) ? 2 : (NP <= 2 ? 3 : 2))) void gemm_x3_kernel(GemmArgs g) {
+template <int LAYOUT, int BM, int BN, int WAVES_M, int NP, int IO = 0, bool ROWSC = false>
+__global__ __launch_bounds__(256, ((VAE_X3_PIPE && NP <= 2 && BM == 128 && BN == 128) || ROWSC ? 2 : (NP <= 2 ? 3 : 2))) void gemm_x3_kernel(GemmArgs g) {
   static_assert(IO == 0 || NP == 1, "bf16 storage goes with the one-plane bf16 product");
+  static_assert(!ROWSC || (LAYOUT == TN && NP == 2), "per-row scales: the two-f16-term wgrad");
+  __shared__ __attribute__((aligned(16))) float row_sc[ROWSC ? BM : 4];
+  __shared__ float row_inv[ROWSC ? BM : 4];
   constexpr bool PIPE = VAE_X3_PIPE && NP <= 2 && BM == 128 && BN == 128;   // the 160-wide tiles do not fit two waves per SIMD
   constexpr int STAGES = PIPE ? 2 : 1;
   constexpr bool ABF = (IO & 1) != 0, BBF = (IO & 2) != 0, CBF = (IO & 4) != 0;
@@ -959,8 +974,35 @@ __global__ __launch_bounds__(256, ((VAE_X3_PIPE && NP <= 2 && BM == 128 && BN ==
     return m;
   };
   // Called once, after the first tile's loads are issued (its latency hides behind them) and before the first split
+  // ROWSC: the scales of the four product rows (columns of the k-major A) that chunk i of this thread stages -- its 16 bytes
+  // of the (BM / 4)-quad row, a 16-byte LDS read per chunk (for BM = 128 the same quad every time)
+  auto scale_a4 = [&](int i) {
+    if (ROWSC) return *reinterpret_cast<const float4*>(&row_sc[4 * ((tid + 256 * i) % (BM / 4))]);
+    return make_float4(scA, scA, scA, scA);
+  };
   auto scales = [&]() {
     if (NP != 2) return;
+    if (ROWSC) {   // per-row scales from the producer's per-chunk column maxima; B keeps one scale
+      __shared__ float red_b[4];
+      if (tid < BM) {
+        const int m = m0 + tid;
+        float mx = 0.f;
+        if (m < g.M) {
+          const float* q = m < g.rmax_split ? g.rmax0 + m : g.rmax1 + (m - g.rmax_split);
+          for (int c = 0; c < g.rmax_chunks; ++c) mx = fmaxf(mx, q[(int64_t)c * g.rmax_stride]);
+        }
+        const float sc = vae_scale_from_absmax(mx);
+        row_sc[tid] = sc;
+        row_inv[tid] = 1.f / sc;
+      }
+      float mb = partial_max(g.sb, g.nb);
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) mb = fmaxf(mb, __shfl_xor(mb, o, 64));
+      if (lane == 0) red_b[wave] = mb;
+      __syncthreads();
+      scB = vae_scale_from_absmax(fmaxf(fmaxf(red_b[0], red_b[1]), fmaxf(red_b[2], red_b[3])));
+      return;
+    }
     if (g.na > 0 || g.nb > 0) {  // reduce the producers' partial maxima (a few KB, L2-resident)
       // 8 floats: own storage, or (PIPE: two stages of exactly 40 KB = two workgroups per CU, not a byte to spare) the start
       // of LDS stage 1, which nothing writes before the barrier that follows the first conversion
@@ -981,7 +1023,7 @@ __global__ __launch_bounds__(256, ((VAE_X3_PIPE && NP <= 2 && BM == 128 && BN ==
       if (g.sb) scB = *g.sb;
     }
   };
-  auto put = [&](__bf16* base, int plane, int off, const auto& vin, float sc) {
+  auto put = [&](__bf16* base, int plane, int off, const auto& vin, const float4 sc4) {
     if constexpr (std::is_same_v<std::decay_t<decltype(vin)>, uint2>) {   // bf16 in HBM: already the operand image
       *reinterpret_cast<uint2*>(base + off) = vin;
       return;
@@ -989,10 +1031,11 @@ __global__ __launch_bounds__(256, ((VAE_X3_PIPE && NP <= 2 && BM == 128 && BN ==
     const float4 v = vin;
     const float f[4] = {v.x, v.y, v.z, v.w};
     if (NP == 2) {  // two f16 terms of the scaled value: hi = rn(a s), lo = rn(a s - hi): 22 significant bits
+      const float sc[4] = {sc4.x, sc4.y, sc4.z, sc4.w};
       f16x4 h4, l4;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const float as = f[j] * sc;
+        const float as = f[j] * sc[j];
         const _Float16 h = (_Float16)as;
         h4[j] = h;
         l4[j] = (_Float16)(as - (float)h);
@@ -1023,9 +1066,9 @@ __global__ __launch_bounds__(256, ((VAE_X3_PIPE && NP <= 2 && BM == 128 && BN ==
     __syncthreads();  // the previous tile's fragment reads are done
     GSTAMP();
 #pragma unroll
-    for (int i = 0; i < NA; ++i) put(sA, PLA, wa[i], ra[i], scA);
+    for (int i = 0; i < NA; ++i) put(sA, PLA, wa[i], ra[i], scale_a4(i));
 #pragma unroll
-    for (int i = 0; i < NB; ++i) put(sB, PLB, wb[i], rb[i], scB);
+    for (int i = 0; i < NB; ++i) put(sB, PLB, wb[i], rb[i], make_float4(scB, scB, scB, scB));
     GSTAMP();
     __syncthreads();
     GSTAMP();
@@ -1126,8 +1169,8 @@ __global__ __launch_bounds__(256, ((VAE_X3_PIPE && NP <= 2 && BM == 128 && BN ==
 #endif
     constexpr int NGRP = 2 * TNN, G0 = VAE_X3_G0, NPUT = NA + NB;
     auto put_one = [&](int pidx, __bf16* base) {
-      if (pidx < NA) put(base, PLA, wa[pidx], ra[pidx], scA);
-      else put(base + NP * PLA, PLB, wb[pidx - NA], rb[pidx - NA], scB);
+      if (pidx < NA) put(base, PLA, wa[pidx], ra[pidx], scale_a4(pidx));
+      else put(base + NP * PLA, PLB, wb[pidx - NA], rb[pidx - NA], make_float4(scB, scB, scB, scB));
     };
     auto step = [&](int cur) {
       GSTAMP();
@@ -1187,7 +1230,8 @@ __global__ __launch_bounds__(256, ((VAE_X3_PIPE && NP <= 2 && BM == 128 && BN ==
   }
   GSTAMP();
 
-  x3_epilogue<LAYOUT, BM, BN, WAVES_M, NP, CBF, (NP * (PLA + PLB) * 2 >= 4 * 32 * 40 * 4)>(g, acc, smem, m0, n0, tn, s, scA, scB);
+  x3_epilogue<LAYOUT, BM, BN, WAVES_M, NP, CBF, (NP * (PLA + PLB) * 2 >= 4 * 32 * 40 * 4)>(g, acc, smem, m0, n0, tn, s, scA, scB,
+                                                                                            ROWSC ? row_inv : nullptr);
   GSTAMP();
 }
 
@@ -1516,7 +1560,7 @@ int gemm_impl(int layout, int precision, int64_t M, int64_t N, int64_t K, const 
               int64_t ldb, float* C, int64_t ldc, const float* bias, const float* x_mean, int accumulate,
               float* workspace, int64_t workspace_bytes, void* stream, int* slabs_out, const float* scale_a = nullptr,
               const float* scale_b = nullptr, int n_max_a = 0, int n_max_b = 0, VaeGemmRowStats* stats = nullptr,
-              int io = 0) {
+              int io = 0, const VaeGemmRowScale* rsc = nullptr) {
   VAE_REQUIRE(layout >= 0 && layout <= 2, "vae_gemm: layout must be 0 (NT), 1 (NN) or 2 (TN), got %d", layout);
   VAE_REQUIRE(precision >= 0 && precision <= 3, "vae_gemm: precision must be 0 (fp32), 1 (bf16), 2 (bf16x3) or 3 (f16x2), got %d",
               precision);
@@ -1524,7 +1568,7 @@ int gemm_impl(int layout, int precision, int64_t M, int64_t N, int64_t K, const 
   // exact fp32 MFMA kernel (the scales are then not needed)
   // Without scales (the public vae_gemm(precision = 3), or a step whose shapes fell out of the pipeline) the operands
   // could under- or overflow f16 unscaled: such calls run the three-bf16-term split, which needs no scale.
-  const bool f16x2 = precision == 3 && scale_a && scale_b;
+  const bool f16x2 = precision == 3 && ((scale_a && scale_b) || (rsc && scale_b));
   if (precision == 3) precision = 0;
   VAE_REQUIRE(M > 0 && N > 0 && K > 0 && M < (1 << 30) && N < (1 << 30) && K < (1 << 30),
               "vae_gemm: bad shape M=%lld N=%lld K=%lld", (long long)M, (long long)N, (long long)K);
@@ -1540,6 +1584,7 @@ int gemm_impl(int layout, int precision, int64_t M, int64_t N, int64_t K, const 
               "vae_gemm: partial maxima must be 16-byte aligned");
   g.sa = scale_a; g.sb = scale_b; g.na = n_max_a; g.nb = n_max_b;
   g.stat_m = g.stat_s = nullptr; g.stat_cols = 0;
+  g.rmax0 = g.rmax1 = nullptr; g.rmax_split = g.rmax_chunks = 0; g.rmax_stride = 0;
   if (stats) stats->slots = 0;
   g.lda = lda; g.ldb = ldb; g.ldc = ldc;
   g.M = (int)M; g.N = (int)N; g.K = (int)K;
@@ -1547,7 +1592,7 @@ int gemm_impl(int layout, int precision, int64_t M, int64_t N, int64_t K, const 
   g.vecA = (lda % 4 == 0) && ((io & 1) ? (reinterpret_cast<uintptr_t>(A) & 7u) == 0 : vae_aligned16(A));
   g.vecB = (ldb % 4 == 0) && ((io & 2) ? (reinterpret_cast<uintptr_t>(B) & 7u) == 0 : vae_aligned16(B));
   g.group_m = 0;
-  const Plan plan = make_plan(g.M, g.N, g.K, io == 0);
+  const Plan plan = make_plan(g.M, g.N, g.K, io == 0 && !rsc);   // (bf16 storage and per-row scales exist on the 128-wide tiles only)
   static const int no_dma = getenv("VAE_GEMM_NO_DMA") ? atoi(getenv("VAE_GEMM_NO_DMA")) : 0;  // tuning knob
   const bool norm = x_mean != nullptr;
   const bool a_rc = layout == TN, b_rc = layout != NT;
@@ -1563,6 +1608,13 @@ int gemm_impl(int layout, int precision, int64_t M, int64_t N, int64_t K, const 
     const DmaPlan d = make_dma_plan(g.M, g.N, g.K);
     bm = d.bm; bn = d.bn; split = d.split;
     if (io & 4) split = 1;   // a bf16 output is written by the product kernel itself
+  }
+  VAE_REQUIRE(!rsc || (f16x2 && layout == TN && dma_ok && n_max_b > 0 && rsc->max0 && rsc->chunks > 0 &&
+                       (rsc->split >= M || rsc->max1)),
+              "vae_gemm: per-row scales need the two-f16-term wgrad (TN) on the tile pipeline and the maxima of B");
+  if (rsc) {
+    g.rmax0 = rsc->max0; g.rmax1 = rsc->max1; g.rmax_split = (int)(rsc->split < M ? rsc->split : M); g.rmax_chunks = rsc->chunks;
+    g.rmax_stride = rsc->stride;
   }
   // bf16 storage exists in the one-plane split kernel only: the caller (step.hip) checks the shapes with vae_gemm_bf16io_ok
   VAE_REQUIRE(io == 0 || (precision == 1 && dma_ok && io > 0 && io <= 7 && vae_gemm_bf16_storage_ok(layout, io, M, N, K) &&
@@ -1662,6 +1714,10 @@ int gemm_impl(int layout, int precision, int64_t M, int64_t N, int64_t K, const 
       if (layout == NT) VAE_X3_LAUNCH(NT, 1);
       else if (layout == NN) VAE_X3_LAUNCH(NN, 1);
       else VAE_X3_LAUNCH(TN, 1);
+    } else if (rsc) {   // two f16 terms, one scale per product row (the decoder weight gradient)
+      if (bm == 128 && bn == 128) hipLaunchKernelGGL((gemm_x3_kernel<TN, 128, 128, 2, 2, 0, true>), grid1, dim3(256), 0, st, g);
+      else if (bn == 160)         hipLaunchKernelGGL((gemm_x3_kernel<TN, 128, 160, 4, 2, 0, true>), grid1, dim3(256), 0, st, g);
+      else                        hipLaunchKernelGGL((gemm_x3_kernel<TN, 160, 128, 1, 2, 0, true>), grid1, dim3(256), 0, st, g);
     } else if (f16x2) {
       if (layout == NT) VAE_X3_LAUNCH(NT, 2);
       else if (layout == NN) VAE_X3_LAUNCH(NN, 2);
@@ -1782,6 +1838,19 @@ int vae_gemm_f16x2(int layout, int64_t M, int64_t N, int64_t K, const float* A, 
                    nullptr, slabs_out ? 0 : accumulate, workspace, workspace_bytes, stream, slabs_out, max_a, max_b, n_max_a,
                    n_max_b, stats);
 }
+// whether fp32 operands with 16-byte aligned rows of this shape run the 128-wide tile pipeline (split / LDS-DMA kernels)
+bool vae_gemm_tile_pipeline_ok(int layout, int64_t M, int64_t N, int64_t K) {
+  return vae_gemm_bf16_storage_ok(layout, 1, M, N, K) != 0;   // the same shape conditions
+}
+// C (M, N) = A^T B on two f16 terms with ONE SCALE PER ROW m of the product (per column of the k-major A), from per-chunk
+// column maxima of |A| (VaeGemmRowScale), and one scale for B from its partial maxima: the decoder weight gradient
+int vae_gemm_f16x2_rowscaled(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const VaeGemmRowScale* rsc, const float* B,
+                             int64_t ldb, const float* max_b, int n_max_b, float* C, int64_t ldc, float* workspace,
+                             int64_t workspace_bytes, void* stream) {
+  VAE_REQUIRE(rsc && max_b && n_max_b > 0, "vae_gemm_f16x2_rowscaled: maxima missing");
+  return gemm_impl(TN, 3, M, N, K, A, lda, B, ldb, C, ldc, nullptr, nullptr, 0, workspace, workspace_bytes, stream, nullptr,
+                   nullptr, max_b, 0, n_max_b, nullptr, 0, rsc);
+}
 // vae_gemm that may also leave the softmax statistics of its output rows (see VaeGemmRowStats)
 int vae_gemm_rowstats(int layout, int precision, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B,
                       int64_t ldb, float* C, int64_t ldc, const float* bias, float* workspace, int64_t workspace_bytes,
@@ -1873,6 +1942,20 @@ extern "C" int vae_gemm_scaled(int layout, int64_t M, int64_t N, int64_t K, cons
                    nullptr, scale_a, scale_b);
 }
 
+extern "C" int vae_gemm_rowscaled_ok(int64_t M, int64_t N, int64_t K) { return vae_gemm_tile_pipeline_ok(TN, M, N, K) ? 1 : 0; }
+
+extern "C" int vae_gemm_rowscaled(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* col_max, int64_t n_chunks,
+                                  int64_t ld_max, const float* B, int64_t ldb, const float* b_max, int64_t n_b_max, float* C,
+                                  int64_t ldc, float* workspace, int64_t workspace_bytes, void* stream) {
+  VAE_REQUIRE(col_max && b_max && n_chunks > 0 && n_chunks < (1 << 20) && ld_max >= M && n_b_max > 0 && n_b_max < (1 << 24),
+              "vae_gemm_rowscaled: maxima missing or misshapen");
+  VAE_REQUIRE(M > 0 && N > 0 && K > 0 && vae_gemm_rowscaled_ok(M, N, K), "vae_gemm_rowscaled: M=%lld N=%lld K=%lld is outside the tile pipeline",
+              (long long)M, (long long)N, (long long)K);
+  VAE_REQUIRE(A && B && C && lda % 4 == 0 && ldb % 4 == 0 && vae_aligned16(A) && vae_aligned16(B), "vae_gemm_rowscaled: operands need 16-byte aligned rows");
+  const VaeGemmRowScale rsc{col_max, nullptr, M, (int)n_chunks, ld_max};
+  return vae_gemm_f16x2_rowscaled(M, N, K, A, lda, &rsc, B, ldb, b_max, (int)n_b_max, C, ldc, workspace, workspace_bytes, stream);
+}
+
 extern "C" int vae_gemm_scaled_slabs(int layout, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
                                      const float* scale_a, const float* B, int64_t ldb, const float* scale_b,
                                      float* workspace, int64_t workspace_bytes, int* n_slabs, void* stream) {
@@ -1901,9 +1984,15 @@ namespace {
 float* g_scratch_ptr[NOALLOC_MAX_DEVICES];       // per device, null until the first call on that device
 std::mutex g_scratch_mutex;
 
-int noalloc_scratch(float** out) {
+// stream != null: the lookup is keyed on the STREAM's device, which must be the current one (as for any launch on it)
+int noalloc_scratch(float** out, void* stream) {
   int dev = -1;
   if (hipGetDevice(&dev) != hipSuccess) return vae_set_error(VAE_ERR_LAUNCH, "vae_gemm_noalloc: hipGetDevice failed (no GPU?)");
+  if (stream) {
+    int sdev = -1;
+    if (hipStreamGetDevice((hipStream_t)stream, &sdev) == hipSuccess && sdev != dev)
+      return vae_set_error(VAE_ERR_ARG, "vae_gemm_noalloc: the stream belongs to device %d, the current device is %d", sdev, dev);
+  }
   VAE_REQUIRE(dev >= 0 && dev < NOALLOC_MAX_DEVICES, "vae_gemm_noalloc: device ordinal %d outside [0, %d)", dev, NOALLOC_MAX_DEVICES);
   std::lock_guard<std::mutex> lock(g_scratch_mutex);
   if (!g_scratch_ptr[dev]) {
@@ -1917,6 +2006,13 @@ int noalloc_scratch(float** out) {
   return VAE_OK;
 }
 }  // namespace
+
+// Resolves the current device's scratch address now (idempotent): callers that will run vae_gemm_noalloc under HIP graph
+// capture call this once per device BEFORE capturing, so that no runtime query happens inside the capture.
+extern "C" int vae_gemm_noalloc_init(void) {
+  float* p = nullptr;
+  return noalloc_scratch(&p, nullptr);
+}
 
 extern "C" int64_t vae_gemm_noalloc_max_bytes(void) { return NOALLOC_BYTES; }
 
@@ -1932,7 +2028,7 @@ extern "C" int vae_gemm_noalloc(int layout, int precision, int64_t M, int64_t N,
               (long long)NOALLOC_BYTES);
   float* ws = nullptr;
   if (need > 0) {   // slabs are fully overwritten before they are read: nothing to clear between calls
-    const int rc = noalloc_scratch(&ws);
+    const int rc = noalloc_scratch(&ws, stream);
     if (rc != VAE_OK) return rc;
   }
   return gemm_impl(layout, precision, M, N, K, A, lda, B, ldb, C, ldc, bias, x_mean, accumulate, ws, need, stream, nullptr);

@@ -32,6 +32,19 @@ int vae_gemm_f16x2(int layout, int64_t M, int64_t N, int64_t K, const float* A, 
                    const float* B, int64_t ldb, const float* max_b, int n_max_b, float* C, int64_t ldc, const float* bias,
                    int accumulate, float* workspace, int64_t workspace_bytes, void* stream, int* slabs_out,
                    VaeGemmRowStats* stats = nullptr);
+// Per-row scales of the two-f16-term wgrad: row m's scale comes from max over c < chunks of
+// (m < split ? max0[c * stride + m] : max1[c * stride + m - split])
+struct VaeGemmRowScale {
+  const float* max0;
+  const float* max1;
+  int64_t split;
+  int chunks;
+  int64_t stride;
+};
+bool vae_gemm_tile_pipeline_ok(int layout, int64_t M, int64_t N, int64_t K);
+int vae_gemm_f16x2_rowscaled(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const VaeGemmRowScale* rsc, const float* B,
+                             int64_t ldb, const float* max_b, int n_max_b, float* C, int64_t ldc, float* workspace,
+                             int64_t workspace_bytes, void* stream);
 int vae_gemm_rowstats(int layout, int precision, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B,
                       int64_t ldb, float* C, int64_t ldc, const float* bias, float* workspace, int64_t workspace_bytes,
                       VaeGemmRowStats* stats, void* stream);
@@ -72,7 +85,8 @@ int vae_softmax_stats_merge(const float* stat_m, const float* stat_s, int slots,
 // Entries of the partial-maxima arrays the producers below fill (all of them, every call)
 #define VAE_NORM_WAVES 4           /* vae_normalize_rows_ex / vae_gene_dropout_ex: B * 4 entries      */
 #define VAE_MID_WAVES 8            /* vae_mid_forward / vae_mid_backward: B * 8 entries               */
-int64_t vae_nbzinb_bwd_workgroups(int64_t B, int64_t G);   /* vae_nbzinb_bwd_ex: one entry per workgroup */
+int64_t vae_nbzinb_bwd_workgroups(int64_t B, int64_t G);
+int vae_nbzinb_bwd_chunks(int64_t B, int64_t G);           /* cell chunks = slabs [chunk][VAE_SLAB_ROWS][G] it leaves */   /* vae_nbzinb_bwd_ex: one entry per workgroup */
 
 // vae_normalize_rows / _u8 (x_dtype) that also stores the per-wave maxima of |xn| (absmax may be null)
 // xn_bf16 != 0: xn is written as bf16 (ld_xn in elements, % 8 == 0)

@@ -1272,8 +1272,10 @@ __global__ __launch_bounds__(256) void cell_heads_kernel(HeadsArgs a) {
       const bool valid = ti != -100 && ti >= 0 && ti < n;   // ignore_index (task.py:437)
       if (valid) {
         const float p = expf(logit - m) / ssum;
-        dl = (p - (lane - s0 == ti ? 1.f : 0.f)) * mk * a.scale;
-        if (lane == s0) lossc = (logf(ssum) + m - lg[wave][s0 + ti]) * mk * a.inv_b;
+        const float* cw = a.h.class_weight[hh];              // balance_classes (task.py:129-132): weight of the target's class
+        const float wk = cw ? cw[ti] * mk : mk;
+        dl = (p - (lane - s0 == ti ? 1.f : 0.f)) * wk * a.scale;
+        if (lane == s0) lossc = (logf(ssum) + m - lg[wave][s0 + ti]) * wk * a.inv_b;
       }
     } else {
       const float d = logit - t;

@@ -229,7 +229,7 @@ int check_common(const vae_step_config* cfg, const void* a, const void* b, const
   if (!make_layout(*cfg, lo)) return vae_set_error(VAE_ERR_ARG, "%s: bad configuration", who);
   if (ldx < cfg->G) return vae_set_error(VAE_ERR_ARG, "%s: ldx < G", who);
   if (cfg->x_dtype != VAE_X_F32 && cfg->x_dtype != VAE_X_U8) return vae_set_error(VAE_ERR_ARG, "%s: bad x_dtype", who);
-  if (cfg->B >= (1 << 30) || cfg->G >= (1 << 29))
+  if (cfg->B >= (1 << 30) || cfg->G >= (1 << 24))   // (the likelihood kernels address the gene table with 24-bit multiplies)
     return vae_set_error(VAE_ERR_ARG, "%s: B=%lld / G=%lld too large", who, (long long)cfg->B, (long long)cfg->G);
   if (!(cfg->l_var > 0.f)) return vae_set_error(VAE_ERR_ARG, "%s: l_var must be positive", who);
   if (cfg->precision != VAE_FP32 && cfg->precision != VAE_BF16 && cfg->precision != VAE_FP32_F16X2)
@@ -474,7 +474,14 @@ extern "C" int vae_elbo_step_backward_events(const vae_step_config* cfg, const v
   if (k.hb())   // px16: the bf16 image the forward made
     TRY(vae_gemm_bf16io(VAE_TN, VAE_IO_A_BF16 | VAE_IO_B_BF16, NH, Hd, B, logits, NH, k.h16(lo.px16), Hd, g->heads_w, Hd, nullptr,
                         ws + lo.scratch, lo.scratch_floats * 4, nullptr, nullptr, stream));
-  else
+  else if (k.fx() && vae_gemm_tile_pipeline_ok(VAE_TN, NH, Hd, B) && !getenv("VAE_WGRAD_EXACT")) {
+    // two f16 terms with one scale PER GENE: the backward epilogue left per-chunk maxima of every gene's column of both
+    // gradient arrays in its slabs (rows 3, 4), the product derives a power of two per output row from them
+    const VaeGemmRowScale rsc{ws + lo.bwd_slabs + 3 * G, c.zinb ? ws + lo.bwd_slabs + 4 * G : nullptr, G, vae_nbzinb_bwd_chunks(B, G),
+                              (int64_t)VAE_SLAB_ROWS * G};
+    TRY(vae_gemm_f16x2_rowscaled(NH, Hd, B, logits, NH, &rsc, px, Hd, k.am(AM_PX), k.an(AM_PX), g->heads_w, Hd, ws + lo.scratch,
+                                 lo.scratch_floats * 4, stream));
+  } else
     TRY(k.gemm(VAE_TN, NH, Hd, B, logits, NH, px, Hd, g->heads_w, Hd, nullptr, nullptr, 0));
   if (event_heads_ready) {
     if (hipEventRecord((hipEvent_t)event_heads_ready, (hipStream_t)stream) != hipSuccess)

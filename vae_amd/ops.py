@@ -160,6 +160,36 @@ def gemm_scaled(layout: int, a: torch.Tensor, b: torch.Tensor, scale_a: Optional
     return out
 
 
+def gemm_rowscaled(a: torch.Tensor, b: torch.Tensor, col_max: Optional[torch.Tensor] = None, b_max: Optional[torch.Tensor] = None, *,
+                   out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """a(K, M)^T b(K, N) -> out(M, N) on two f16 terms with one power-of-two scale per OUTPUT ROW (include/vae_amd.h,
+    vae_gemm_rowscaled: the step's decoder-head weight gradient).  ``col_max`` (chunks, M): maxima of |a| per column over
+    chunks of its rows (default: one chunk, computed here); ``b_max``: partial maxima of |b| (default: computed here)."""
+    lib = _lib.load()
+    _chk2d(a, "a"); _chk2d(b, "b")
+    (K, M), (K2, N) = a.shape, b.shape
+    if K != K2:
+        raise ValueError(f"vae_amd.ops.gemm_rowscaled: inner dimensions differ ({K} vs {K2})")
+    if not lib.vae_gemm_rowscaled_ok(M, N, K):
+        raise ValueError(f"vae_amd.ops.gemm_rowscaled: shape {(M, N, K)} is outside the tile pipeline")
+    if col_max is None:
+        col_max = a.abs().amax(dim=0, keepdim=True).contiguous()
+    if b_max is None:
+        b_max = b.abs().amax().expand(4).contiguous()
+    _chk2d(col_max, "col_max")
+    if col_max.shape[1] < M or b_max.dim() != 1 or b_max.dtype != torch.float32 or not b_max.is_cuda or not b_max.is_contiguous():
+        raise ValueError("vae_amd.ops.gemm_rowscaled: col_max must be (chunks, >= M), b_max a contiguous 1-D float32 GPU tensor")
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.float32, device=a.device)
+    _chk2d(out, "out")
+    nbytes = lib.vae_gemm_workspace_bytes(M, N, K)
+    ws = workspace(nbytes, a.device) if nbytes else None
+    rc = lib.vae_gemm_rowscaled(M, N, K, _p(a), _ld(a), _p(col_max), col_max.shape[0], _ld(col_max), _p(b), _ld(b), _p(b_max),
+                                b_max.numel(), _p(out), _ld(out), _p(ws), nbytes, _stream())
+    _lib.check(rc, "gemm_rowscaled")
+    return out
+
+
 IO_A_BF16, IO_B_BF16, IO_C_BF16 = 1, 2, 4
 
 

@@ -36,8 +36,8 @@ class FusedAdamW:
         ``track_weight_maxima``: every step also leaves the partial maxima of the two gene-sized weight matrices
         (first-layer encoder weights, decoder-head weights) in ``self.weight_maxima`` (2, P) while it stores the updated
         weights; ``ElboStep.use_weight_maxima(opt)`` then skips the step's own 72 MB scan for the two-f16-term GEMM
-        scales.  Anything else that changes those weights (loading a checkpoint, a broadcast) must call
-        ``refresh_weight_maxima()``.
+        scales.  Anything else that changes those weights must call ``arena.touch()`` (``broadcast_parameters`` and
+        ``LitVAE``'s state-dict load hook do) or ``refresh_weight_maxima()``.
 
         ``track_bf16_images``: the bf16-mode counterpart -- every step also leaves bf16 images (nearest even) of the same
         two matrices in ``self.weight_images`` while it stores the updated weights; ``ElboStep.use_weight_images(opt)``
@@ -111,6 +111,16 @@ class FusedAdamW:
         if track_bf16_images:
             self.weight_images = tuple(torch.empty(e - b, dtype=torch.bfloat16, device=arena.device) for b, e in self._max_spans)
             self.refresh_weight_images()
+        self._seen_version = arena.version
+
+    def sync(self) -> None:
+        """Refresh the tracked side products when the arena was written by anything but ``step()`` since they were made
+        (``ParamArena.touch()``: ``broadcast_parameters`` and ``LitVAE``'s load hook call it; ``ElboStep`` calls this before
+        every step that consumes them -- an integer compare)."""
+        if self._seen_version != self.arena.version:
+            self.refresh_weight_maxima()
+            self.refresh_weight_images()
+            self._seen_version = self.arena.version
 
     def refresh_weight_images(self) -> None:
         """Recompute the bf16 images from the weights as they are now (after anything but ``step()`` changed them)."""

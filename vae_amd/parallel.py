@@ -166,3 +166,4 @@ def broadcast_parameters(arena: ParamArena, src: int = 0, group=None) -> None:
             arena.flat.copy_(host)
         else:
             dist.broadcast(arena.flat, src=src, group=group)
+        arena.touch()   # weight maxima / bf16 images a FusedAdamW keeps are stale now

@@ -76,7 +76,9 @@ class CellHeads:
     on ``ElboStep.run(cell_head_fn=...)`` (torch autograd on the (B, L) latent)."""
 
     def __init__(self, arena: ParamArena, cell_properties: Dict[str, dict], grad_reverse: Optional[Dict[str, float]] = None,
-                 prefix: str = "cell_decoder.cell_mlp."):
+                 prefix: str = "cell_decoder.cell_mlp.", class_weights: Optional[Dict[str, torch.Tensor]] = None):
+        """``class_weights``: per discrete head, the ``weight`` of its ``nn.CrossEntropyLoss`` (``balance_classes``,
+        task.py:129-132: ``clip(1 / freq, 0.1, 10)``); heads without an entry are unweighted."""
         self.lib = _lib.load()
         self.arena = arena
         names = list(cell_properties)
@@ -85,6 +87,7 @@ class CellHeads:
         h = _lib.CellHeads()
         h.n_heads = len(names)
         self.L = None
+        self._class_weights = []
         for i, k in enumerate(names):
             wk, bk = f"{prefix}{k}.weight", f"{prefix}{k}.bias"
             if wk not in arena.offsets or bk not in arena.offsets:
@@ -102,6 +105,15 @@ class CellHeads:
                 h.dz_coeff[i] = 0.0 if prop["stop_grad"] else 1.0
             h.w[i], h.b[i] = w.data_ptr(), arena.p(bk).data_ptr()
             h.dw[i], h.db[i] = arena.g(wk).data_ptr(), arena.g(bk).data_ptr()
+            cw = (class_weights or {}).get(k)
+            if cw is not None:
+                if not prop["discrete"]:
+                    raise ValueError(f"CellHeads: head {k!r} is continuous: class weights apply to discrete heads")
+                cw = torch.as_tensor(cw, dtype=torch.float32).to(arena.device).contiguous()
+                if cw.shape != (width,):
+                    raise ValueError(f"CellHeads: head {k!r}: {width} class weights expected, got {tuple(cw.shape)}")
+                self._class_weights.append(cw)     # keeps the device memory alive
+                h.class_weight[i] = cw.data_ptr()
         if self.L > 64 or sum(h.width[i] for i in range(len(names))) > 64:
             raise ValueError("CellHeads: the native heads take a latent of at most 64 and at most 64 outputs in all")
         self.h, self.n = h, len(names)
@@ -195,6 +207,7 @@ class ElboStep:
         self.grads = _tensors(a.g, a.gcat, self.n_layers, self.zinb)
         self.weight_maxima = None
         self.weight_images = None
+        self._maxima_source = self._images_source = None
         self._plans: Dict[int, tuple] = {}
         self.max_plans = 4          # distinct (batch size, training) workspaces kept alive (train, validation, two tails)
         self._ev_heads = self._ev_small = None
@@ -206,6 +219,7 @@ class ElboStep:
         ``track_weight_maxima=True``, or a (2, P) float32 GPU tensor kept current by the caller; ``None`` = scan again)
         instead of scanning 72 MB of weights at the start of every two-f16-term forward."""
         t = getattr(source, "weight_maxima", source)
+        self._maxima_source = source if hasattr(source, "sync") else None
         if t is not None and (not torch.is_tensor(t) or t.dim() != 2 or t.shape[0] != 2 or t.dtype != torch.float32
                               or not t.is_cuda or not t.is_contiguous() or t.shape[1] % 4):
             raise ValueError("ElboStep.use_weight_maxima: need a contiguous (2, P) float32 GPU tensor, P a multiple of 4")
@@ -217,6 +231,7 @@ class ElboStep:
         encoder weights as stored in the arena, row padding included, and the decoder-head weights; ``None`` = cast again)
         instead of casting them at the start of every bf16-storage forward.  Other precision modes ignore them."""
         t = getattr(source, "weight_images", source)
+        self._images_source = source if hasattr(source, "sync") else None
         if t is not None:
             want = ((self.H + self.Hl) * self.a.ld_enc_w, (2 if self.zinb else 1) * self.G * self.Hd)
             ok = isinstance(t, (tuple, list)) and len(t) == 2 and all(
@@ -279,6 +294,9 @@ class ElboStep:
         cfg, ws, nbytes, v = self._plans[key]
         cfg.loss_scale = float(loss_scale)
         cfg.kl_weight = self.kl_weight
+        for src in (self._maxima_source, self._images_source):   # stale after a load / broadcast? (ParamArena.touch)
+            if src is not None:
+                src.sync()
         wm = self.weight_maxima
         cfg.weight_max_enc = wm[0].data_ptr() if wm is not None else None
         cfg.weight_max_heads = wm[1].data_ptr() if wm is not None else None

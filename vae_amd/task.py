@@ -20,14 +20,30 @@ from .distributions import NegativeBinomial, Poisson, ZeroInflatedNegativeBinomi
 from .step import CellHeads, ElboStep
 
 
+def class_balance_weights(cell_properties: Dict[str, Any]) -> Dict[str, torch.Tensor]:
+    """Per discrete property the ``weight`` of its cross-entropy under ``balance_classes`` (task.py:129-132):
+    ``clip(1 / freq, 0.1, 10)`` as float32, from the property's ``freq`` entry (data.py fills it)."""
+    out = {}
+    for k, prop in cell_properties.items():
+        if prop["discrete"]:
+            if "freq" not in prop:
+                raise ValueError(f"balance_classes: cell property {k!r} has no 'freq' entry (class frequencies)")
+            out[k] = torch.from_numpy(np.float32(np.clip(1 / np.asarray(prop["freq"]), 0.1, 10.0)))
+    return out
+
+
 def cell_loss(cell_pred: Dict[str, torch.Tensor], cell_properties: Dict[str, Any], cell_prop_vals: torch.Tensor,
-              cell_mask: torch.Tensor, weights=1.0) -> torch.Tensor:
+              cell_mask: torch.Tensor, weights=1.0, class_weights: Optional[Dict[str, torch.Tensor]] = None) -> torch.Tensor:
     """LitVAE._cell_loss without GroupDRO (task.py:419-451): masked cross-entropy (ignore_index
-    -100) / MSE per property, each averaged over ALL cells of the batch."""
+    -100; per-class ``class_weights`` under balance_classes, task.py:129-132) / MSE per property, each averaged over
+    ALL cells of the batch."""
     total = 0.0
     for n, (k, prop) in enumerate(cell_properties.items()):
         if prop["discrete"]:
-            per = nn.functional.cross_entropy(cell_pred[k], cell_prop_vals[:, n].to(torch.int64), reduction="none",
+            cw = (class_weights or {}).get(k)
+            if cw is not None:
+                cw = cw.to(device=cell_pred[k].device, dtype=cell_pred[k].dtype)
+            per = nn.functional.cross_entropy(cell_pred[k], cell_prop_vals[:, n].to(torch.int64), weight=cw, reduction="none",
                                               ignore_index=-100)
         else:
             per = (torch.squeeze(cell_pred[k]) - cell_prop_vals[:, n]) ** 2
@@ -102,6 +118,8 @@ class LitVAE(nn.Module):
         # its cast of the two gene-sized weight matrices
         self.weight_maxima_source = None
         self._create_results_dict()
+        # balance_classes (task.py:129-132): class weights of every discrete head's cross-entropy
+        self.class_weights = class_balance_weights(cell_properties) if (balance_classes and cell_properties) else None
         if use_gdro:
             raise NotImplementedError("vae_amd: GroupDRO re-weighting (off in the shipped config) is not wired in")
 
@@ -147,7 +165,7 @@ class LitVAE(nn.Module):
         return loss, kl_z
 
     def _cell_loss(self, cell_pred, cell_prop_vals, cell_mask, group_idx):
-        return cell_loss(cell_pred, self.cell_properties, cell_prop_vals, cell_mask)
+        return cell_loss(cell_pred, self.cell_properties, cell_prop_vals, cell_mask, class_weights=self.class_weights)
 
     def training_step(self, batch, batch_idx):
         self.train_step += 1
@@ -314,6 +332,10 @@ class LitVAE(nn.Module):
             p.data = arena.p(k)
             p.grad = None if k in arena.no_grad else arena.g(k)
         self._arena = arena
+        # a checkpoint loaded into the network writes the arena views behind the optimiser's back
+        if getattr(self, "_load_hook", None) is not None:
+            self._load_hook.remove()
+        self._load_hook = net.register_load_state_dict_post_hook(lambda *_: arena.touch())
         self._fused = self._fused_val = None
         self._l1 = None
         self._native_heads = None
@@ -365,10 +387,17 @@ class LitVAE(nn.Module):
         fn = heads = None
         if self.cell_properties is not None and cell_prop_vals is not None:
             if getattr(self, "_native_heads", None) is None:   # linear heads (the shipped setting): native kernels
-                try:
-                    self._native_heads = CellHeads(self._arena, self.cell_properties, self.network.cell_decoder.grad_reverse_dict)
-                except ValueError:
-                    self._native_heads = False                  # hidden-layer heads: torch autograd on the (B, L) latent
+                dec = self.network.cell_decoder
+                if dec.grad_reverse_dict is None:   # the module path (and the reference, modules.py:317) raise here too
+                    raise AttributeError("CellDecoder: grad_reverse_dict is None (pass a dict, may be empty)")
+                hidden = any(not isinstance(m, nn.Linear) for m in dec.cell_mlp.values())
+                widths = sum(len(v["values"]) if v["discrete"] else 1 for v in self.cell_properties.values())
+                from . import _lib
+                if hidden or len(self.cell_properties) > _lib.VAE_MAX_HEADS or widths > 64 or self.network.n_latent > 64:
+                    self._native_heads = False      # hidden-layer heads / beyond the kernel's limits: torch autograd on (B, L)
+                else:                               # any other configuration error surfaces
+                    self._native_heads = CellHeads(self._arena, self.cell_properties, dec.grad_reverse_dict,
+                                                   class_weights=self.class_weights)
             if self._native_heads:
                 heads = (self._native_heads, cell_prop_vals.to(torch.float32), cell_mask.to(torch.float32))
             else:
