@@ -47,8 +47,9 @@ HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s
 # dense TFLOP/s.  fp32 GEMMs run as six bf16 MFMA products per fp32 multiply-add (exact 3-way operand
 # split, gemm.hip), so their ceiling in ALGORITHMIC fp32 flops is the bf16 peak / 6 -- above the
 # 157.3 TFLOP/s of the fp32 MFMA instruction that the first version of the path used.
-MFMA_PEAK = {"fp32": 2500.0 / 3.0, "fp32x3": 2500.0 / 6.0, "bf16": 2500.0}
-MFMA_BASIS = {"fp32": "f16 dense 2500 TFLOP/s / 3 products per fp32 multiply-add (two scaled f16 terms); the fp32 MFMA peak is 157.3",
+MFMA_PEAK = {"fp32": 2500.0 / 3.0, "fp32x2": 2500.0 / 2.0, "fp32x3": 2500.0 / 6.0, "bf16": 2500.0}
+MFMA_BASIS = {"fp32x2": "f16 dense 2500 TFLOP/s / 2 products per fp32 multiply-add (integer counts on one f16 term x two-term weights / gradients)",
+              "fp32": "f16 dense 2500 TFLOP/s / 3 products per fp32 multiply-add (two scaled f16 terms); the fp32 MFMA peak is 157.3",
               "fp32x3": "bf16 dense 2500 TFLOP/s / 6 products per fp32 multiply-add (three bf16 terms); the fp32 MFMA peak is 157.3",
               "bf16": "bf16 dense 2500 TFLOP/s"}
 DTYPE_TEXT = {"fp32": "f32 (the five gene-sized GEMMs: operands scaled by a power of two -- the decoder weight gradient: one per gene -- "
@@ -133,8 +134,17 @@ def kernel_breakdown(arena, cfg, x, precision, bf16_storage=False):
         mm = lambda lay, a, b, out=None: ops.gemm_scaled(lay, a, b, sc[id(a)], sc[id(b)], out=out)  # noqa: E731
     else:
         mm = lambda lay, a, b, out=None: ops.gemm(lay, a, b, out=out, precision=P)  # noqa: E731
-    if mm is not None:
+    if mm is not None and P == ops.F16X2 and not os.environ.get("VAE_NO_XDIRECT"):
+        # the two encoder products of this mode stream the RAW counts (vae_gemm_counts): one f16 term for the integer counts
+        _, xmax, xflags, _ = ops.row_stats(x, w_enc)
+        wmax = w_enc.abs().amax().expand(4).contiguous()
+        dps = (dpre / mean[:, None]).contiguous()
+        dmax, colsum = dps.abs().amax().expand(4).contiguous(), dpre.sum(dim=0)
+        ks["row_stats"] = (time_kernel(lambda: ops.row_stats(x, w_enc)), "hbm", 4.0 * (B + H + Hl) * G)
+        ks["gemm_enc_fwd"] = (time_kernel(lambda: ops.gemm_counts(ops.NT, x, w_enc, xmax, wmax, xflags)), "mfma", fl(B, H + Hl, G), "fp32x2")
+    elif mm is not None:
         ks["gemm_enc_fwd"] = (time_kernel(lambda: mm(ops.NT, xn, w_enc)), "mfma", fl(B, H + Hl, G))
+    if mm is not None:
         ks["gemm_dec_fwd"] = (time_kernel(lambda: mm(ops.NT, px, w_heads, logits)), "mfma", fl(B, NH, Hd))
         if P == ops.F16X2:
             sc[id(logits)] = ops.absmax_scale(logits)
@@ -147,7 +157,11 @@ def kernel_breakdown(arena, cfg, x, precision, bf16_storage=False):
             wg = lambda: mm(ops.TN, logits, px, gw_heads)  # noqa: E731
         ks["gemm_dec_wgrad"] = (time_kernel(wg), "mfma", fl(NH, Hd, B))
         ks["gemm_dec_dgrad"] = (time_kernel(lambda: mm(ops.NN, logits, w_heads)), "mfma", fl(B, Hd, NH))
-        ks["gemm_enc_wgrad"] = (time_kernel(lambda: mm(ops.TN, dpre, xn, gw_enc)), "mfma", fl(H + Hl, G, B))
+        if "row_stats" in ks:
+            ks["gemm_enc_wgrad"] = (time_kernel(lambda: ops.gemm_counts(ops.TN, dps, x, dmax, xmax, xflags, row_sub=colsum, out=gw_enc)),
+                                    "mfma", fl(H + Hl, G, B), "fp32x2")
+        else:
+            ks["gemm_enc_wgrad"] = (time_kernel(lambda: mm(ops.TN, dpre, xn, gw_enc)), "mfma", fl(H + Hl, G, B))
     logits.normal_()
     lb = 2 if bf16_storage else 4                 # bytes per stored logit
     per = 4 + (2 if zinb else 1) * lb

@@ -99,6 +99,28 @@ int vae_gemm_scaled_slabs(int layout, int64_t M, int64_t N, int64_t K, const flo
                           const float* B, int64_t ldb, const float* scale_b, float* workspace, int64_t workspace_bytes,
                           int* n_slabs, void* stream);
 
+/* The count-operand form of the encoder's first layer (Encoder.forward, modules.py:264,267: Linear over x / mean - 1).
+ * x / mean - 1 is never materialised:
+ *   forward          (x / m - 1) W^T = (x W^T) / m - sum_g W[:, g]
+ *   weight gradient  dpre^T (x / m - 1) = (dpre / m)^T x - colsum(dpre) 1^T
+ * so both gene-sized products stream the RAW fp32 counts, which are exact in ONE scaled f16 term when they are integers
+ * below 2048 (single-cell counts; the reference stores them as uint8, create_dataset.py:131-142): that operand's lo
+ * term, its LDS plane and one of the three matrix-core products fall away.
+ * vae_row_stats: mean[b] of row b of x (B, G), per-wave maxima of |x| and per-wave flags "some count needs its lo term"
+ *   (4 entries per row each: absmax / flags hold B * 4 floats, 16-byte aligned), and wsum[h] = sum_g W[h, g] of the (HE, G)
+ *   weight, one launch, fixed summation order.
+ * vae_gemm_counts: vae_gemm on two f16 terms (as vae_gemm_scaled, the scales derived from n_max partial maxima per
+ *   operand) where the count operand is A for VAE_NT and B for VAE_TN.  VAE_NT: when every flag is 0 the counts run on their
+ *   hi term alone, otherwise the kernel takes the plain two-term loop (decided on the device).  VAE_TN: always two terms
+ *   (flags may be NULL; the one-term form of this product measured slower -- it is bound by the latency of its K steps,
+ *   not by its matrix-core work).  row_sub (nullable, VAE_TN, M floats): C[m, n] -= row_sub[m].  Shapes outside the 128-wide tile pipeline are rejected (vae_gemm_rowscaled_ok's conditions,
+ *   with the layout's own alignment: K % 4 == 0, TN: M % 4 == N % 4 == 0).                                              */
+int vae_row_stats(const float* x, int64_t ldx, int64_t B, int64_t G, float* mean, float* absmax, float* flags, const float* W,
+                  int64_t ldw, int64_t HE, float* wsum, void* stream);
+int vae_gemm_counts(int layout, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* max_a, int64_t n_max_a,
+                    const float* B, int64_t ldb, const float* max_b, int64_t n_max_b, float* C, int64_t ldc, const float* flags,
+                    int64_t n_flags, const float* row_sub, float* workspace, int64_t workspace_bytes, void* stream);
+
 /* The weight-gradient product C (M, N) = A^T B (A stored (K, M), B stored (K, N): layout VAE_TN; dW = dy^T x of an
  * nn.Linear, modules.py:361-369) on two f16 terms with ONE POWER-OF-TWO SCALE PER OUTPUT ROW m instead of one for all of A:
  * the decoder-head weight gradient of the training step, where column m of A = dlogits is gene m's gradient and its

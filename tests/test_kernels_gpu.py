@@ -107,6 +107,52 @@ def test_gemm_rowscaled_keeps_every_row_fp32_grade(ops, shape):
         ops.gemm_rowscaled(A[:, :30].contiguous(), Bm)                           # outside the tile pipeline
 
 
+@pytest.mark.parametrize("counts", ["integer", "fractional", "large"])
+@pytest.mark.parametrize("B,G,HE", [(512, 20000, 384), (384, 4096, 256), (2304, 4096, 384)])
+def test_count_operand_products(ops, B, G, HE, counts):
+    """vae_row_stats + vae_gemm_counts: the encoder's first layer and its weight gradient over the RAW counts,
+    (x W^T) / m - sum W and (dpre / m)^T x - colsum(dpre) 1^T (modules.py:264,267).  Integer counts below 2048 run on ONE
+    f16 term (flags all zero); fractional counts (mixup, data.py:457-477) or counts from 2048 on must make the kernels
+    take the two-term loop -- the same fp32-grade accuracy against fp64 in every case (a one-term product of inexact
+    counts would be off by 2^-11)."""
+    g = torch.Generator().manual_seed(61)
+    x = torch.poisson(torch.rand(B, G, generator=g) * 3.0, generator=g) * (torch.rand(B, G, generator=g) > 0.5)
+    x[:, 0] += 1.0
+    if counts == "fractional":
+        x = x * 0.63 + 0.11 * torch.rand(B, G, generator=g)
+    if counts == "large":
+        x[3, 5], x[7, 9] = 2049.0, 40001.0         # 12 significant bits; beyond 2^15
+    w = _rand((HE, G), 62, 0.05).float()
+    dpre = (_rand((B, HE), 63, 1e-3) * torch.exp2(torch.randint(-6, 1, (B, 1), generator=g).double())).float()
+    xd, wd, dd = x.cuda(), w.cuda(), dpre.cuda()
+    mean, amax, flags, wsum = ops.row_stats(xd, wd)
+    assert torch.equal(mean.cpu(), x.sum(dim=1) / G) or rel_err(mean.cpu().numpy(), x.double().mean(dim=1).numpy()) < 1e-6
+    assert float(amax.max()) == float(x.abs().max())
+    assert bool(flags.max() > 0) == (counts != "integer")
+    assert rel_err(wsum.cpu().numpy(), w.double().sum(dim=1).numpy()) < 1e-6
+    wmax = wd.abs().amax().expand(4).contiguous()
+    # forward: x W^T
+    out = ops.gemm_counts(ops.NT, xd, wd, amax, wmax, flags).double().cpu()
+    ref, mag = x.double() @ w.double().t(), x.double().abs() @ w.double().abs().t()
+    assert float(((out - ref).abs() / mag).max()) < (2e-6 if counts == "large" else 4e-7 * max(1.0, np.sqrt(G) / 16))
+    # ... and what the middle makes of it equals the Linear over x / mean - 1
+    pre = out / mean.double().cpu()[:, None] - wsum.double().cpu()[None, :]
+    xn = x.double() / x.double().mean(dim=1, keepdim=True) - 1.0
+    assert rel_err(pre.numpy(), (xn @ w.double().t()).numpy()) < 2e-6
+    # weight gradient: (dpre / m)^T x - colsum(dpre) 1^T
+    dps = (dd / mean[:, None]).contiguous()
+    dmax = dps.abs().amax().expand(4).contiguous()
+    colsum = dd.double().sum(dim=0).float()
+    gw = ops.gemm_counts(ops.TN, dps, xd, dmax, amax, flags, row_sub=colsum).double().cpu()
+    ref_w = dpre.double().t() @ xn
+    assert rel_err(gw.numpy(), ref_w.numpy()) < 2e-6
+    mag_w = dps.double().cpu().abs().t() @ x.double().abs() + colsum.double().cpu().abs()[:, None]
+    ref_s = dps.double().cpu().t() @ x.double() - colsum.double().cpu()[:, None]
+    # ("large": one term of 40001 dominates its column's sum from its k step on, and every later fp32 accumulation rounds
+    # at that magnitude -- the accumulator's own behaviour, ~sqrt(96 accumulations) x 2^-25; not a property of the operands)
+    assert float(((gw - ref_s).abs() / mag_w).max()) < (2e-6 if counts == "large" else 4e-7 * max(1.0, np.sqrt(B) / 16))
+
+
 @pytest.mark.parametrize("layout", [0, 1, 2])
 @pytest.mark.parametrize("shape", [(132, 260, 4096), (640, 1280, 256), (512, 384, 2048), (260, 136, 4100), (96, 257, 4101)])
 def test_gemm_two_f16_terms(ops, layout, shape):

@@ -50,6 +50,9 @@ SIGNATURES = {
                                      C.POINTER(C.c_int), _ptr]),
     "vae_gemm_rowscaled_ok": (_i32, [_i64, _i64, _i64]),
     "vae_gemm_rowscaled": (_i32, [_i64, _i64, _i64, _ptr, _i64, _ptr, _i64, _i64, _ptr, _i64, _ptr, _i64, _ptr, _i64, _ptr, _i64, _ptr]),
+    "vae_row_stats": (_i32, [_ptr, _i64, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _i64, _i64, _ptr, _ptr]),
+    "vae_gemm_counts": (_i32, [_i32, _i64, _i64, _i64, _ptr, _i64, _ptr, _i64, _ptr, _i64, _ptr, _i64, _ptr, _i64, _ptr, _i64, _ptr, _ptr,
+                               _i64, _ptr]),
     "vae_row_mean": (_i32, [_ptr, _i64, _i64, _i64, _ptr, _ptr]),
     "vae_normalize_rows": (_i32, [_ptr, _i64, _i64, _i64, _ptr, _ptr, _i64, _ptr]),
     "vae_normalize_rows_u8": (_i32, [_ptr, _i64, _i64, _i64, _ptr, _ptr, _i64, _ptr]),

@@ -70,6 +70,15 @@ struct GemmArgs {
   const float* rmax1;
   int rmax_split, rmax_chunks;
   int64_t rmax_stride;
+  // gemm_x3_kernel<..., XONE>: the COUNT operand (XONE = 1: A of an NT product, XONE = 2: B of a TN product) is raw counts;
+  // integer counts below 2048 are exact in ONE scaled f16 term, so its lo plane, that plane's LDS traffic and one of the
+  // three products fall away.  xone_flags: n_xone floats written by the kernel that read the counts (vae_row_mean_ex), any
+  // entry > 0 = some count needs its lo term: the kernel then runs the plain two-term loop (a uniform branch, decided
+  // once).  row_sub (nullable): C[m, n] -= row_sub[m] in the output stage (the -sum_b dpre term of the weight gradient
+  // over x / mean - 1 written as (dpre / mean)^T x - colsum(dpre) 1^T).
+  const float* xone_flags;
+  int n_xone;
+  const float* row_sub;
 };
 
 // ---- global -> register tile loaders (R*8/256 float4 per thread per operand, R = 64 or 128) ----
@@ -654,7 +663,8 @@ typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
 template <int LAYOUT, int BM, int BN, int WAVES_M, int NP, bool CBF, bool PATCHED>
 __device__ __forceinline__ void x3_epilogue(const GemmArgs& g, f32x16 (&acc)[BM / (32 * WAVES_M)][BN / (32 * (4 / WAVES_M))],
                                             void* smem, int m0, int n0, int tn, int s, float scA, float scB,
-                                            const float* row_inv = nullptr) {   // LDS: 1 / (row scale) of the tile's BM rows
+                                            const float* row_inv = nullptr,     // LDS: 1 / (row scale) of the tile's BM rows
+                                            float rs_pref = 0.f) {              // thread tid < BM: row_sub[m0 + tid], loaded at kernel start
   constexpr int WAVES_N = 4 / WAVES_M;
   constexpr int TM = BM / (32 * WAVES_M), TNN = BN / (32 * WAVES_N);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -681,6 +691,13 @@ __device__ __forceinline__ void x3_epilogue(const GemmArgs& g, f32x16 (&acc)[BM 
     bvs[ni] = (g.split == 1 && g.bias && n < g.N) ? g.bias[n] : 0.f;
   }
   if (vec_out) __syncthreads();   // every wave is done with the operand planes
+  // row_sub of this tile's rows, parked behind the waves' patches (vector path; the element path reads it from memory)
+  float* rsub = reinterpret_cast<float*>(smem) + 4 * (32 * 40);
+  const bool sub = NP == 2 && g.row_sub != nullptr && g.split == 1;   // (NP == 2: the LDS behind the patches exists)
+  if (vec_out && sub) {
+    if (tid < BM) rsub[tid] = rs_pref;
+    __syncthreads();
+  }
   // running softmax statistics of this wave's rows over its column span: lane (8 r' + c) holds rows r' + 8 i, i < 4
   constexpr bool STAT_OK = LAYOUT == NT && TM <= 2;         // tile shapes whose epilogue carries the statistics registers
   const bool stats = STAT_OK && g.stat_m != nullptr;        // the host enables it only when every block takes the path below
@@ -748,7 +765,7 @@ __device__ __forceinline__ void x3_epilogue(const GemmArgs& g, f32x16 (&acc)[BM 
         for (int r = 0; r < 16; ++r) {
           const int rl = (r & 3) + 8 * (r >> 2) + 4 * h;
           const float is = row_inv ? inv_sc * row_inv[wm * (32 * TM) + mi * 32 + rl] : inv_sc;
-          patch[rl * 40 + l31] = (NP == 2 ? acc[mi][ni][r] * is : acc[mi][ni][r]) + bv;
+          patch[rl * 40 + l31] = (NP == 2 ? acc[mi][ni][r] * is : acc[mi][ni][r]) + (sub ? bv - rsub[wm * (32 * TM) + mi * 32 + rl] : bv);
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -786,7 +803,7 @@ __device__ __forceinline__ void x3_epilogue(const GemmArgs& g, f32x16 (&acc)[BM 
         if (m < g.M) {
           float* p = out + (int64_t)m * ldc + n;
           const float is = row_inv ? inv_sc * row_inv[m - m0] : inv_sc;
-          float v = (NP == 2 ? acc[mi][ni][r] * is : acc[mi][ni][r]) + bv;
+          float v = (NP == 2 ? acc[mi][ni][r] * is : acc[mi][ni][r]) + (sub ? bv - g.row_sub[m] : bv);
           if (g.split == 1 && g.accumulate) v += *p;
           *p = v;
         }
@@ -833,10 +850,12 @@ __device__ __forceinline__ void x3_epilogue(const GemmArgs& g, f32x16 (&acc)[BM 
 #ifndef VAE_X3_SCHEDB
 #define VAE_X3_SCHEDB 0
 #endif
-template <int LAYOUT, int BM, int BN, int WAVES_M, int NP, int IO = 0, bool ROWSC = false>
-__global__ __launch_bounds__(256, ((VAE_X3_PIPE && NP <= 2 && BM == 128 && BN == 128) || ROWSC ? 2 : (NP <= 2 ? 3 : 2))) void gemm_x3_kernel(GemmArgs g) {
+template <int LAYOUT, int BM, int BN, int WAVES_M, int NP, int IO = 0, bool ROWSC = false, int XONE = 0>
+__global__ __launch_bounds__(256, ((VAE_X3_PIPE && NP <= 2 && BM == 128 && BN == 128) || ROWSC || XONE != 0 ? 2 : (NP <= 2 ? 3 : 2))) void gemm_x3_kernel(GemmArgs g) {
   static_assert(IO == 0 || NP == 1, "bf16 storage goes with the one-plane bf16 product");
   static_assert(!ROWSC || (LAYOUT == TN && NP == 2), "per-row scales: the two-f16-term wgrad");
+  static_assert(XONE == 0 || (NP == 2 && !ROWSC && ((XONE == 1 && LAYOUT == NT) || (XONE == 2 && LAYOUT == TN))),
+                "one-term count operand: A of the two-f16-term NT product or B of the TN product");
   __shared__ __attribute__((aligned(16))) float row_sc[ROWSC ? BM : 4];
   __shared__ float row_inv[ROWSC ? BM : 4];
   constexpr bool PIPE = VAE_X3_PIPE && NP <= 2 && BM == 128 && BN == 128;   // the 160-wide tiles do not fit two waves per SIMD
@@ -886,6 +905,9 @@ __global__ __launch_bounds__(256, ((VAE_X3_PIPE && NP <= 2 && BM == 128 && BN ==
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
   const int l31 = lane & 31, h = lane >> 5;
+  // GemmArgs::row_sub of this tile's rows: requested now, parked in LDS by the output stage (a load there would be a
+  // dependent round trip that every workgroup of the single generation pays at the same time)
+  const float rs_pref = (NP == 2 && g.row_sub && g.split == 1 && tid < BM && m0 + tid < g.M) ? g.row_sub[m0 + tid] : 0.f;
 
   // ---- global -> register staging: unconditional 16-byte (bf16 storage: 8-byte) loads from clamped addresses ----
   // addresses = a workgroup-uniform base (the tile's origin at this K step: scalar registers, advanced per step) + a
@@ -958,6 +980,7 @@ __global__ __launch_bounds__(256, ((VAE_X3_PIPE && NP <= 2 && BM == 128 && BN ==
   };
   auto fetch_tail = [&](int tail) { fetch_tail_to(tail, ra, rb); };
   float scA = 1.f, scB = 1.f;   // NP == 2: operand scales
+  int x_one = 0;                // XONE: every count is exact in one scaled f16 term (workgroup-uniform)
   // Maximum of n partial maxima (16-byte aligned array): 16-byte loads, four in flight per lane
   auto partial_max = [&](const float* __restrict__ p, int n) {
     float m = 0.f;
@@ -1006,24 +1029,29 @@ __global__ __launch_bounds__(256, ((VAE_X3_PIPE && NP <= 2 && BM == 128 && BN ==
     if (g.na > 0 || g.nb > 0) {  // reduce the producers' partial maxima (a few KB, L2-resident)
       // 8 floats: own storage, or (PIPE: two stages of exactly 40 KB = two workgroups per CU, not a byte to spare) the start
       // of LDS stage 1, which nothing writes before the barrier that follows the first conversion
-      __shared__ float red_own[PIPE ? 1 : 8];
+      __shared__ float red_own[PIPE ? 1 : 12];
       float* red_s = PIPE ? reinterpret_cast<float*>(smem + STG) : red_own;
       float ma = partial_max(g.sa, g.na), mb = partial_max(g.sb, g.nb);
+      float mf = XONE != 0 ? partial_max(g.xone_flags, g.n_xone) : 0.f;
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) {
         ma = fmaxf(ma, __shfl_xor(ma, o, 64));
         mb = fmaxf(mb, __shfl_xor(mb, o, 64));
+        if (XONE != 0) mf = fmaxf(mf, __shfl_xor(mf, o, 64));
       }
-      if (lane == 0) { red_s[wave] = ma; red_s[4 + wave] = mb; }
+      if (lane == 0) { red_s[wave] = ma; red_s[4 + wave] = mb; if (XONE != 0) red_s[8 + wave] = mf; }
       __syncthreads();
       scA = vae_scale_from_absmax(fmaxf(fmaxf(red_s[0], red_s[1]), fmaxf(red_s[2], red_s[3])));
       scB = vae_scale_from_absmax(fmaxf(fmaxf(red_s[4], red_s[5]), fmaxf(red_s[6], red_s[7])));
+      if (XONE != 0)
+        x_one = __builtin_amdgcn_readfirstlane(fmaxf(fmaxf(red_s[8], red_s[9]), fmaxf(red_s[10], red_s[11])) > 0.f ? 0 : 1);
     } else {
       if (g.sa) scA = *g.sa;
       if (g.sb) scB = *g.sb;
     }
   };
-  auto put = [&](__bf16* base, int plane, int off, const auto& vin, const float4 sc4) {
+  // with_lo (a std::bool_constant): false = the operand is exact in its hi term (XONE): no lo plane is computed or written
+  auto put = [&](__bf16* base, int plane, int off, const auto& vin, const float4 sc4, auto with_lo) {
     if constexpr (std::is_same_v<std::decay_t<decltype(vin)>, uint2>) {   // bf16 in HBM: already the operand image
       *reinterpret_cast<uint2*>(base + off) = vin;
       return;
@@ -1038,10 +1066,10 @@ __global__ __launch_bounds__(256, ((VAE_X3_PIPE && NP <= 2 && BM == 128 && BN ==
         const float as = f[j] * sc[j];
         const _Float16 h = (_Float16)as;
         h4[j] = h;
-        l4[j] = (_Float16)(as - (float)h);
+        if constexpr (decltype(with_lo)::value) l4[j] = (_Float16)(as - (float)h);
       }
       *reinterpret_cast<bf16x4*>(base + off) = __builtin_bit_cast(bf16x4, h4);
-      *reinterpret_cast<bf16x4*>(base + plane + off) = __builtin_bit_cast(bf16x4, l4);
+      if constexpr (decltype(with_lo)::value) *reinterpret_cast<bf16x4*>(base + plane + off) = __builtin_bit_cast(bf16x4, l4);
       return;
     }
     bf16x4 hi, mi, lo;
@@ -1061,14 +1089,17 @@ __global__ __launch_bounds__(256, ((VAE_X3_PIPE && NP <= 2 && BM == 128 && BN ==
 #ifdef VAE_PROBE
   int pi = 0;
 #endif
-  auto stage = [&]() {
+  // `one` (a std::integral_constant<int, 0 | 1 | 2>): which operand runs on its hi term alone in this instantiation of the
+  // K loop (0: none, 1: A, 2: B) -- see XONE
+  auto stage = [&](auto one) {
+    constexpr int ONE = decltype(one)::value;
     GSTAMP();
     __syncthreads();  // the previous tile's fragment reads are done
     GSTAMP();
 #pragma unroll
-    for (int i = 0; i < NA; ++i) put(sA, PLA, wa[i], ra[i], scale_a4(i));
+    for (int i = 0; i < NA; ++i) put(sA, PLA, wa[i], ra[i], scale_a4(i), std::bool_constant<ONE != 1>{});
 #pragma unroll
-    for (int i = 0; i < NB; ++i) put(sB, PLB, wb[i], rb[i], make_float4(scB, scB, scB, scB));
+    for (int i = 0; i < NB; ++i) put(sB, PLB, wb[i], rb[i], make_float4(scB, scB, scB, scB), std::bool_constant<ONE != 2>{});
     GSTAMP();
     __syncthreads();
     GSTAMP();
@@ -1105,19 +1136,20 @@ __global__ __launch_bounds__(256, ((VAE_X3_PIPE && NP <= 2 && BM == 128 && BN ==
 
   // `between(group)` runs after the MFMAs of each of the 2 * TNN (ks, tj) groups: the pipelined loop converts the next
   // K step there, in the shadow of the matrix cores
-  auto multiply_from = [&](const __bf16* sAst, const __bf16* sBst, auto&& between) {
+  auto multiply_from = [&](auto one, const __bf16* sAst, const __bf16* sBst, auto&& between) {
+    constexpr int ONE = decltype(one)::value;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       bf16x8 a[TM][NP];
 #pragma unroll
       for (int ti = 0; ti < TM; ++ti)
 #pragma unroll
-        for (int q = 0; q < NP; ++q) a[ti][q] = frag(sAst + q * PLA, A_KC, fa, ti, ks);
+        for (int q = 0; q < (ONE == 1 ? 1 : NP); ++q) a[ti][q] = frag(sAst + q * PLA, A_KC, fa, ti, ks);
 #pragma unroll
       for (int tj = 0; tj < TNN; ++tj) {
         bf16x8 b[NP];
 #pragma unroll
-        for (int q = 0; q < NP; ++q) b[q] = frag(sBst + q * PLB, B_KC, fb, tj, ks);
+        for (int q = 0; q < (ONE == 2 ? 1 : NP); ++q) b[q] = frag(sBst + q * PLB, B_KC, fb, tj, ks);
 #pragma unroll
         for (int ti = 0; ti < TM; ++ti) {
           f32x16 c = acc[ti][tj];  // smallest terms first
@@ -1128,8 +1160,8 @@ __global__ __launch_bounds__(256, ((VAE_X3_PIPE && NP <= 2 && BM == 128 && BN ==
           if (NP == 2) {  // f16 hi / lo: lo*hi, hi*lo, hi*hi (the dropped lo*lo is < 2^-22 of the product)
             const f16x8 ah = __builtin_bit_cast(f16x8, a[ti][0]), al = __builtin_bit_cast(f16x8, a[ti][NP > 1 ? 1 : 0]);
             const f16x8 bh = __builtin_bit_cast(f16x8, b[0]), bl = __builtin_bit_cast(f16x8, b[NP > 1 ? 1 : 0]);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, c, 0, 0, 0);
+            if constexpr (ONE != 1) c = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, c, 0, 0, 0);   // (an exact operand has no lo term)
+            if constexpr (ONE != 2) c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, c, 0, 0, 0);
             c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, c, 0, 0, 0);
             acc[ti][tj] = c;
             continue;
@@ -1146,92 +1178,106 @@ __global__ __launch_bounds__(256, ((VAE_X3_PIPE && NP <= 2 && BM == 128 && BN ==
       }
     }
   };
-  auto multiply = [&]() { multiply_from(sA, sB, [](int) {}); };
+  auto multiply = [&](auto one) { multiply_from(one, sA, sB, [](int) {}); };
 
   (void)stage; (void)multiply; (void)fetch; (void)fetch_tail;   // the unpipelined loop's helpers
   GSTAMP();
   const int nfull = kend > kbeg ? (kend - kbeg) / BK : 0;
   const int tail = kend > kbeg ? (kend - kbeg) % BK : 0;   // only the last slab of a K that is not a multiple of 32
+  // The first K step's loads are issued, then the operand scales (and the XONE decision) are derived while they travel;
+  // run(one) is the rest of the K loop, instantiated per `one` and chosen ONCE per workgroup (uniform branch).
+  int left = nfull;                                      // PIPE: full steps not fetched yet
+  auto fetch_full = [&]() {                              // branch-free: past the end the last step is read again (unused)
+    load_to(ra, rb);
+    bA += left > 1 ? step_a : 0;
+    bB += left > 1 ? step_b : 0;
+    --left;
+  };
+  (void)fetch_full;
   if constexpr (PIPE) {
-    // the pipelined loop covers the FULL K steps; a partial last step (K % 32 != 0) runs unpipelined after it
-    int left = nfull;                                    // full steps not fetched yet
-    auto fetch_full = [&]() {                            // branch-free: past the end the last step is read again (unused)
-      load_to(ra, rb);
-      bA += left > 1 ? step_a : 0;
-      bB += left > 1 ? step_b : 0;
-      --left;
-    };
-    // Step i: the loads of step i + 1 are issued first and land during the first half of the MFMA groups; the second
-    // half alternates with their conversion into the other LDS stage (after the last step the registers hold a re-read
-    // of it, written to the stage nobody reads again).
-    #ifndef VAE_X3_G0
+    if (nfull > 0) fetch_full();
+  } else {
+    if (nfull > 0) fetch();
+    else if (tail) fetch_tail(tail);
+  }
+  scales();
+  auto run = [&](auto one) {
+    constexpr int ONE = decltype(one)::value;
+    if constexpr (PIPE) {
+      // the pipelined loop covers the FULL K steps; a partial last step (K % 32 != 0) runs unpipelined after it
+      // Step i: the loads of step i + 1 are issued first and land during the first half of the MFMA groups; the second
+      // half alternates with their conversion into the other LDS stage (after the last step the registers hold a re-read
+      // of it, written to the stage nobody reads again).
+#ifndef VAE_X3_G0
 #define VAE_X3_G0 (NGRP / 2)
 #endif
-    constexpr int NGRP = 2 * TNN, G0 = VAE_X3_G0, NPUT = NA + NB;
-    auto put_one = [&](int pidx, __bf16* base) {
-      if (pidx < NA) put(base, PLA, wa[pidx], ra[pidx], scale_a4(pidx));
-      else put(base + NP * PLA, PLB, wb[pidx - NA], rb[pidx - NA], make_float4(scB, scB, scB, scB));
-    };
-    auto step = [&](int cur) {
-      GSTAMP();
-      fetch_full();
-      __bf16* nxt = smem + (cur ^ 1) * STG;
-      multiply_from(smem + cur * STG, smem + cur * STG + NP * PLA, [&](int grp) {
+      constexpr int NGRP = 2 * TNN, G0 = VAE_X3_G0, NPUT = NA + NB;
+      auto put_one = [&](int pidx, __bf16* base) {
+        if (pidx < NA) put(base, PLA, wa[pidx], ra[pidx], scale_a4(pidx), std::bool_constant<ONE != 1>{});
+        else put(base + NP * PLA, PLB, wb[pidx - NA], rb[pidx - NA], make_float4(scB, scB, scB, scB), std::bool_constant<ONE != 2>{});
+      };
+      auto step = [&](int cur) {
+        GSTAMP();
+        fetch_full();
+        __bf16* nxt = smem + (cur ^ 1) * STG;
+        multiply_from(one, smem + cur * STG, smem + cur * STG + NP * PLA, [&](int grp) {
 #pragma unroll
-        for (int pidx = 0; pidx < NPUT; ++pidx)
-          if (G0 + pidx * (NGRP - G0) / NPUT == grp) put_one(pidx, nxt);
-        if (VAE_X3_SCHEDB) __builtin_amdgcn_sched_barrier(0);   // keep a group's conversions in its own slot
-      });
-      GSTAMP();
-      __syncthreads();   // stage cur ^ 1 published; every wave is done reading stage cur
-      GSTAMP();
-    };
-    if (nfull > 0) {
-      fetch_full();
-      scales();
+          for (int pidx = 0; pidx < NPUT; ++pidx)
+            if (G0 + pidx * (NGRP - G0) / NPUT == grp) put_one(pidx, nxt);
+          if (VAE_X3_SCHEDB) __builtin_amdgcn_sched_barrier(0);   // keep a group's conversions in its own slot
+        });
+        GSTAMP();
+        __syncthreads();   // stage cur ^ 1 published; every wave is done reading stage cur
+        GSTAMP();
+      };
+      if (nfull > 0) {
 #pragma unroll
-      for (int pidx = 0; pidx < NPUT; ++pidx) put_one(pidx, smem);
-      __syncthreads();
-      for (int i = 0; i < nfull; i += 2) {
-        step(0);
-        if (i + 1 < nfull) step(1);
+        for (int pidx = 0; pidx < NPUT; ++pidx) put_one(pidx, smem);
+        __syncthreads();
+        for (int i = 0; i < nfull; i += 2) {
+          step(0);
+          if (i + 1 < nfull) step(1);
+        }
+        if (tail) {   // the base pointers stopped at the last full step: move on to the partial one
+          bA += step_a;
+          bB += step_b;
+        }
       }
-      if (tail) {   // the base pointers stopped at the last full step: move on to the partial one
-        bA += step_a;
-        bB += step_b;
+      if (tail) {
+        fetch_tail(tail);
+        stage(one);
+        multiply(one);
+        __syncthreads();
       }
-    } else scales();
-    if (tail) {
-      fetch_tail(tail);
-      stage();
-      multiply();
-      __syncthreads();
-    }
-  } else {
-  if (nfull > 0) fetch();
-  else if (tail) fetch_tail(tail);
-  scales();
-  for (int i = 0; i < nfull; ++i) {
+    } else {
+      for (int i = 0; i < nfull; ++i) {
 #ifdef VAE_ABL   // ablations for tools/micro/gemm_probe.hip: 1 = stage once, 2 = fetch once, 4 = no multiply
-    if (!(VAE_ABL & 1) || i == 0) stage();
-    if ((!(VAE_ABL & 2) || i == 0) && i + 1 < nfull) fetch();
-    if (!(VAE_ABL & 4)) multiply();
+        if (!(VAE_ABL & 1) || i == 0) stage(one);
+        if ((!(VAE_ABL & 2) || i == 0) && i + 1 < nfull) fetch();
+        if (!(VAE_ABL & 4)) multiply(one);
 #else
-    stage();
-    if (i + 1 < nfull) fetch();  // in flight during the MFMAs below
-    else if (tail) fetch_tail(tail);
-    multiply();
+        stage(one);
+        if (i + 1 < nfull) fetch();  // in flight during the MFMAs below
+        else if (tail) fetch_tail(tail);
+        multiply(one);
 #endif
-  }
-  if (tail) {
-    stage();
-    multiply();
-  }
+      }
+      if (tail) {
+        stage(one);
+        multiply(one);
+      }
+    }
+  };
+  if constexpr (XONE != 0) {
+    if (x_one) run(std::integral_constant<int, XONE>{});
+    else run(std::integral_constant<int, 0>{});
+  } else {
+    run(std::integral_constant<int, 0>{});
   }
   GSTAMP();
 
   x3_epilogue<LAYOUT, BM, BN, WAVES_M, NP, CBF, (NP * (PLA + PLB) * 2 >= 4 * 32 * 40 * 4)>(g, acc, smem, m0, n0, tn, s, scA, scB,
-                                                                                            ROWSC ? row_inv : nullptr);
+                                                                                            ROWSC ? row_inv : nullptr, rs_pref);
   GSTAMP();
 }
 
@@ -1417,7 +1463,7 @@ __global__ __launch_bounds__(256, 2) void gemm16_dma_kernel(GemmArgs g) {
 template <bool VEC>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int split, int M, int N,
                                                             const float* __restrict__ bias, float* __restrict__ C,
-                                                            int64_t ldc, int accumulate) {
+                                                            int64_t ldc, int accumulate, const float* __restrict__ row_sub) {
   const int64_t total = (int64_t)M * N;
   if (VEC) {
     const int64_t total4 = total >> 2;
@@ -1441,6 +1487,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
         const float4 bb = *reinterpret_cast<const float4*>(bias + n);
         v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
       }
+      if (row_sub) {   // GemmArgs::row_sub
+        const float r = row_sub[m];
+        v.x -= r; v.y -= r; v.z -= r; v.w -= r;
+      }
       float4* o = reinterpret_cast<float4*>(C + (int64_t)m * ldc + n);
       if (accumulate) {
         const float4 c0 = *o;
@@ -1454,6 +1504,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
       float v = 0.f;
       for (int s = 0; s < split; ++s) v += ws[(int64_t)s * total + i];
       if (bias) v += bias[n];
+      if (row_sub) v -= row_sub[m];
       float* p = C + (int64_t)m * ldc + n;
       if (accumulate) v += *p;
       *p = v;
@@ -1560,7 +1611,7 @@ int gemm_impl(int layout, int precision, int64_t M, int64_t N, int64_t K, const 
               int64_t ldb, float* C, int64_t ldc, const float* bias, const float* x_mean, int accumulate,
               float* workspace, int64_t workspace_bytes, void* stream, int* slabs_out, const float* scale_a = nullptr,
               const float* scale_b = nullptr, int n_max_a = 0, int n_max_b = 0, VaeGemmRowStats* stats = nullptr,
-              int io = 0, const VaeGemmRowScale* rsc = nullptr) {
+              int io = 0, const VaeGemmRowScale* rsc = nullptr, const VaeGemmCounts* xo = nullptr) {
   VAE_REQUIRE(layout >= 0 && layout <= 2, "vae_gemm: layout must be 0 (NT), 1 (NN) or 2 (TN), got %d", layout);
   VAE_REQUIRE(precision >= 0 && precision <= 3, "vae_gemm: precision must be 0 (fp32), 1 (bf16), 2 (bf16x3) or 3 (f16x2), got %d",
               precision);
@@ -1585,6 +1636,7 @@ int gemm_impl(int layout, int precision, int64_t M, int64_t N, int64_t K, const 
   g.sa = scale_a; g.sb = scale_b; g.na = n_max_a; g.nb = n_max_b;
   g.stat_m = g.stat_s = nullptr; g.stat_cols = 0;
   g.rmax0 = g.rmax1 = nullptr; g.rmax_split = g.rmax_chunks = 0; g.rmax_stride = 0;
+  g.xone_flags = nullptr; g.n_xone = 0; g.row_sub = nullptr;
   if (stats) stats->slots = 0;
   g.lda = lda; g.ldb = ldb; g.ldc = ldc;
   g.M = (int)M; g.N = (int)N; g.K = (int)K;
@@ -1592,7 +1644,7 @@ int gemm_impl(int layout, int precision, int64_t M, int64_t N, int64_t K, const 
   g.vecA = (lda % 4 == 0) && ((io & 1) ? (reinterpret_cast<uintptr_t>(A) & 7u) == 0 : vae_aligned16(A));
   g.vecB = (ldb % 4 == 0) && ((io & 2) ? (reinterpret_cast<uintptr_t>(B) & 7u) == 0 : vae_aligned16(B));
   g.group_m = 0;
-  const Plan plan = make_plan(g.M, g.N, g.K, io == 0 && !rsc);   // (bf16 storage and per-row scales exist on the 128-wide tiles only)
+  const Plan plan = make_plan(g.M, g.N, g.K, io == 0 && !rsc && !xo);   // (bf16 storage and per-row scales exist on the 128-wide tiles only)
   static const int no_dma = getenv("VAE_GEMM_NO_DMA") ? atoi(getenv("VAE_GEMM_NO_DMA")) : 0;  // tuning knob
   const bool norm = x_mean != nullptr;
   const bool a_rc = layout == TN, b_rc = layout != NT;
@@ -1612,6 +1664,11 @@ int gemm_impl(int layout, int precision, int64_t M, int64_t N, int64_t K, const 
   VAE_REQUIRE(!rsc || (f16x2 && layout == TN && dma_ok && n_max_b > 0 && rsc->max0 && rsc->chunks > 0 &&
                        (rsc->split >= M || rsc->max1)),
               "vae_gemm: per-row scales need the two-f16-term wgrad (TN) on the tile pipeline and the maxima of B");
+  VAE_REQUIRE(!xo || (f16x2 && !rsc && layout != NN && dma_ok && n_max_a > 0 && n_max_b > 0 &&
+                      (!xo->flags || (xo->n_flags > 0 && vae_aligned16(xo->flags))) &&
+                      (!xo->row_sub || (layout == TN && !slabs_out && !accumulate))),
+              "vae_gemm: the count-operand form needs a two-f16-term NT / TN product on the tile pipeline with operand maxima");
+  if (xo) { g.xone_flags = xo->flags; g.n_xone = xo->n_flags; g.row_sub = xo->row_sub; }
   if (rsc) {
     g.rmax0 = rsc->max0; g.rmax1 = rsc->max1; g.rmax_split = (int)(rsc->split < M ? rsc->split : M); g.rmax_chunks = rsc->chunks;
     g.rmax_stride = rsc->stride;
@@ -1714,6 +1771,13 @@ int gemm_impl(int layout, int precision, int64_t M, int64_t N, int64_t K, const 
       if (layout == NT) VAE_X3_LAUNCH(NT, 1);
       else if (layout == NN) VAE_X3_LAUNCH(NN, 1);
       else VAE_X3_LAUNCH(TN, 1);
+    } else if (xo && xo->flags && layout == NT) {   // two f16 terms, the count operand A on ONE term when every count is exact in it
+      // (the TN form -- counts = B, static_assert'ed in the kernel -- is not instantiated: measured on the cfg2 weight
+      // gradient it is SLOWER than the plain two-term kernel, 41.8 vs 37.5 us in-step, 38.2 vs 34.9 stand-alone; these
+      // products are bound by the latency of their K steps, not by their MFMA or conversion work.  TN runs below.)
+      if (bm == 128 && bn == 128) hipLaunchKernelGGL((gemm_x3_kernel<NT, 128, 128, 2, 2, 0, false, 1>), grid1, dim3(256), 0, st, g);
+      else if (bn == 160)         hipLaunchKernelGGL((gemm_x3_kernel<NT, 128, 160, 4, 2, 0, false, 1>), grid1, dim3(256), 0, st, g);
+      else                        hipLaunchKernelGGL((gemm_x3_kernel<NT, 160, 128, 1, 2, 0, false, 1>), grid1, dim3(256), 0, st, g);
     } else if (rsc) {   // two f16 terms, one scale per product row (the decoder weight gradient)
       if (bm == 128 && bn == 128) hipLaunchKernelGGL((gemm_x3_kernel<TN, 128, 128, 2, 2, 0, true>), grid1, dim3(256), 0, st, g);
       else if (bn == 160)         hipLaunchKernelGGL((gemm_x3_kernel<TN, 128, 160, 4, 2, 0, true>), grid1, dim3(256), 0, st, g);
@@ -1755,10 +1819,10 @@ int gemm_impl(int layout, int precision, int64_t M, int64_t N, int64_t K, const 
     if (blocks > 2048) blocks = 2048;
     if (vec)
       hipLaunchKernelGGL(splitk_reduce_kernel<true>, dim3(blocks), dim3(256), 0, st, workspace, split, g.M, g.N, bias, C,
-                         ldc, accumulate);
+                         ldc, accumulate, g.row_sub);
     else
       hipLaunchKernelGGL(splitk_reduce_kernel<false>, dim3(blocks), dim3(256), 0, st, workspace, split, g.M, g.N, bias,
-                         C, ldc, accumulate);
+                         C, ldc, accumulate, g.row_sub);
     VAE_CHECK_LAUNCH("vae_gemm(splitk_reduce)");
   }
   return VAE_OK;
@@ -1832,11 +1896,11 @@ int vae_absmax_partials(const float* X, int64_t rows, int64_t cols, int64_t ld, 
 int vae_gemm_f16x2(int layout, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* max_a, int n_max_a,
                    const float* B, int64_t ldb, const float* max_b, int n_max_b, float* C, int64_t ldc, const float* bias,
                    int accumulate, float* workspace, int64_t workspace_bytes, void* stream, int* slabs_out,
-                   VaeGemmRowStats* stats) {
+                   VaeGemmRowStats* stats, const VaeGemmCounts* counts) {
   VAE_REQUIRE(max_a && max_b && n_max_a > 0 && n_max_b > 0, "vae_gemm_f16x2: operand maxima missing");
   return gemm_impl(layout, 3, M, N, K, A, lda, B, ldb, slabs_out ? nullptr : C, slabs_out ? N : ldc, slabs_out ? nullptr : bias,
                    nullptr, slabs_out ? 0 : accumulate, workspace, workspace_bytes, stream, slabs_out, max_a, max_b, n_max_a,
-                   n_max_b, stats);
+                   n_max_b, stats, 0, nullptr, counts);
 }
 // whether fp32 operands with 16-byte aligned rows of this shape run the 128-wide tile pipeline (split / LDS-DMA kernels)
 bool vae_gemm_tile_pipeline_ok(int layout, int64_t M, int64_t N, int64_t K) {
@@ -1940,6 +2004,21 @@ extern "C" int vae_gemm_scaled(int layout, int64_t M, int64_t N, int64_t K, cons
   VAE_REQUIRE(scale_a && scale_b, "vae_gemm_scaled: null scale");
   return gemm_impl(layout, 3, M, N, K, A, lda, B, ldb, C, ldc, bias, nullptr, accumulate, workspace, workspace_bytes, stream,
                    nullptr, scale_a, scale_b);
+}
+
+extern "C" int vae_gemm_counts(int layout, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* max_a,
+                               int64_t n_max_a, const float* B, int64_t ldb, const float* max_b, int64_t n_max_b, float* C, int64_t ldc,
+                               const float* flags, int64_t n_flags, const float* row_sub, float* workspace, int64_t workspace_bytes,
+                               void* stream) {
+  VAE_REQUIRE(layout == NT || layout == TN, "vae_gemm_counts: layout must be VAE_NT (counts = A) or VAE_TN (counts = B)");
+  VAE_REQUIRE((layout == TN || flags) && n_flags >= 0 && n_flags < (1 << 30) && (!flags || n_flags > 0) && n_max_a > 0 && n_max_a < (1 << 30) && n_max_b > 0 && n_max_b < (1 << 30) &&
+                  max_a && max_b, "vae_gemm_counts: maxima / flags missing");
+  VAE_REQUIRE(M > 0 && N > 0 && K > 0 && vae_gemm_tile_pipeline_ok(layout, M, N, K), "vae_gemm_counts: M=%lld N=%lld K=%lld is outside the tile pipeline",
+              (long long)M, (long long)N, (long long)K);
+  VAE_REQUIRE(A && B && C && lda % 4 == 0 && ldb % 4 == 0 && vae_aligned16(A) && vae_aligned16(B), "vae_gemm_counts: operands need 16-byte aligned rows");
+  const VaeGemmCounts xc{flags, (int)n_flags, row_sub};
+  return vae_gemm_f16x2(layout, M, N, K, A, lda, max_a, (int)n_max_a, B, ldb, max_b, (int)n_max_b, C, ldc, nullptr, 0, workspace,
+                        workspace_bytes, stream, nullptr, nullptr, &xc);
 }
 
 extern "C" int vae_gemm_rowscaled_ok(int64_t M, int64_t N, int64_t K) { return vae_gemm_tile_pipeline_ok(TN, M, N, K) ? 1 : 0; }

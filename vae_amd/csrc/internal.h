@@ -28,10 +28,21 @@ struct VaeGemmRowStats {
   int64_t capacity;
   int slots;     // out
 };
+// The COUNT operand of the two encoder products (A of the NT forward, B of the TN weight gradient) handed over as RAW
+// counts instead of x / mean - 1 (the caller applies (x W^T) / mean - sum_g W and (dpre / mean)^T x - colsum(dpre) 1^T,
+// modules.py:264): integer counts below 2048 are exact in ONE scaled f16 term, so that operand's lo plane and one of the
+// three products fall away.  flags: n_flags floats (16-byte aligned) left by the kernel that read the counts
+// (vae_row_mean_ex), any > 0 = some count needs its lo term -> the kernel runs the plain two-term loop instead (decided
+// on the device, once per workgroup); flags == null: always the two-term loop.  row_sub (nullable, TN only): C[m, n] -= row_sub[m].
+struct VaeGemmCounts {
+  const float* flags;
+  int n_flags;
+  const float* row_sub;
+};
 int vae_gemm_f16x2(int layout, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* max_a, int n_max_a,
                    const float* B, int64_t ldb, const float* max_b, int n_max_b, float* C, int64_t ldc, const float* bias,
                    int accumulate, float* workspace, int64_t workspace_bytes, void* stream, int* slabs_out,
-                   VaeGemmRowStats* stats = nullptr);
+                   VaeGemmRowStats* stats = nullptr, const VaeGemmCounts* counts = nullptr);
 // Per-row scales of the two-f16-term wgrad: row m's scale comes from max over c < chunks of
 // (m < split ? max0[c * stride + m] : max1[c * stride + m - split])
 struct VaeGemmRowScale {
@@ -92,6 +103,7 @@ int vae_nbzinb_bwd_chunks(int64_t B, int64_t G);           /* cell chunks = slab
 // xn_bf16 != 0: xn is written as bf16 (ld_xn in elements, % 8 == 0)
 int vae_normalize_rows_ex(const void* x, int x_dtype, int64_t ldx, int64_t B, int64_t G, float* mean, void* xn, int xn_bf16,
                           int64_t ld_xn, float* absmax, void* stream);
+// (vae_row_stats: include/vae_amd.h)
 // vae_gene_dropout that also stores the per-wave maxima of |xn| of the masked, normalised counts
 int vae_gene_dropout_ex(const void* x, int x_dtype, int64_t ldx, int64_t B, int64_t G, float p, float alpha, uint64_t seed,
                         uint32_t step, float* running, int32_t* counts, uint32_t* threshold, float* stats, float* mean,

@@ -135,6 +135,8 @@ __device__ __forceinline__ void ln_stats2(const float (&g)[ME], int W0, int W1, 
 struct MidFwd {
   const float* slabs; int nslab; int64_t slab_stride;   // [nslab][B][H+Hl] partial pre-activations
   const float* enc_b0;
+  // count-operand form (nullable pair): the slabs hold x W^T of the RAW counts; pre = slabs / x_mean[b] - wsum[e] + bias[e]
+  const float* x_mean; const float* wsum;
   const float *gz, *bz, *gl, *bl;                        // LayerNorm affine, z / library encoder
   const float *hz_w, *hz_b, *hl_w, *hl_b;               // heads: (L+1,H),(L+1) and (2,Hl),(2)
   const float *eps_z, *eps_l;
@@ -212,7 +214,7 @@ __global__ __launch_bounds__(T) void mid_fwd_kernel(MidFwd a) {
   for (int i = 0; i < ME; ++i) {
     const int e = t + T * i;
     const bool zh = e < H;
-    eb[i] = e < HE ? a.enc_b0[e] : 0.f;
+    eb[i] = e < HE ? a.enc_b0[e] - (a.wsum ? a.wsum[e] : 0.f) : 0.f;
     gam[i] = e < HE ? (zh ? a.gz[e] : a.gl[e - H]) : 0.f;
     bet[i] = e < HE ? (zh ? a.bz[e] : a.bl[e - H]) : 0.f;
     db[i] = e < Hd ? a.d_b[e] : 0.f;
@@ -244,12 +246,13 @@ __global__ __launch_bounds__(T) void mid_fwd_kernel(MidFwd a) {
 
   // 1. sum the split-K slabs, add the bias: pre-activation of both first layers
   float pre[ME], g[ME];
+  const float inv_m = a.x_mean ? 1.f / a.x_mean[b] : 1.f;
   slab_sum(a.slabs + (int64_t)b * HE, a.nslab, a.slab_stride, HE, pre);
 #pragma unroll
   for (int i = 0; i < ME; ++i) {
     const int e = t + T * i;
     if (e < HE) {
-      pre[i] += eb[i];
+      pre[i] = a.x_mean ? fmaf(pre[i], inv_m, eb[i]) : pre[i] + eb[i];
       a.pre_enc0[(int64_t)b * HE + e] = pre[i];
     }
     g[i] = e < HE ? gelu_f(pre[i]) : 0.f;
@@ -378,6 +381,9 @@ struct MidBwd {
   float *dq_z, *dq_l;                                    // (B, L+1), (B, 2)
   float *dbet_e, *dgam_e, *dpre_e;                       // (B, H+Hl) rows
   VaeDropout drop;
+  // count-operand form (nullable pair): dpre_s = dpre_e / x_mean[b] is the A operand of the weight gradient over the raw
+  // counts; the maxima are then taken of dpre_s
+  const float* x_mean; float* dpre_s;
   float* absmax_dpre;                                    // nullable: B * NWV per-wave maxima of |dpre_e|
   uint16_t* dpre16;                                      // nullable: dpre_e again as bf16 (a bf16-storage step's operand image)
 };
@@ -533,6 +539,7 @@ __global__ __launch_bounds__(T) void mid_bwd_kernel(MidBwd a) {
   }
   block_sums<4>(q4, red);
   float am = 0.f;
+  const float inv_m = a.x_mean ? 1.f / a.x_mean[b] : 1.f;
   q4[0] /= (float)H; q4[1] /= (float)H;
   q4[2] /= (float)Hl; q4[3] /= (float)Hl;
 #pragma unroll
@@ -544,7 +551,12 @@ __global__ __launch_bounds__(T) void mid_bwd_kernel(MidBwd a) {
       const float o = dg * gelu_grad(pv[i]);
       a.dpre_e[(int64_t)b * HE + e] = o;
       if (a.dpre16) a.dpre16[(int64_t)b * HE + e] = __builtin_bit_cast(uint16_t, (__bf16)o);
-      am = fmaxf(am, fabsf(o));
+      if (a.dpre_s) {
+        const float os = o * inv_m;
+        a.dpre_s[(int64_t)b * HE + e] = os;
+        am = fmaxf(am, fabsf(os));
+      } else
+        am = fmaxf(am, fabsf(o));
     }
   }
   if (a.absmax_dpre) vae_wave_absmax_store(a.absmax_dpre + b * NWV + (t >> 6), am);
@@ -656,7 +668,7 @@ __global__ __launch_bounds__(64 * WPB) void mid_fwd_wave_kernel(MidFwd a) {
   for (int i = 0; i < NEE; ++i) {
     const int e = lane + 64 * i;
     const bool zh = e < H;
-    eb[i] = e < HE ? a.enc_b0[e] : 0.f;
+    eb[i] = e < HE ? a.enc_b0[e] - (a.wsum ? a.wsum[e] : 0.f) : 0.f;
     gam[i] = e < HE ? (zh ? a.gz[e] : a.gl[e - H]) : 0.f;
     bet[i] = e < HE ? (zh ? a.bz[e] : a.bl[e - H]) : 0.f;
   }
@@ -678,13 +690,14 @@ __global__ __launch_bounds__(64 * WPB) void mid_fwd_wave_kernel(MidFwd a) {
     const float epsl = a.eps_l[b];
     // 1. pre-activation of both first layers, GELU
     float pre[NEE], g[NEE];
+    const float inv_m = a.x_mean ? 1.f / a.x_mean[b] : 1.f;
     slab_sum_wave<NEE, WPB>(a.slabs + (int64_t)b * HE, a.nslab, a.slab_stride, HE, lane, pre);
     float st[2] = {0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < NEE; ++i) {
       const int e = lane + 64 * i;
       if (e < HE) {
-        pre[i] += eb[i];
+        pre[i] = a.x_mean ? fmaf(pre[i], inv_m, eb[i]) : pre[i] + eb[i];
         a.pre_enc0[(int64_t)b * HE + e] = pre[i];
       }
       g[i] = e < HE ? gelu_f(pre[i]) : 0.f;
@@ -990,6 +1003,7 @@ __global__ __launch_bounds__(64 * WPB) void mid_bwd_wave_kernel(MidBwd a) {
     q4[0] /= (float)H; q4[1] /= (float)H;
     q4[2] /= (float)Hl; q4[3] /= (float)Hl;
     float am = 0.f;
+    const float inv_m = a.x_mean ? 1.f / a.x_mean[b] : 1.f;
 #pragma unroll
     for (int i = 0; i < NEE; ++i) {
       const int e = lane + 64 * i;
@@ -999,7 +1013,12 @@ __global__ __launch_bounds__(64 * WPB) void mid_bwd_wave_kernel(MidBwd a) {
         const float o = dg * gelu_grad(pe[i]);
         a.dpre_e[(int64_t)b * HE + e] = o;
         if (a.dpre16) a.dpre16[(int64_t)b * HE + e] = __builtin_bit_cast(uint16_t, (__bf16)o);
-        am = fmaxf(am, fabsf(o));
+        if (a.dpre_s) {
+          const float os = o * inv_m;
+          a.dpre_s[(int64_t)b * HE + e] = os;
+          am = fmaxf(am, fabsf(os));
+        } else
+          am = fmaxf(am, fabsf(o));
       }
     }
     if (a.absmax_dpre) {
@@ -1370,8 +1389,9 @@ int vae_mid_forward(const vae_step_config& c, const vae_step_tensors* p, const f
                     const float* eps_l, float* pre_enc0, float* h_enc0, float* ln_mz, float* ln_rz, float* ln_ml,
                     float* ln_rl, float* heads_z, float* heads_l, float* qz_v, float* z, float* kl_z, float* ql_v,
                     float* library, float* kl_l, float* dec_pre, float* dec_h, float* ln_md, float* ln_rd, float* absmax_px,
-                    uint16_t* px16, void* stream) {
+                    uint16_t* px16, const float* x_mean, const float* wsum, void* stream) {
   MidFwd a;
+  a.x_mean = x_mean; a.wsum = x_mean ? wsum : nullptr;
   a.absmax_px = absmax_px;
   a.px16 = px16;
   a.slabs = slabs; a.nslab = nslab; a.slab_stride = c.B * (c.H + c.Hl);
@@ -1403,8 +1423,10 @@ int vae_mid_backward(const vae_step_config& c, const vae_step_tensors* p, const 
                      const float* pre_enc0, const float* ln_mz, const float* ln_rz, const float* ln_ml,
                      const float* ln_rl, const float* z, const float* h_enc0, float* dbet_d, float* dgam_d,
                      float* dpre_d, float* dq_z, float* dq_l, float* dbet_e, float* dgam_e, float* dpre_e,
-                     float* absmax_dpre, uint16_t* dpre16, const VaeDeferredColreduce* cr, void* stream) {
+                     float* absmax_dpre, uint16_t* dpre16, const VaeDeferredColreduce* cr, const float* x_mean, float* dpre_s,
+                     void* stream) {
   MidBwd a;
+  a.x_mean = dpre_s ? x_mean : nullptr; a.dpre_s = x_mean ? dpre_s : nullptr;
   a.dpre16 = dpre16;
   a.absmax_dpre = absmax_dpre;
   a.slabs = slabs; a.nslab = nslab; a.slab_stride = c.B * c.Hd;

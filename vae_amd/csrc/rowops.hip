@@ -132,6 +132,92 @@ __global__ __launch_bounds__(256) void normalize_rows_kernel(const XT* __restric
 }
 
 // ---------------------------------------------------------------------------------------
+// The count-operand form of the encoder's first layer (step.hip, VaeGemmCounts): x / mean - 1 is never materialised.
+//   (x / m - 1) W^T = (x W^T) / m - sum_g W[:, g]          dW = dpre^T (x / m - 1) = (dpre / m)^T x - colsum(dpre) 1^T
+// so the two gene-sized products stream the RAW counts -- exact in one scaled f16 term when they are integers below
+// 2048 -- and this launch provides what they need: workgroups [HE, HE + B) read a cell's counts once (whole row in registers)
+// and leave its mean (modules.py:264), the per-wave maxima of |x| (the operand scale) and per-wave flags "some count needs
+// its lo term" (significant bits beyond f16's 11, or a magnitude from 2^15 on, where a scale that keeps the largest count
+// in range could push a count of 1 out of it); workgroups [0, HE) sum one row of the (HE, G) first-layer weight each,
+// in a fixed order (they are the first HE workgroups of the grid).  72 MB read, nothing gene-sized written (normalize_rows: 41 MB read + 41 MB written).
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void row_stats_kernel(const float* __restrict__ x, int64_t ld, int B, int G, int vec,
+                                                        float* __restrict__ mean, float* __restrict__ absmax,
+                                                        float* __restrict__ flags, const float* __restrict__ W, int64_t ldw,
+                                                        int vecw, float* __restrict__ wsum) {
+  constexpr int EPT = 20;
+  __shared__ float red[4];
+  const int tid = threadIdx.x;
+  const int HE = (int)gridDim.x - B;
+  if ((int)blockIdx.x < HE) {   // one weight row (these workgroups come FIRST: a tail of them would be exposed)
+    const int h = blockIdx.x;
+    const float* row = W + (int64_t)h * ldw;
+    float s = 0.f;
+    if (vecw && (G & 3) == 0 && G <= 256 * 4 * EPT) {   // the whole row in flight at once, as a count row below
+      const int n4 = G >> 2;
+      float4 v[EPT];
+#pragma unroll
+      for (int j = 0; j < EPT; ++j) {
+        const int i = tid + 256 * j;
+        v[j] = i < n4 ? load4(row, i) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int j = 0; j < EPT; ++j) s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+    } else {
+      const int n4 = vecw ? (G >> 2) : 0;
+      for (int i0 = tid; i0 < n4; i0 += 4 * 256) {   // four 16-byte loads in flight per lane
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = i0 + 256 * u < n4 ? load4(row, i0 + 256 * u) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) s += (v[u].x + v[u].y) + (v[u].z + v[u].w);
+      }
+      for (int i = (n4 << 2) + tid; i < G; i += 256) s += row[i];
+    }
+    s = block_sum<4>(s, red);
+    if (tid == 0) wsum[h] = s;
+    return;
+  }
+  const int b = blockIdx.x - HE;
+  const float* row = x + (int64_t)b * ld;
+  float s = 0.f, am = 0.f;
+  uint32_t bits = 0u;
+  auto take = [&](float v) { s += v; am = fmaxf(am, fabsf(v)); bits |= __float_as_uint(v); };
+  if (vec && G <= 256 * 4 * EPT) {
+    const int n4 = G >> 2;
+    float4 v[EPT];
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) {
+      const int i = tid + 256 * j;
+      v[j] = i < n4 ? load4(row, i) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) {   // (the same association as normalize_rows_kernel: integer counts sum exactly anyway)
+      s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+      am = fmaxf(fmaxf(am, fmaxf(fabsf(v[j].x), fabsf(v[j].y))), fmaxf(fabsf(v[j].z), fabsf(v[j].w)));
+      bits |= (__float_as_uint(v[j].x) | __float_as_uint(v[j].y)) | (__float_as_uint(v[j].z) | __float_as_uint(v[j].w));
+    }
+  } else {
+    const int n4 = vec ? (G >> 2) : 0;
+    for (int i = tid; i < n4; i += 256) {
+      const float4 v = load4(row, i);
+      take(v.x); take(v.y); take(v.z); take(v.w);
+    }
+    for (int i = (n4 << 2) + tid; i < G; i += 256) take(row[i]);
+  }
+  // per wave: maximum and "needs a lo term"
+  am = wave_max_dpp(am);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) bits |= (uint32_t)__shfl_xor((int)bits, o, 64);
+  if ((tid & 63) == 0) {
+    absmax[b * VAE_NORM_WAVES + (tid >> 6)] = am;
+    flags[b * VAE_NORM_WAVES + (tid >> 6)] = ((bits & 0x1fffu) != 0u || !(am < 32768.f)) ? 1.f : 0.f;
+  }
+  s = block_sum<4>(s, red);
+  if (tid == 0) mean[b] = s / (float)G;
+}
+
+// ---------------------------------------------------------------------------------------
 // GELU(erf) -> LayerNorm(eps 1e-5, affine) forward (FCLayers, modules.py:112-114).
 // `pre` = Linear output incl. bias.  Saves mean / rstd of the GELU output per row.
 // ---------------------------------------------------------------------------------------
@@ -640,6 +726,19 @@ extern "C" int vae_normalize_rows(const float* x, int64_t ldx, int64_t B, int64_
 extern "C" int vae_normalize_rows_u8(const uint8_t* x, int64_t ldx, int64_t B, int64_t G, float* mean, float* xn,
                                      int64_t ld_xn, void* stream) {
   return normalize_rows_impl<uint8_t>(x, ldx, B, G, mean, xn, ld_xn, nullptr, stream);
+}
+
+// mean[b] of the raw fp32 counts, absmax / flags [B * VAE_NORM_WAVES] and wsum[h] = sum_g W[h, g], h < HE (row_stats_kernel)
+extern "C" int vae_row_stats(const float* x, int64_t ldx, int64_t B, int64_t G, float* mean, float* absmax, float* flags, const float* W,
+                  int64_t ldw, int64_t HE, float* wsum, void* stream) {
+  VAE_REQUIRE(x && mean && absmax && flags && W && wsum && B > 0 && G > 0 && HE > 0 && ldx >= G && ldw >= G && B + HE < (1 << 30),
+              "vae_row_stats: bad arguments");
+  const int vec = (G % 4 == 0) && (ldx % 4 == 0) && vae_aligned16(x);
+  const int vecw = (ldw % 4 == 0) && vae_aligned16(W);
+  hipLaunchKernelGGL(row_stats_kernel, dim3((unsigned)(B + HE)), dim3(256), 0, (hipStream_t)stream, x, ldx, (int)B, (int)G, vec, mean,
+                     absmax, flags, W, ldw, vecw, wsum);
+  VAE_CHECK_LAUNCH("vae_row_stats");
+  return VAE_OK;
 }
 
 extern "C" int vae_gelu_ln_fwd(const float* pre, int64_t ld_pre, const float* gamma, const float* beta, int64_t B,

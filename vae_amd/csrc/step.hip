@@ -30,6 +30,7 @@ struct Layout {
   int64_t amax[8]; int amax_n[8];  // partial maxima of the operands of the two-f16-term GEMMs (AM_*): offset, entries
   int64_t stat_m, stat_s, stat_cap;   // per-slot softmax statistics the decoder-head GEMM leaves (internal.h)
   int64_t w_enc16, w_heads16, px16, dpre16;   // bf16 images (bf16_storage): the two gene-sized weight matrices, px, dpre_enc0
+  int64_t wsum, xflags, dpre_s;   // count-operand form of the encoder products (Ctx::xd): sum_g W, per-wave flags, dpre / mean
   int64_t fwd_part;       // per-strip partials of ll[b] / S_b of the streaming likelihood pass
   int64_t bwd_slabs;      // column-sum slabs of the epilogue backward (kept until the last launch of the backward)
   int64_t scratch;        // split-K slabs (shared, used by one launch at a time)
@@ -133,6 +134,7 @@ bool make_layout(const vae_step_config& c, Layout* lo) {
   s = maxi(s, vae_gemm_slabs_workspace_bytes(B, H + Hl, G));  // slabs consumed by the fused middle
   s = maxi(s, vae_gemm_slabs_workspace_bytes(B, Hd, NH));
   s = maxi(s, vae_nbzinb_bwd_workspace_bytes(B, G));
+  lo->wsum = take(H + Hl); lo->xflags = take(B * VAE_NORM_WAVES); lo->dpre_s = take(B * (H + Hl));
   lo->fwd_part = take(vae_nbzinb_fwd_workspace_bytes(B, G) / 4 + 4);
   lo->stat_cap = B * ((G + 31) / 32);            // narrowest slot of the GEMM's row statistics: 32 columns
   lo->stat_m = take(lo->stat_cap); lo->stat_s = take(lo->stat_cap);
@@ -161,6 +163,7 @@ struct Ctx {
   Layout lo;
   void* st;
   const vae_step_tensors* par;   // the parameters (for offsets into their bf16 images)
+  bool xd;                       // count-operand form of the two encoder products (xdirect() below)
   uint16_t* h16(int64_t off) const { return reinterpret_cast<uint16_t*>(ws + off); }
   // the two-f16-term pipeline needs 16-byte rows everywhere; ragged shapes run as VAE_FP32
   bool hb() const { return bf16_storage(c); }   // logits / logit gradients held as bf16
@@ -222,6 +225,16 @@ struct Ctx {
                     lo.scratch_floats * 4, st);
   }
 };
+
+// The two encoder products of a two-f16-term step on the fused-middle path stream the RAW fp32 counts (VaeGemmCounts,
+// internal.h): no x / mean - 1 matrix is written or read, and integer counts run on one f16 term.  A/B knob: VAE_NO_XDIRECT.
+bool xdirect(const vae_step_config& c, const Ctx& k, const void* x, int64_t ldx) {
+  static const bool off = getenv("VAE_NO_XDIRECT") != nullptr;
+  if (off || !k.fx() || !vae_mid_supported(c) || c.input_dropout_rate > 0.f || c.x_dtype != VAE_X_F32) return false;
+  if (ldx % 4 != 0 || !vae_aligned16(x) || ldx >= (1 << 22)) return false;
+  const int64_t HE = c.H + c.Hl;
+  return vae_gemm_tile_pipeline_ok(VAE_NT, c.B, HE, c.G) && vae_gemm_tile_pipeline_ok(VAE_TN, HE, c.G, c.B);
+}
 
 int check_common(const vae_step_config* cfg, const void* a, const void* b, const void* x, int64_t ldx,
                  const float* eps_z, const float* eps_l, float* ws, int64_t ws_bytes, Layout* lo, const char* who) {
@@ -287,7 +300,8 @@ extern "C" int vae_elbo_step_forward(const vae_step_config* cfg, const vae_step_
   Layout lo;
   TRY(check_common(cfg, p, p, xv, ldx, eps_z, eps_l, ws, ws_bytes, &lo, "vae_elbo_step_forward"));
   const vae_step_config& c = *cfg;
-  const Ctx k{c, ws, lo, stream, p};
+  Ctx k{c, ws, lo, stream, p, false};
+  k.xd = xdirect(c, k, xv, ldx);
   const int64_t B = c.B, G = c.G, H = c.H, Hl = c.Hl, L = c.L, Hd = c.Hd, HE = c.H + c.Hl;
   const int64_t NH = c.zinb ? 2 * G : G;
 
@@ -307,7 +321,10 @@ extern "C" int vae_elbo_step_forward(const vae_step_config* cfg, const vae_step_
     TRY(vae_cast_bf16(p->enc_w0, k.h16(lo.w_enc16), HE * k.ldw(), p->heads_w, k.h16(lo.w_heads16), NH * Hd, stream));
   }
   // encoders: x/mean-1 -> Linear(G, H+Hl) -> GELU -> LayerNorm (z and library halves)
-  TRY(vae_normalize_rows_ex(xv, c.x_dtype, ldx, B, G, ws + lo.mean, ws + lo.xn, k.hb(), lo.ld_xn, k.am(AM_XN), stream));
+  if (k.xd)   // raw counts go to the products: the cells' means, maxima and exactness flags, and sum_g W (one launch)
+    TRY(vae_row_stats((const float*)xv, ldx, B, G, ws + lo.mean, k.am(AM_XN), ws + lo.xflags, p->enc_w0, k.ldw(), HE, ws + lo.wsum, stream));
+  else
+    TRY(vae_normalize_rows_ex(xv, c.x_dtype, ldx, B, G, ws + lo.mean, ws + lo.xn, k.hb(), lo.ld_xn, k.am(AM_XN), stream));
   // GeneDropout (training): the z-encoder reads its own masked + normalised counts, the library encoder xn
   const bool gd = c.input_dropout_rate > 0.f;
   if (gd)
@@ -324,13 +341,18 @@ extern "C" int vae_elbo_step_forward(const vae_step_config* cfg, const vae_step_
       TRY(k.enc_fwd(Hl, ws + lo.xn, AM_XN, p->enc_w0 + H * k.ldw(), ws + lo.pre_enc0 + H, HE, nullptr, nullptr));
       slabs = ws + lo.pre_enc0;
       nslab = 1;
+    } else if (k.xd) {   // x W^T of the raw counts; the middle applies 1 / mean and - sum_g W
+      const VaeGemmCounts xc{ws + lo.xflags, (int)(B * VAE_NORM_WAVES), nullptr};
+      TRY(vae_gemm_f16x2(VAE_NT, B, HE, G, (const float*)xv, ldx, k.am(AM_XN), k.an(AM_XN), p->enc_w0, k.ldw(), k.am(AM_WENC),
+                         k.an(AM_WENC), nullptr, HE, nullptr, 0, ws + lo.scratch, lo.scratch_floats * 4, stream, &nslab, nullptr, &xc));
     } else {
       TRY(k.enc_fwd(HE, ws + lo.xn, AM_XN, p->enc_w0, nullptr, HE, nullptr, &nslab));
     }
     TRY(vae_mid_forward(c, p, slabs, nslab, eps_z, eps_l, ws + lo.pre_enc0, ws + lo.h_enc0, ws + lo.ln_mz[0],
                         ws + lo.ln_rz[0], ws + lo.ln_ml, ws + lo.ln_rl, ws + lo.heads_z, ws + lo.heads_l, ws + lo.qz_v,
                         ws + lo.z, ws + lo.kl_z, ws + lo.ql_v, ws + lo.library, ws + lo.kl_l, ws + lo.dec_pre[0],
-                        ws + lo.dec_h[0], ws + lo.ln_md[0], ws + lo.ln_rd[0], k.am(AM_PX), k.hb() ? k.h16(lo.px16) : nullptr, stream));
+                        ws + lo.dec_h[0], ws + lo.ln_md[0], ws + lo.ln_rd[0], k.am(AM_PX), k.hb() ? k.h16(lo.px16) : nullptr,
+                        k.xd ? ws + lo.mean : nullptr, k.xd ? ws + lo.wsum : nullptr, stream));
     px = ws + lo.dec_h[0];
   } else {
     if (gd) {
@@ -448,7 +470,8 @@ extern "C" int vae_elbo_step_backward_events(const vae_step_config* cfg, const v
   Layout lo;
   TRY(check_common(cfg, p, g, xv, ldx, eps_z, eps_l, ws, ws_bytes, &lo, "vae_elbo_step_backward"));
   const vae_step_config& c = *cfg;
-  const Ctx k{c, ws, lo, stream, p};
+  Ctx k{c, ws, lo, stream, p, false};
+  k.xd = xdirect(c, k, xv, ldx);
   const int64_t B = c.B, G = c.G, H = c.H, Hl = c.Hl, L = c.L, Hd = c.Hd, HE = c.H + c.Hl;
   const int64_t NH = c.zinb ? 2 * G : G;
   // d loss / d ll[b] = -coeff/B ; d loss / d kl[b] = coeff*kl_weight/B   (task.py:202,489)
@@ -499,7 +522,8 @@ extern "C" int vae_elbo_step_backward_events(const vae_step_config* cfg, const v
                          ws + lo.qz_v, ws + lo.ql_v, ws + lo.dlibrary, ws + lo.pre_enc0, ws + lo.ln_mz[0], ws + lo.ln_rz[0],
                          ws + lo.ln_ml, ws + lo.ln_rl, ws + lo.z, ws + lo.h_enc0, ws + lo.dbet_d, ws + lo.dgam_d,
                          ws + lo.dpx, ws + lo.dheads_z, ws + lo.dheads_l, ws + lo.dbet_e, ws + lo.dgam_e,
-                         ws + lo.dpre_enc0, k.am(AM_DPRE), k.hb() ? k.h16(lo.dpre16) : nullptr, &cr, stream));
+                         ws + lo.dpre_enc0, k.am(AM_DPRE), k.hb() ? k.h16(lo.dpre16) : nullptr, &cr,
+                         k.xd ? ws + lo.mean : nullptr, k.xd ? ws + lo.dpre_s : nullptr, stream));
   } else {
     // The row kernels of the unfused backward leave their LayerNorm / bias column sums per workgroup in lo.colpart; ONE
     // launch at the end adds them in workgroup order and overwrites the gradients: no float atomics, no clearing, and the
@@ -616,6 +640,10 @@ extern "C" int vae_elbo_step_backward_events(const vae_step_config* cfg, const v
   if (c.input_dropout_rate > 0.f) {  // GeneDropout: each encoder's weight gradient over its own input
     TRY(k.enc_wgrad(H, ws + lo.dpre_enc0, HE, ws + lo.xn_z, AM_XNZ, g->enc_w0));
     TRY(k.enc_wgrad(Hl, ws + lo.dpre_enc0 + H, HE, ws + lo.xn, AM_XN, g->enc_w0 + H * k.ldw()));
+  } else if (k.xd) {   // dW = (dpre / mean)^T x - colsum(dpre) 1^T; colsum(dpre) = the first-layer bias gradient, final by now
+    const VaeGemmCounts xc{nullptr, 0, g->enc_b0};   // (two terms of x: gemm.hip, the one-term TN form measured slower)
+    TRY(vae_gemm_f16x2(VAE_TN, HE, G, B, ws + lo.dpre_s, HE, k.am(AM_DPRE), k.an(AM_DPRE), (const float*)xv, ldx, k.am(AM_XN),
+                       k.an(AM_XN), g->enc_w0, k.ldw(), nullptr, 0, ws + lo.scratch, lo.scratch_floats * 4, stream, nullptr, nullptr, &xc));
   } else {
     TRY(k.enc_wgrad(HE, ws + lo.dpre_enc0, HE, ws + lo.xn, AM_XN, g->enc_w0));
   }

@@ -190,6 +190,53 @@ def gemm_rowscaled(a: torch.Tensor, b: torch.Tensor, col_max: Optional[torch.Ten
     return out
 
 
+def row_stats(x: torch.Tensor, w: torch.Tensor):
+    """-> (mean (B,), absmax (B*4,), flags (B*4,), wsum (HE,)): what the count-operand products need (include/vae_amd.h,
+    vae_row_stats): per-cell mean of the raw counts, per-wave maxima of |x|, per-wave "needs a lo term" flags, and the
+    row sums of the (HE, G) first-layer weight."""
+    lib = _lib.load()
+    _chk2d(x, "x"); _chk2d(w, "w")
+    B, G = x.shape
+    if w.shape[1] != G:
+        raise ValueError(f"vae_amd.ops.row_stats: w must be (HE, {G}), got {tuple(w.shape)}")
+    mean = torch.empty(B, dtype=torch.float32, device=x.device)
+    absmax, flags = torch.empty(B * 4, dtype=torch.float32, device=x.device), torch.empty(B * 4, dtype=torch.float32, device=x.device)
+    wsum = torch.empty(w.shape[0], dtype=torch.float32, device=x.device)
+    _lib.check(lib.vae_row_stats(_p(x), _ld(x), B, G, _p(mean), _p(absmax), _p(flags), _p(w), _ld(w), w.shape[0], _p(wsum), _stream()),
+               "row_stats")
+    return mean, absmax, flags, wsum
+
+
+def gemm_counts(layout: int, a: torch.Tensor, b: torch.Tensor, max_a: torch.Tensor, max_b: torch.Tensor, flags: torch.Tensor, *,
+                row_sub: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``gemm_scaled`` whose count operand (``a`` for NT, ``b`` for TN) runs on ONE f16 term when ``flags`` (from
+    ``row_stats``) are all zero (include/vae_amd.h, vae_gemm_counts); ``max_a`` / ``max_b``: partial maxima of |a| / |b|;
+    ``row_sub`` (TN): out[m, :] -= row_sub[m]."""
+    lib = _lib.load()
+    _chk2d(a, "a"); _chk2d(b, "b")
+    if layout == NT:
+        (M, K), (N, K2) = a.shape, b.shape
+    elif layout == TN:
+        (K, M), (K2, N) = a.shape, b.shape
+    else:
+        raise ValueError("vae_amd.ops.gemm_counts: layout must be NT or TN")
+    if K != K2:
+        raise ValueError(f"vae_amd.ops.gemm_counts: inner dimensions differ ({K} vs {K2})")
+    for t, name in ((max_a, "max_a"), (max_b, "max_b"), (flags, "flags")):
+        if t.dim() != 1 or t.dtype != torch.float32 or not t.is_cuda or not t.is_contiguous():
+            raise ValueError(f"vae_amd.ops.gemm_counts: {name} must be a contiguous 1-D float32 GPU tensor")
+    _chk1d(row_sub, M, "row_sub")
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.float32, device=a.device)
+    _chk2d(out, "out")
+    nbytes = lib.vae_gemm_workspace_bytes(M, N, K)
+    ws = workspace(nbytes, a.device) if nbytes else None
+    rc = lib.vae_gemm_counts(layout, M, N, K, _p(a), _ld(a), _p(max_a), max_a.numel(), _p(b), _ld(b), _p(max_b), max_b.numel(), _p(out),
+                             _ld(out), _p(flags), flags.numel(), _p(row_sub), _p(ws), nbytes, _stream())
+    _lib.check(rc, "gemm_counts")
+    return out
+
+
 IO_A_BF16, IO_B_BF16, IO_C_BF16 = 1, 2, 4
 
 
