@@ -33,7 +33,7 @@ def test_probe_functions():
     assert lib.vae_version() >= 100
     assert lib.vae_arch() == b"gfx950"
     assert lib.vae_device_count() >= 0
-    assert lib.vae_gene_table_rows() == 37
+    assert lib.vae_gene_table_rows() == 69      # 5 per-gene rows + 2 x 32 count-indexed rows
     assert lib.vae_nbzinb_max_genes() >= 30000    # the streaming forward and the step have no limit
 
 

@@ -36,7 +36,13 @@
 namespace {
 
 constexpr float EPS = 1e-8f;
-constexpr int KTAB = 16;                  // counts 0..KTAB-1 are served by the gene table
+// Counts 0..KTAB-1 are served by the gene table.  32, not 16: a count beyond the table sends its WAVE through the closed-form
+// branch (two Stirling lgammas / a digamma), and with 16 that was no rare event -- a lane's slot j covers 64 genes of a
+// wave, and one gene among them whose counts reach 16 (0.9 % of the genes of the SURVEY 8(d) synthetic matrix, a handful
+// of highly expressed genes in real data) took the slot's whole wave there in every cell: 42 % of the (wave, slot, cell)
+// evaluations, ~30 of the forward's 92 instructions per element.  With 32 rows it is 8 %.
+constexpr int KTAB = 32;
+constexpr int KSEG = KTAB / 4;            // the table is built four counts per thread
 constexpr int ROW_TH = 0, ROW_LTE = 1, ROW_ITE = 2, ROW_LG = 3, ROW_PSI = 4, ROW_LGD = 5, ROW_DGD = 5 + KTAB;
 constexpr int TABLE_ROWS = 5 + 2 * KTAB;
 
@@ -65,6 +71,10 @@ __device__ __forceinline__ float lgamma_stirling(float z) {
   return (z - 0.5f) * flog(z) - z + 0.91893853320467274178f +
          iz * (0.083333333333f - iz2 * (0.0027777777778f - iz2 * 0.00079365079365f));
 }
+// the count-dependent term beyond the table, x >= KTAB (integer or not): both arguments are far above 8, plain Stirling
+__device__ __forceinline__ float lgd_large(float x, float th, float lg_th) {
+  return lgamma_stirling(x + th) - lg_th - lgamma_stirling(x + 1.f);
+}
 // lgamma for any z > 0: below 8 shift up by 8 with the recurrence (one extra log)
 __device__ __forceinline__ float lgamma_any(float z) {
   if (z >= 8.f) return lgamma_stirling(z);
@@ -85,6 +95,17 @@ __device__ __forceinline__ float digamma_any(float z) {
   return digamma_asym(z + 6.f) - s;
 }
 
+// count-dependent terms of a count the table does not cover: beyond it (the usual case: plain asymptotics, no recurrence)
+// or fractional inside its range (mixup)
+__device__ __forceinline__ float lgd_beyond(float x, float th, float lg_th) {
+  if (x >= (float)KTAB) return lgd_large(x, th, lg_th);
+  return lgamma_any(x + th) - lg_th - lgamma_any(x + 1.f);
+}
+__device__ __forceinline__ float dgd_beyond(float x, float th, float psi_th) {
+  if (x >= (float)KTAB) return digamma_asym(x + th) - psi_th;
+  return digamma_any(x + th) - psi_th;
+}
+
 // ---- gene table --------------------------------------------------------------------------
 // built with the accurate libm-grade functions: it runs over G genes once per step
 __device__ __forceinline__ float digamma_exact(float z) {
@@ -96,24 +117,43 @@ __device__ __forceinline__ float digamma_exact(float z) {
   const float iz = 1.f / z, iz2 = iz * iz;
   return r + logf(z) - 0.5f * iz - iz2 * (0.083333333333f - iz2 * (0.0083333333333f - iz2 * 0.003968253968f));
 }
-__device__ __forceinline__ void gene_table_entry(const float* __restrict__ px_r, int G, float* __restrict__ T, int g) {
-  if (g >= G) return;
+// unit u < KSEG * G: counts [4 q, 4 q + 4) of gene g, q = u / G (unit 0 of a gene also writes its five base rows).  The two
+// running sums at the unit's first count are formed without walking the counts before it one logarithm at a time:
+// log of the rising-factorial ratio in chunks of four factors per logarithm (theta <= ~1e4: a chunk stays below 1e16;
+// all terms of a gene's sum share a sign, so nothing cancels), the digamma difference as plain reciprocals.  At most
+// 7 + 4 logarithms per thread where one thread per gene would walk 32.
+__device__ __forceinline__ void gene_table_entry(const float* __restrict__ px_r, int G, float* __restrict__ T, int u) {
+  const int q = u / G, g = u - q * G;
+  if (q >= KSEG) return;
   const float th = expf(px_r[g]);
-  T[ROW_TH * G + g] = th;
-  // 1 / (theta + eps) by the SAME hardware instruction the kernels use (frcp), so that expressions built from it on
-  // both sides of a difference agree bit for bit; log(theta + eps) is no longer subtracted from anything (elem_core)
-  T[ROW_LTE * G + g] = logf(th + EPS);
-  T[ROW_ITE * G + g] = frcp(th + EPS);
-  T[ROW_LG * G + g] = lgammaf(th);
-  T[ROW_PSI * G + g] = digamma_exact(th);
+  if (q == 0) {
+    T[ROW_TH * G + g] = th;
+    // 1 / (theta + eps) by the SAME hardware instruction the kernels use (frcp), so that expressions built from it on
+    // both sides of a difference agree bit for bit; log(theta + eps) is no longer subtracted from anything (elem_core)
+    T[ROW_LTE * G + g] = logf(th + EPS);
+    T[ROW_ITE * G + g] = frcp(th + EPS);
+    T[ROW_LG * G + g] = lgammaf(th);
+    T[ROW_PSI * G + g] = digamma_exact(th);
+  }
   float lg = 0.f, dg = 0.f;  // k = 0
-  for (int k = 0; k < KTAB; ++k) {
+  for (int c = 0; c < q; ++c) {
+    float p = 1.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float k = (float)(4 * c + i);
+      p *= (th + k) / (k + 1.f);
+      dg += 1.f / (th + k);
+    }
+    lg += logf(p);
+  }
+  for (int k = 4 * q; k < 4 * q + 4; ++k) {
     T[(ROW_LGD + k) * G + g] = lg;
     T[(ROW_DGD + k) * G + g] = dg;
-    lg += logf((th + (float)k) / (float)(k + 1));  // log of the rising-factorial ratio: no cancellation
+    lg += logf((th + (float)k) / (float)(k + 1));
     dg += 1.f / (th + (float)k);
   }
 }
+__host__ __device__ inline unsigned gene_table_blocks(int64_t G) { return (unsigned)((KSEG * G + 255) / 256); }
 __global__ void gene_table_kernel(const float* __restrict__ px_r, int G, float* __restrict__ T) {
   gene_table_entry(px_r, G, T, blockIdx.x * blockDim.x + threadIdx.x);
 }
@@ -148,6 +188,9 @@ __device__ __forceinline__ int tab_index(float x) {  // 0 for zeros and for coun
 // Count-indexed table entry: base = T + first_row * G + gene (hoisted by the caller), row k < 16: a 24-bit multiply
 // (v_mul_u32_u24, full rate -- the 32-bit v_mul_lo_u32 is a quarter-rate instruction) and an unsigned offset.
 __device__ __forceinline__ float tab_load(const float* __restrict__ base, int k, int G) {
+#ifdef VAE_PROBE_NO_GATHER   // timing probe only (wrong results): what the count-indexed gathers cost
+  return 0.f;
+#endif
   return base[__umul24((unsigned)k, (unsigned)G)];
 }
 
@@ -185,7 +228,7 @@ __device__ __forceinline__ Fwd elem_fwd(float x, float mu, float pi, float th, f
   const bool pos = x > EPS;
   float lgd = lgd_tab;
   if (pos && !(x < (float)KTAB && x == truncf(x)))  // rare: large or fractional count
-    lgd = lgamma_any(x + th) - Tg[ROW_LG * G] - lgamma_any(x + 1.f);
+    lgd = lgd_beyond(x, th, Tg[ROW_LG * G]);
   if (ZINB) {
     const float sp = fsoftplus(-pi);
     const float ptl = fmaf(th, dlt, -pi);
@@ -222,7 +265,7 @@ __device__ __forceinline__ Bwd elem_bwd(float x, float mu, float pi, float th, f
   const float dptl_dth = fmaf(th * ite, k.rru, dlt);
   const bool pos = x > EPS;
   float dgd = dgd_tab;
-  if (pos && !(x < (float)KTAB && x == truncf(x))) dgd = digamma_any(x + th) - Tg[ROW_PSI * G];
+  if (pos && !(x < (float)KTAB && x == truncf(x))) dgd = dgd_beyond(x, th, Tg[ROW_PSI * G]);
   const float a_nz = (x * frcp(mu + EPS) - (x + th) * itm) * mu;
   const float dth_nz = dptl_dth - x * itm + dgd;
   if (ZINB) {
@@ -275,9 +318,9 @@ __device__ __forceinline__ Fwd2 elem_fwd2(f2 x, f2 mu, f2 pi, f2 th, f2 lte, f2 
   const Core2 k = elem_core2(mu, lte, ite);
   const bool px = x.x > EPS, py = x.y > EPS;
   if (px && !(x.x < (float)KTAB && x.x == truncf(x.x)))  // rare: large or fractional count
-    lgd.x = lgamma_any(x.x + th.x) - Tg0[ROW_LG * G] - lgamma_any(x.x + 1.f);
+    lgd.x = lgd_beyond(x.x, th.x, Tg0[ROW_LG * G]);
   if (py && !(x.y < (float)KTAB && x.y == truncf(x.y)))
-    lgd.y = lgamma_any(x.y + th.y) - Tg1[ROW_LG * G] - lgamma_any(x.y + 1.f);
+    lgd.y = lgd_beyond(x.y, th.y, Tg1[ROW_LG * G]);
   const f2 L2E2 = mk2(LOG2E, LOG2E), LN22 = mk2(LN2, LN2);
   if (ZINB) {
     const f2 npi = -pi;
@@ -321,8 +364,8 @@ __device__ __forceinline__ Bwd2 elem_bwd2(f2 x, f2 mu, f2 pi, f2 th, f2 lte, f2 
   const Core2 k = elem_core2(mu, lte, ite);
   const f2 dptl_dth = fma2(th * ite, k.rru, k.dlt);
   const bool px = x.x > EPS, py = x.y > EPS;
-  if (px && !(x.x < (float)KTAB && x.x == truncf(x.x))) dgd.x = digamma_any(x.x + th.x) - Tg0[ROW_PSI * G];
-  if (py && !(x.y < (float)KTAB && x.y == truncf(x.y))) dgd.y = digamma_any(x.y + th.y) - Tg1[ROW_PSI * G];
+  if (px && !(x.x < (float)KTAB && x.x == truncf(x.x))) dgd.x = dgd_beyond(x.x, th.x, Tg0[ROW_PSI * G]);
+  if (py && !(x.y < (float)KTAB && x.y == truncf(x.y))) dgd.y = dgd_beyond(x.y, th.y, Tg1[ROW_PSI * G]);
   const f2 a_nz = (x * rcp2(mu + EPS) - (x + th) * k.itm) * mu;
   const f2 dth_nz = (dptl_dth - x * k.itm) + dgd;
   if (ZINB) {
@@ -896,7 +939,7 @@ extern "C" int64_t vae_gene_table_rows(void) { return TABLE_ROWS; }
 
 extern "C" int vae_gene_table(const float* px_r, int64_t G, float* table, void* stream) {
   VAE_REQUIRE(px_r && table && G > 0, "vae_gene_table: bad arguments");
-  hipLaunchKernelGGL(gene_table_kernel, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, (hipStream_t)stream, px_r,
+  hipLaunchKernelGGL(gene_table_kernel, dim3(gene_table_blocks(G)), dim3(256), 0, (hipStream_t)stream, px_r,
                      (int)G, table);
   VAE_CHECK_LAUNCH("vae_gene_table");
   return VAE_OK;
@@ -908,7 +951,7 @@ int vae_step_prologue(const float* w0, int64_t n0, const float* w1, int64_t n1, 
                       int64_t G, float* table, void* stream) {
   VAE_REQUIRE(w0 && w1 && part0 && part1 && n0 > 0 && n1 > 0 && n0 % 4 == 0 && n1 % 4 == 0 && vae_aligned16(w0) &&
                   vae_aligned16(w1) && px_r && table && G > 0, "vae_step_prologue: bad arguments");
-  hipLaunchKernelGGL(step_prologue_kernel, dim3(VAE_ABSMAX_PARTIALS + (unsigned)((G + 255) / 256)), dim3(256), 0,
+  hipLaunchKernelGGL(step_prologue_kernel, dim3(VAE_ABSMAX_PARTIALS + gene_table_blocks(G)), dim3(256), 0,
                      (hipStream_t)stream, w0, n0, w1, n1, part0, part1, px_r, (int)G, table);
   VAE_CHECK_LAUNCH("vae_step_prologue");
   return VAE_OK;
@@ -1246,7 +1289,7 @@ int vae_softmax_stats_merge(const float* stat_m, const float* stat_s, int slots,
                             const float* px_r, int64_t G, float* table, void* stream) {
   VAE_REQUIRE(stat_m && stat_s && slots > 0 && B > 0 && rowmax && rowsum, "vae_softmax_stats_merge: bad arguments");
   VAE_REQUIRE(!px_r || (table && G > 0), "vae_softmax_stats_merge: the gene table needs px_r, G and the table");
-  const unsigned extra = px_r ? (unsigned)((G + 255) / 256) : 0u;
+  const unsigned extra = px_r ? gene_table_blocks(G) : 0u;
   hipLaunchKernelGGL(softmax_stats_merge_kernel, dim3((unsigned)((B + 3) / 4) + extra), dim3(256), 0, (hipStream_t)stream, stat_m,
                      stat_s, slots, (int)B, rowmax, rowsum, px_r, (int)G, table);
   VAE_CHECK_LAUNCH("vae_softmax_stats_merge");
