@@ -256,7 +256,12 @@ def main():
     ap.add_argument("--precision", default="", choices=["", "fp32", "fp32x3", "bf16"],
                     help="fp32 = fp32-grade products on two scaled f16 terms / three MFMA products (default of cfg1/cfg2); "
                          "fp32x3 = three bf16 terms / six products; bf16 = operands rounded to bf16")
-    ap.add_argument("--grad-payload", default="fp32", choices=["fp32", "bf16"])
+    ap.add_argument("--grad-payload", default="auto", choices=["auto", "fp32", "bf16"],
+                    help="wire format of the gradient all-reduce (N > 1); auto = bf16 where the step's products already round "
+                         "their operands to bf16 (cfg4/cfg5), fp32 for the fp32-grade configurations")
+    ap.add_argument("--enc-slabs", type=int, default=0,
+                    help="release the first-layer encoder weight gradient (the last bucket) in up to this many row slabs "
+                         "(vae_elbo_step_backward_slabs); at N = 1 the reducer is inert and the figure shows what slabbing costs")
     ap.add_argument("--counts", default="f32", choices=["f32", "u8"],
                     help="dtype of the resident count matrix: f32 as the reference's loader delivers it (default, the "
                          "headline), or u8 = the reference's on-disk format expanded inside the kernels (row f2)")
@@ -361,7 +366,10 @@ def main():
         from vae_amd.optim import FusedAdamW
         fopt = FusedAdamW(arena, lr=5e-4, weight_decay=0.1, max_grad_norm=0.5, track_bf16_images=True)
         step.use_weight_images(fopt)
-    reducer = GradAllReducer(arena, payload=args.grad_payload) if world > 1 else None
+    if args.grad_payload == "auto":
+        args.grad_payload = "bf16" if precision == ops.BF16 else "fp32"
+    reducer = (GradAllReducer(arena, payload=args.grad_payload, enc_slabs=args.enc_slabs)
+               if world > 1 or args.enc_slabs > 1 else None)
     head_fn = heads = None
     if cell_decoder is not None:   # CellDecoder + _cell_loss (modules.py:312-324, task.py:419-451) on z
         from vae_amd.step import CellHeads
@@ -464,6 +472,7 @@ def main():
             "config": {"workload": f"{args.config}: {cfg['desc']}", "batch_per_gpu": B, "global_batch": B * world,
                        "genes": G, "likelihood": cfg["likelihood"], "n_layers": cfg["n_layers"],
                        "parallelism": f"dp{world}", "grad_payload": args.grad_payload if world > 1 else None,
+                       "enc_slabs": reducer.enc_slabs if reducer is not None else None,
                        "counts": args.counts, "bf16_activations": bf16_st,
                        "weight_operand_scales": ("scanned by every forward" if fopt is None else
                                                  "maxima kept by the fused optimiser (vae_adamw_step_wmax)" if fopt.weight_maxima is not None

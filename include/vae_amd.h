@@ -452,6 +452,17 @@ int vae_elbo_step_backward_events(const vae_step_config* cfg, const vae_step_ten
                                   float* workspace, int64_t workspace_bytes, void* event_heads_ready,
                                   void* event_small_ready, void* stream);
 
+/* The same with the LAST bucket of a data-parallel caller cut into row slabs: the (H + Hl, G) first-layer encoder weight
+ * gradient is written by the last GEMM of the backward, so its all-reduce cannot hide behind later compute; here that
+ * product runs as n_enc_slabs launches over the rows [enc_row_bounds[i], enc_row_bounds[i + 1]) (i < n_enc_slabs; bounds
+ * from 0 to H + Hl in multiples of 4 -- 128 keeps every slab on the tile pipeline; with input dropout one bound at H), each
+ * a contiguous range of the gradient arena, and enc_slab_events[i] (hipEvent_t, nullable) is recorded behind slab i: slab
+ * i travels while slab i + 1 is computed.  n_enc_slabs = 0: one launch, as vae_elbo_step_backward_events.              */
+int vae_elbo_step_backward_slabs(const vae_step_config* cfg, const vae_step_tensors* params, const vae_step_tensors* grads,
+                                 const void* x, int64_t ldx, const float* eps_z, const float* eps_l, int use_dz_extra,
+                                 float* workspace, int64_t workspace_bytes, void* event_heads_ready, void* event_small_ready,
+                                 const int64_t* enc_row_bounds, void* const* enc_slab_events, int n_enc_slabs, void* stream);
+
 /* ---- cell-property heads ------------------------------------------------------
  * CellDecoder with linear heads (modules.py:297-324; cell_decoder_hidden_layer = False is the shipped setting,
  * config.py:67) and LitVAE._cell_loss (task.py:419-451), forward and backward on the (B, L) latent:

@@ -49,7 +49,7 @@ def _worker(rank, world, port, payload, likelihood, q):
         sentinel = arena.flat_grad[arena.used_end:].clone().fill_(7.0)
         arena.flat_grad[arena.used_end:] = sentinel
         red = GradAllReducer(arena, payload=payload)
-        from vae_amd.parallel import BUCKET_ORDER
+        BUCKET_ORDER = red.bucket_tags()
         spans = sorted(sp for t in BUCKET_ORDER for sp in red.buckets[t] if sp[1] > sp[0])
         covered = sum(hi - lo for lo, hi in spans)      # the buckets tile every gradient the loss reaches, once
         assert all(a[1] <= b[0] for a, b in zip(spans, spans[1:])) and spans[0][0] == 0 and spans[-1][1] == arena.used_end
@@ -86,6 +86,30 @@ def test_gradient_allreduce_matches_full_batch(payload, likelihood):
     for p in procs:
         p.join(timeout=60)
     assert all(r[1] == "ok" for r in res), res
+
+
+def test_encoder_bucket_row_slabs():
+    """the (H + Hl, G) encoder weight gradient -- the last, exposed bucket -- cut into row slabs that the
+    native backward releases one by one.  Slabs are whole 128-row tiles, at least 8 MB each, contiguous, and tile the
+    bucket exactly; small models keep one bucket."""
+    from oracle import vae_oracle as O
+    from vae_amd.arena import ParamArena
+    from vae_amd.parallel import GradAllReducer
+    G = 16384
+    arena = ParamArena(O.init_params(G, 256, 32, 128, 8, 1, seed=1), 1, "zinb", "cpu")
+    one = GradAllReducer(arena)
+    assert one.enc_slabs == 1 and one.buckets["enc_w0"] == [(0, 384 * G)] and one.bucket_tags() == ["dec_heads", "small", "enc_w0"]
+    for want, bounds in ((3, [0, 128, 256, 384]), (2, [0, 256, 384]), (16, [0, 128, 256, 384])):   # 16: 8 MB = 128 rows here
+        red = GradAllReducer(arena, enc_slabs=want)
+        assert red.enc_row_bounds == bounds and red.enc_slabs == len(bounds) - 1
+        tags = [t for t in red.bucket_tags() if t.startswith("enc_w0")]
+        assert tags == [f"enc_w0:{i}" for i in range(len(bounds) - 1)] and "enc_w0" not in red.buckets
+        spans = [red.buckets[t][0] for t in tags]
+        assert spans[0][0] == 0 and spans[-1][1] == one.buckets["enc_w0"][0][1]
+        assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+        assert all((hi - lo) * 4 >= (8 << 20) and lo % (128 * G) == 0 for lo, hi in spans)
+    small = ParamArena(O.init_params(512, 64, 32, 32, 8, 1, seed=1), 1, "zinb", "cpu")
+    assert GradAllReducer(small, enc_slabs=4).enc_slabs == 1
 
 
 def _seed_worker(rank, world, port, q):

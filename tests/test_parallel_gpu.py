@@ -17,10 +17,11 @@ class _SnapshotReducer:
     """Stands in for GradAllReducer: 'reducing' a bucket = copying it, on a side stream, behind the event."""
     world, on_gpu = 2, True
 
-    def __init__(self, arena):
+    def __init__(self, arena, enc_slabs=0):
         from vae_amd.parallel import GradAllReducer
         self.arena = arena
-        self.buckets = GradAllReducer(arena).buckets
+        real = GradAllReducer(arena, enc_slabs=enc_slabs)
+        self.buckets, self.enc_slabs, self.enc_row_bounds = real.buckets, real.enc_slabs, real.enc_row_bounds
         self.stream = torch.cuda.Stream()
         self.snap, self.had_event = {}, {}
 
@@ -35,8 +36,11 @@ class _SnapshotReducer:
             self.snap[tag] = [self.arena.flat_grad[lo:hi].clone() for lo, hi in self.buckets[tag]]
 
 
+@pytest.mark.parametrize("enc_slabs,precision", [(0, 3), (3, 3), (3, 0), (3, 1)], ids=["one_bucket", "slabs_f16x2", "slabs_bf16x3", "slabs_bf16"])
 @pytest.mark.parametrize("n_layers", [1, 2])
-def test_native_events_release_buckets_only_when_final(n_layers):
+def test_native_events_release_buckets_only_when_final(n_layers, enc_slabs, precision):
+    """enc_slabs = 3: the encoder weight gradient produced and released in three 128-row slabs
+    (vae_elbo_step_backward_slabs), in every precision mode; its values must not depend on the slabbing beyond summation order."""
     from oracle import vae_oracle as O
     from vae_amd.arena import ParamArena
     from vae_amd.step import ElboStep
@@ -46,14 +50,19 @@ def test_native_events_release_buckets_only_when_final(n_layers):
     g = torch.Generator().manual_seed(4)
     ez, el = torch.randn(B, L, generator=g).cuda(), torch.randn(B, 1, generator=g).cuda()
     arena = ParamArena(p, n_layers, "zinb", "cuda")
-    step = ElboStep(arena, l_mean=7.0, l_var=1.0)
-    red = _SnapshotReducer(arena)
+    step = ElboStep(arena, l_mean=7.0, l_var=1.0, precision=precision)
+    red = _SnapshotReducer(arena, enc_slabs)
+    step.run(x, ez, el)
+    whole = arena.flat_grad.clone()                  # one launch over all rows
     for it in range(3):
         arena.flat_grad.fill_(float("nan"))      # a bucket released too early would be snapshotted with NaNs in it
         torch.cuda.synchronize()
         step.run(x, ez, el, reducer=red)
         torch.cuda.synchronize()
-        assert red.had_event == {"dec_heads": True, "small": True, "enc_w0": False}
+        if enc_slabs:
+            assert red.had_event == {"dec_heads": True, "small": True, "enc_w0:0": True, "enc_w0:1": True, "enc_w0:2": True}
+        else:
+            assert red.had_event == {"dec_heads": True, "small": True, "enc_w0": False}
         real = torch.zeros(arena.total, dtype=torch.bool, device="cuda")     # gradient elements (not alignment padding)
         for k, (off, shape) in arena.offsets.items():
             if k not in arena.no_grad:
@@ -65,7 +74,10 @@ def test_native_events_release_buckets_only_when_final(n_layers):
                 assert torch.isfinite(snap[m]).all(), (it, tag)
                 assert torch.equal(snap[m], arena.flat_grad[lo:hi][m]), (it, tag)
                 seen += int(m.sum())
-        assert seen == int(real.sum())                                      # the three buckets cover every gradient
+        assert seen == int(real.sum())                                      # the buckets cover every gradient
+        # ... and slabbing changes only the summation order (a 128-row launch may pick another split of the cell axis)
+        diff = (arena.flat_grad[real] - whole[real]).abs().max() / whole[real].abs().max()
+        assert float(diff) == 0.0 if not enc_slabs else float(diff) < 1e-5
 
 
 def _nccl_worker(rank, world, port, payload, q):

@@ -89,6 +89,7 @@ SIGNATURES = {
     "vae_elbo_step_forward": (_i32, [_ptr, _ptr, _ptr, _i64, _ptr, _ptr, _ptr, _i64, _ptr]),
     "vae_elbo_step_backward": (_i32, [_ptr, _ptr, _ptr, _ptr, _i64, _ptr, _ptr, _i32, _ptr, _i64, _ptr, _ptr]),
     "vae_elbo_step_backward_events": (_i32, [_ptr, _ptr, _ptr, _ptr, _i64, _ptr, _ptr, _i32, _ptr, _i64, _ptr, _ptr, _ptr]),
+    "vae_elbo_step_backward_slabs": (_i32, [_ptr, _ptr, _ptr, _ptr, _i64, _ptr, _ptr, _i32, _ptr, _i64, _ptr, _ptr, _ptr, _ptr, _i32, _ptr]),
     "vae_adamw_workspace_bytes": (_i64, []),
     "vae_adamw_step": (_i32, [_ptr, _ptr, _ptr, _ptr, _i64, _ptr, _i32, C.c_double, C.c_double, C.c_double, C.c_double,
                               _i64, C.c_double, C.c_double, _ptr, _i64, _ptr, _ptr]),

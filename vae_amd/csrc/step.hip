@@ -467,6 +467,15 @@ extern "C" int vae_elbo_step_backward_events(const vae_step_config* cfg, const v
                                              const void* xv, int64_t ldx, const float* eps_z, const float* eps_l,
                                              int use_dz_extra, float* ws, int64_t ws_bytes, void* event_heads_ready,
                                              void* event_small_ready, void* stream) {
+  return vae_elbo_step_backward_slabs(cfg, p, g, xv, ldx, eps_z, eps_l, use_dz_extra, ws, ws_bytes, event_heads_ready,
+                                      event_small_ready, nullptr, nullptr, 0, stream);
+}
+
+extern "C" int vae_elbo_step_backward_slabs(const vae_step_config* cfg, const vae_step_tensors* p, const vae_step_tensors* g,
+                                            const void* xv, int64_t ldx, const float* eps_z, const float* eps_l,
+                                            int use_dz_extra, float* ws, int64_t ws_bytes, void* event_heads_ready,
+                                            void* event_small_ready, const int64_t* enc_row_bounds, void* const* enc_slab_events,
+                                            int n_enc_slabs, void* stream) {
   Layout lo;
   TRY(check_common(cfg, p, g, xv, ldx, eps_z, eps_l, ws, ws_bytes, &lo, "vae_elbo_step_backward"));
   const vae_step_config& c = *cfg;
@@ -637,15 +646,45 @@ extern "C" int vae_elbo_step_backward_events(const vae_step_config* cfg, const v
                  // it would delay -- the whole enc_w0 slice travels last anyway)
     TRY(k.gemm(VAE_TN, HE, c.n_cov, B, ws + lo.dpre_enc0, HE, c.batch_cov, c.ld_cov, g->enc_w0 + G, k.ldw(), nullptr, nullptr, 0));
   // (dpre16, the bf16 image of dpre: left by the fused middle or by the first layer's LayerNorm backward launches)
-  if (c.input_dropout_rate > 0.f) {  // GeneDropout: each encoder's weight gradient over its own input
-    TRY(k.enc_wgrad(H, ws + lo.dpre_enc0, HE, ws + lo.xn_z, AM_XNZ, g->enc_w0));
-    TRY(k.enc_wgrad(Hl, ws + lo.dpre_enc0 + H, HE, ws + lo.xn, AM_XN, g->enc_w0 + H * k.ldw()));
-  } else if (k.xd) {   // dW = (dpre / mean)^T x - colsum(dpre) 1^T; colsum(dpre) = the first-layer bias gradient, final by now
-    const VaeGemmCounts xc{nullptr, 0, g->enc_b0};   // (two terms of x: gemm.hip, the one-term TN form measured slower)
-    TRY(vae_gemm_f16x2(VAE_TN, HE, G, B, ws + lo.dpre_s, HE, k.am(AM_DPRE), k.an(AM_DPRE), (const float*)xv, ldx, k.am(AM_XN),
-                       k.an(AM_XN), g->enc_w0, k.ldw(), nullptr, 0, ws + lo.scratch, lo.scratch_floats * 4, stream, nullptr, nullptr, &xc));
-  } else {
-    TRY(k.enc_wgrad(HE, ws + lo.dpre_enc0, HE, ws + lo.xn, AM_XN, g->enc_w0));
+  // The (H + Hl, G) weight gradient is the last and, for a data-parallel caller, the only exposed all-reduce bucket: with
+  // n_enc_slabs > 1 it is produced in row slabs [enc_row_bounds[i], enc_row_bounds[i + 1]) -- contiguous ranges of the
+  // gradient arena -- by one launch each, and enc_slab_events[i] is recorded behind slab i, so that slab i travels while
+  // slab i + 1 is computed.  (One launch per slab fills the chip less well than one launch over all rows: a caller without
+  // a reducer passes n_enc_slabs = 0.)
+  int nsl = c.input_dropout_rate > 0.f ? 2 : 1;   // GeneDropout: one product per encoder, each over its own input
+  const int64_t one[3] = {0, c.input_dropout_rate > 0.f ? H : HE, HE};
+  const int64_t* rb = one;
+  if (enc_row_bounds && n_enc_slabs > 0) {
+    if (n_enc_slabs > 64 || enc_row_bounds[0] != 0 || enc_row_bounds[n_enc_slabs] != HE)
+      return vae_set_error(VAE_ERR_ARG, "vae_elbo_step_backward: enc_row_bounds must run from 0 to H + Hl in at most 64 slabs");
+    for (int i = 0; i < n_enc_slabs; ++i)
+      if (enc_row_bounds[i + 1] <= enc_row_bounds[i] || enc_row_bounds[i] % 4 != 0)
+        return vae_set_error(VAE_ERR_ARG, "vae_elbo_step_backward: enc_row_bounds must increase in multiples of 4");
+    if (c.input_dropout_rate > 0.f) {   // GeneDropout: one product per encoder -- a slab must not straddle the two
+      bool at_h = false;
+      for (int i = 0; i <= n_enc_slabs; ++i) at_h = at_h || enc_row_bounds[i] == H;
+      if (!at_h) return vae_set_error(VAE_ERR_ARG, "vae_elbo_step_backward: with input dropout a slab boundary must sit at row H");
+    }
+    nsl = n_enc_slabs;
+    rb = enc_row_bounds;
+  }
+  for (int i = 0; i < nsl; ++i) {
+    const int64_t r0 = rb[i], rows = rb[i + 1] - rb[i];
+    const float* dpre_i = ws + lo.dpre_enc0 + r0;
+    float* dw_i = g->enc_w0 + r0 * k.ldw();
+    if (c.input_dropout_rate > 0.f) {  // GeneDropout: each encoder's weight gradient over its own input
+      TRY(k.enc_wgrad(rows, dpre_i, HE, r0 < H ? ws + lo.xn_z : ws + lo.xn, r0 < H ? AM_XNZ : AM_XN, dw_i));
+    } else if (k.xd) {   // dW = (dpre / mean)^T x - colsum(dpre) 1^T; colsum(dpre) = the first-layer bias gradient, final by now
+      const VaeGemmCounts xc{nullptr, 0, g->enc_b0 + r0};   // (two terms of x: gemm.hip, the one-term TN form measured slower)
+      TRY(vae_gemm_f16x2(VAE_TN, rows, G, B, ws + lo.dpre_s + r0, HE, k.am(AM_DPRE), k.an(AM_DPRE), (const float*)xv, ldx, k.am(AM_XN),
+                         k.an(AM_XN), dw_i, k.ldw(), nullptr, 0, ws + lo.scratch, lo.scratch_floats * 4, stream, nullptr, nullptr, &xc));
+    } else {
+      TRY(k.enc_wgrad(rows, dpre_i, HE, ws + lo.xn, AM_XN, dw_i));
+    }
+    if (enc_slab_events && rb != one && enc_slab_events[i]) {
+      if (hipEventRecord((hipEvent_t)enc_slab_events[i], (hipStream_t)stream) != hipSuccess)
+        return vae_set_error(VAE_ERR_LAUNCH, "vae_elbo_step_backward: hipEventRecord failed");
+    }
   }
   return VAE_OK;
 }

@@ -41,9 +41,14 @@ BUCKET_ORDER = ("dec_heads", "small", "enc_w0")
 
 class GradAllReducer:
     def __init__(self, arena: ParamArena, group: Optional["dist.ProcessGroup"] = None, payload: str = "fp32",
-                 force_collectives: bool = False):
+                 force_collectives: bool = False, enc_slabs: int = 0):
         """``force_collectives``: run every collective although the group has ONE rank (they are identities then) --
-        lets a one-GPU box execute the whole RCCL path (events, side stream, in-place AVG on arena slices)."""
+        lets a one-GPU box execute the whole RCCL path (events, side stream, in-place AVG on arena slices).
+
+        ``enc_slabs``: cut the last bucket -- the (H + Hl, G) first-layer encoder weight gradient, written by the last GEMM
+        of the backward -- into up to this many ROW slabs (contiguous arena ranges, whole 128-row tiles, at least 8 MB
+        each); the native backward then produces and releases them one by one (``vae_elbo_step_backward_slabs``), so that
+        slab i travels while slab i + 1 is computed.  0 / 1: one bucket, one launch."""
         if payload not in ("fp32", "bf16"):
             raise ValueError("payload must be 'fp32' or 'bf16'")
         self.arena = arena
@@ -69,6 +74,21 @@ class GradAllReducer:
             raise RuntimeError("GradAllReducer: unexpected arena layout (encoder weights must come first)")
         self.buckets: Dict[str, List[Tuple[int, int]]] = {
             "dec_heads": [(lo, hi)], "small": [(after, arena.used_end)], "enc_w0": [(0, lo)]}
+        # row slabs of the encoder bucket: boundaries in rows of the stacked (H + Hl, ld_enc_w) matrix
+        ld = int(getattr(arena, "ld_enc_w", 0)) or arena.p(_enc("z_encoder", 0, "w")).shape[1]
+        rows = lo // ld if lo % ld == 0 else 0
+        self.enc_row_bounds: List[int] = [0, rows]
+        if enc_slabs > 1 and rows >= 256:
+            per = max(128, -(-(8 << 20) // (ld * 4) // 128) * 128, -(-rows // enc_slabs // 128) * 128)   # rows per slab
+            b = list(range(0, rows, per)) + [rows]
+            if len(b) > 2 and b[-1] - b[-2] < 128:      # a short tail joins its neighbour
+                del b[-2]
+            self.enc_row_bounds = b
+            if len(b) > 2:
+                del self.buckets["enc_w0"]
+                for i in range(len(b) - 1):
+                    self.buckets[f"enc_w0:{i}"] = [(b[i] * ld, b[i + 1] * ld)]
+        self.enc_slabs = len(self.enc_row_bounds) - 1
         # wire / staging buffers are allocated once (no allocation in the step loop)
         self._wire: Dict[Tuple[int, int], torch.Tensor] = {}
         self._host: Dict[Tuple[int, int], torch.Tensor] = {}
@@ -82,6 +102,10 @@ class GradAllReducer:
                     self._wire[span] = torch.empty(n, dtype=torch.bfloat16, device=arena.device)
                 if self.host_staged:
                     self._host[span] = torch.empty(n, dtype=wire_dtype).pin_memory()
+
+    def bucket_tags(self) -> List[str]:
+        """Bucket names in the order the backward finishes them (the encoder bucket possibly as row slabs)."""
+        return [t for t in ("dec_heads", "small") if t in self.buckets] + [t for t in self.buckets if t.startswith("enc_w0")]
 
     # -- called by the step right after the kernels writing a bucket were enqueued -----------
     def bucket_ready(self, tag: str, after_event=None) -> None:

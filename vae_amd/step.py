@@ -211,6 +211,7 @@ class ElboStep:
         self._plans: Dict[int, tuple] = {}
         self.max_plans = 4          # distinct (batch size, training) workspaces kept alive (train, validation, two tails)
         self._ev_heads = self._ev_small = None
+        self._ev_slabs = None
         self._zero = None
         self._last_fwd = None
 
@@ -411,15 +412,33 @@ class ElboStep:
                 self._ev_heads.record()   # materialises the hipEvent_t handles (torch creates them lazily)
                 self._ev_small.record()
             ev_heads, ev_small = self._ev_heads, self._ev_small
-        rc = self.lib.vae_elbo_step_backward_events(
-            C.byref(cfg), C.byref(self.params), C.byref(self.grads), x.data_ptr(), ldx, eps_z.data_ptr(), eps_l.data_ptr(),
-            use_extra, ws.data_ptr(), nbytes, C.c_void_p(ev_heads.cuda_event) if ev_heads is not None else None,
-            C.c_void_p(ev_small.cuda_event) if ev_small is not None else None, stream)
+        n_slabs = int(getattr(reducer, "enc_slabs", 1)) if ev_heads is not None else 1
+        if n_slabs > 1:   # the encoder weight gradient in row slabs, each released by its own event (parallel.py)
+            if self._ev_slabs is None or len(self._ev_slabs) != n_slabs:
+                self._ev_slabs = [torch.cuda.Event() for _ in range(n_slabs)]
+                for e in self._ev_slabs:
+                    e.record()
+            bounds = (C.c_int64 * (n_slabs + 1))(*reducer.enc_row_bounds)
+            evs = (C.c_void_p * n_slabs)(*[e.cuda_event for e in self._ev_slabs])
+            rc = self.lib.vae_elbo_step_backward_slabs(
+                C.byref(cfg), C.byref(self.params), C.byref(self.grads), x.data_ptr(), ldx, eps_z.data_ptr(), eps_l.data_ptr(),
+                use_extra, ws.data_ptr(), nbytes, C.c_void_p(ev_heads.cuda_event), C.c_void_p(ev_small.cuda_event), bounds, evs,
+                n_slabs, stream)
+        else:
+            rc = self.lib.vae_elbo_step_backward_events(
+                C.byref(cfg), C.byref(self.params), C.byref(self.grads), x.data_ptr(), ldx, eps_z.data_ptr(), eps_l.data_ptr(),
+                use_extra, ws.data_ptr(), nbytes, C.c_void_p(ev_heads.cuda_event) if ev_heads is not None else None,
+                C.c_void_p(ev_small.cuda_event) if ev_small is not None else None, stream)
         _lib.check(rc, "elbo_step_backward")
         if reducer is not None:
             reducer.bucket_ready("dec_heads", after_event=ev_heads)
             reducer.bucket_ready("small", after_event=ev_small)
-            reducer.bucket_ready("enc_w0")
+            if n_slabs > 1:
+                for i, e in enumerate(self._ev_slabs):
+                    reducer.bucket_ready(f"enc_w0:{i}", after_event=e)
+            else:
+                for tag in [t for t in reducer.buckets if t.startswith("enc_w0")]:   # (slabs without native events: all at the end)
+                    reducer.bucket_ready(tag)
         return out
 
     # ------------------------------------------------------------------------------------

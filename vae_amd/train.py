@@ -70,7 +70,9 @@ def main(train_idx: List[int], test_idx: List[int], cell_class: str, additional_
         task.dropout_seed += 0x9E3779B97F4A7C15 * dist.get_rank() % (2 ** 63)   # every rank its own masks
     arena = task.attach_arena(device)
     broadcast_parameters(arena)
-    reducer = GradAllReducer(arena) if dist.is_initialized() and dist.get_world_size() > 1 else None
+    reducer = (GradAllReducer(arena, payload="bf16" if precision == ops.BF16 else "fp32",
+                              enc_slabs=int(rcfg.get("enc_grad_slabs", 0)))
+               if dist.is_initialized() and dist.get_world_size() > 1 else None)
     # optimiser: clip 0.5 + AdamW + warm-up / inverse-sqrt schedule, one fused call per step (optim.py);
     # fused_optimizer=False keeps torch.optim.AdamW + clip_grad_norm_ exactly as configure_optimizers builds them
     fused_opt = None
@@ -135,7 +137,9 @@ def _main_datamodule(dm, model_cfg, task_cfg, trainer_cfg, max_steps, log_every,
     sampler_gen = torch.Generator().manual_seed(rank_seed(43))   # ... and its own RandomSampler permutations
     arena = task.attach_arena(ds.device)
     broadcast_parameters(arena)
-    reducer = GradAllReducer(arena) if dist.is_initialized() and dist.get_world_size() > 1 else None
+    reducer = (GradAllReducer(arena, payload="bf16" if precision == ops.BF16 else "fp32",
+                              enc_slabs=int(rcfg.get("enc_grad_slabs", 0)))
+               if dist.is_initialized() and dist.get_world_size() > 1 else None)
     if fused_optimizer:
         warm = float(tcfg["warmup_steps"])
         opt = FusedAdamW(arena, lr=tcfg["learning_rate"], weight_decay=tcfg["weight_decay"],
