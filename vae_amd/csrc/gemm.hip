@@ -851,7 +851,7 @@ __device__ __forceinline__ void x3_epilogue(const GemmArgs& g, f32x16 (&acc)[BM 
 #define VAE_X3_SCHEDB 0
 #endif
 template <int LAYOUT, int BM, int BN, int WAVES_M, int NP, int IO = 0, bool ROWSC = false, int XONE = 0>
-__global__ __launch_bounds__(256, ((VAE_X3_PIPE && NP <= 2 && BM == 128 && BN == 128) || ROWSC || XONE != 0 ? 2 : (NP <= 2 ? 3 : 2))) void gemm_x3_kernel(GemmArgs g) {
+__global__ __launch_bounds__(256, ((VAE_X3_PIPE && NP <= 2 && BM == 128 && BN == 128) || ROWSC || XONE != 0 || BN > 160 ? 2 : (NP <= 2 ? 3 : 2))) void gemm_x3_kernel(GemmArgs g) {
   static_assert(IO == 0 || NP == 1, "bf16 storage goes with the one-plane bf16 product");
   static_assert(!ROWSC || (LAYOUT == TN && NP == 2), "per-row scales: the two-f16-term wgrad");
   static_assert(XONE == 0 || (NP == 2 && !ROWSC && ((XONE == 1 && LAYOUT == NT) || (XONE == 2 && LAYOUT == TN))),
@@ -1545,9 +1545,10 @@ Plan make_plan(int M, int N, int K, bool short_k_rule = true) {
 // Plan of the LDS-DMA pipeline: tile shape and K split that minimise a makespan model -- two
 // workgroups per CU (512 slots) run in generations; a split pays for writing and summing its slabs.
 struct DmaPlan { int bm, bn, split; };
-DmaPlan make_dma_plan(int M, int N, int K) {
-  static const int force = getenv("VAE_GEMM_DMA_TILE") ? atoi(getenv("VAE_GEMM_DMA_TILE")) : 0;  // 0 | 128 | 160
+DmaPlan make_dma_plan(int M, int N, int K, bool wide = false) {
+  static const int force = getenv("VAE_GEMM_DMA_TILE") ? atoi(getenv("VAE_GEMM_DMA_TILE")) : 0;  // 0 | 128 | 160 | 320
   const int shapes[3][2] = {{128, 128}, {128, 160}, {160, 128}};
+  if (wide && force == 320 && N >= 320 && M >= 128) return {128, 320, 1};
   const int ktiles = (K + BK - 1) / BK;
   DmaPlan best = {128, 128, 1};
   double best_us = 1e30;
@@ -1657,7 +1658,7 @@ int gemm_impl(int layout, int precision, int64_t M, int64_t N, int64_t K, const 
                       (!a_rc || M % 4 == 0) && (!b_rc || N % 4 == 0) && M >= 4 && N >= 4;
   int bm = plan.tile, bn = plan.tile, split = plan.split;
   if (dma_ok) {
-    const DmaPlan d = make_dma_plan(g.M, g.N, g.K);
+    const DmaPlan d = make_dma_plan(g.M, g.N, g.K, f16x2 && layout == NT && io == 0 && !rsc && !xo && !slabs_out);
     bm = d.bm; bn = d.bn; split = d.split;
     if (io & 4) split = 1;   // a bf16 output is written by the product kernel itself
   }
@@ -1717,7 +1718,7 @@ int gemm_impl(int layout, int precision, int64_t M, int64_t N, int64_t K, const 
   // softmax statistics ride in the 16-byte-store epilogue of the split kernel: every 32-column block must take it
   if (stats && stats->m && stats->s && stats->cols > 0 && dma_ok && layout == NT && split == 1 && !slabs_out && !accumulate &&
       g.vecC && N % 32 == 0 && stats->cols <= N && bm == 128) {   // bm == 128: the tile shapes that carry the registers
-    const int waves_n = bn == 160 ? 1 : (bm == 160 ? 4 : 2);      // WAVES_N of the three tile shapes launched below
+    const int waves_n = bn >= 160 ? 1 : (bm == 160 ? 4 : 2);      // WAVES_N of the tile shapes launched below
     const int span = bn / waves_n;
     const int slots = (stats->cols + span - 1) / span;
     if ((int64_t)slots * M <= stats->capacity) {
@@ -1782,6 +1783,8 @@ int gemm_impl(int layout, int precision, int64_t M, int64_t N, int64_t K, const 
       if (bm == 128 && bn == 128) hipLaunchKernelGGL((gemm_x3_kernel<TN, 128, 128, 2, 2, 0, true>), grid1, dim3(256), 0, st, g);
       else if (bn == 160)         hipLaunchKernelGGL((gemm_x3_kernel<TN, 128, 160, 4, 2, 0, true>), grid1, dim3(256), 0, st, g);
       else                        hipLaunchKernelGGL((gemm_x3_kernel<TN, 160, 128, 1, 2, 0, true>), grid1, dim3(256), 0, st, g);
+    } else if (f16x2 && bn == 320) {
+      hipLaunchKernelGGL((gemm_x3_kernel<NT, 128, 320, 4, 2>), grid1, dim3(256), 0, st, g);
     } else if (f16x2) {
       if (layout == NT) VAE_X3_LAUNCH(NT, 2);
       else if (layout == NN) VAE_X3_LAUNCH(NN, 2);

@@ -41,13 +41,13 @@ BUCKET_ORDER = ("dec_heads", "small", "enc_w0")
 
 class GradAllReducer:
     def __init__(self, arena: ParamArena, group: Optional["dist.ProcessGroup"] = None, payload: str = "fp32",
-                 force_collectives: bool = False, enc_slabs: int = 0):
+                 force_collectives: bool = False, enc_slabs: int = 0, enc_slab_min_bytes: int = 8 << 20):
         """``force_collectives``: run every collective although the group has ONE rank (they are identities then) --
         lets a one-GPU box execute the whole RCCL path (events, side stream, in-place AVG on arena slices).
 
         ``enc_slabs``: cut the last bucket -- the (H + Hl, G) first-layer encoder weight gradient, written by the last GEMM
-        of the backward -- into up to this many ROW slabs (contiguous arena ranges, whole 128-row tiles, at least 8 MB
-        each); the native backward then produces and releases them one by one (``vae_elbo_step_backward_slabs``), so that
+        of the backward -- into up to this many ROW slabs (contiguous arena ranges, whole 128-row tiles, at least
+        ``enc_slab_min_bytes`` each: xGMI wants few, large messages); the native backward then produces and releases them one by one (``vae_elbo_step_backward_slabs``), so that
         slab i travels while slab i + 1 is computed.  0 / 1: one bucket, one launch."""
         if payload not in ("fp32", "bf16"):
             raise ValueError("payload must be 'fp32' or 'bf16'")
@@ -79,7 +79,7 @@ class GradAllReducer:
         rows = lo // ld if lo % ld == 0 else 0
         self.enc_row_bounds: List[int] = [0, rows]
         if enc_slabs > 1 and rows >= 256:
-            per = max(128, -(-(8 << 20) // (ld * 4) // 128) * 128, -(-rows // enc_slabs // 128) * 128)   # rows per slab
+            per = max(128, -(-int(enc_slab_min_bytes) // (ld * 4) // 128) * 128, -(-rows // enc_slabs // 128) * 128)   # rows per slab
             b = list(range(0, rows, per)) + [rows]
             if len(b) > 2 and b[-1] - b[-2] < 128:      # a short tail joins its neighbour
                 del b[-2]
