@@ -128,6 +128,8 @@ def _rccl_one_rank_worker(port, q):
     wire copy, broadcast of the parameter arena -- and must leave the single rank's own gradients behind."""
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import faulthandler
+    faulthandler.dump_traceback_later(100, exit=True)      # a stuck collective names its line instead of timing the test out
     import torch.distributed as dist
     torch.cuda.set_device(0)
     try:
@@ -153,13 +155,33 @@ def _rccl_one_rank_worker(port, q):
         torch.cuda.synchronize()
         want = arena.flat_grad[:arena.used_end].clone()
         res = {}
-        for payload, slabs in (("fp32", 0), ("bf16", 0), ("fp32s", 3), ("bf16s", 3)):
+        order = (("fp32", 0), ("bf16", 0), ("fp32s", 3), ("bf16s", 3))
+        if os.environ.get("VAE_TEST_VARIANT") == "order":   # diagnostic: is it the slabs, or the third reducer's stream?
+            order = order[2:] + order[:2]
+        for payload, slabs in order:
             red = GradAllReducer(arena, payload=payload[:4], force_collectives=True, enc_slabs=slabs, enc_slab_min_bytes=1 << 20)
             assert red.active and red.avg_in_collective and not red.host_staged and red.enc_slabs == max(1, slabs)
-            for _ in range(5):                                              # several steps in flight, no synchronisation
+            if os.environ.get("VAE_TEST_VARIANT") == "nonative" and slabs:   # diagnostic: five collectives, no native slab events
+                red.enc_slabs = 1
+            print("rccl one-rank:", payload, "slabs", red.enc_slabs, red.enc_row_bounds, flush=True)
+            for it in range(5):                                             # several steps in flight, no synchronisation
                 arena.flat_grad.fill_(float("nan"))
                 step.run(x, ez, el, reducer=red)
                 red.finish()
+                if os.environ.get("VAE_TEST_SYNC_EACH") == "dev":
+                    torch.cuda.synchronize()
+                    print("  step", it, "done", flush=True)
+                elif os.environ.get("VAE_TEST_SYNC_EACH"):   # diagnostic: name what is stuck instead of hanging
+                    import time
+                    t_end = time.time() + 20
+                    while time.time() < t_end and not (torch.cuda.current_stream().query() and red.comm_stream.query()):
+                        time.sleep(0.05)
+                    evs = {"heads": step._ev_heads, "small": step._ev_small}
+                    evs.update({f"slab{i}": e for i, e in enumerate(step._ev_slabs or [])})
+                    print("  step", it, "compute done", torch.cuda.current_stream().query(), "comm done", red.comm_stream.query(),
+                          {k: e.query() for k, e in evs.items()}, flush=True)
+                    if not (torch.cuda.current_stream().query() and red.comm_stream.query()):
+                        os._exit(3)
             torch.cuda.synchronize()
             real = torch.zeros(arena.used_end, dtype=torch.bool, device="cuda")     # gradient elements (not alignment padding)
             for k, (off, shape) in arena.offsets.items():

@@ -79,6 +79,7 @@ struct GemmArgs {
   const float* xone_flags;
   int n_xone;
   const float* row_sub;
+  int stagger;               // experiment (VAE_GEMM_STAGGER): start-phase offset of co-resident workgroups, units of 1024 cycles
 };
 
 // ---- global -> register tile loaders (R*8/256 float4 per thread per operand, R = 64 or 128) ----
@@ -881,6 +882,11 @@ __global__ __launch_bounds__(256, ((VAE_X3_PIPE && NP <= 2 && BM == 128 && BN ==
   const int nwg = gridDim.x;
   const int xcd = blockIdx.x & 7, q8 = nwg >> 3, r8 = nwg & 7;
   const int id = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3);
+  if (g.stagger > 0) {   // experiment: start the co-resident workgroups of a CU at different phases
+    constexpr int PER_CU = ((VAE_X3_PIPE && NP <= 2 && BM == 128 && BN == 128) || ROWSC || XONE != 0 || BN > 160) ? 2 : (NP <= 2 ? 3 : 2);
+    const int sl = (blockIdx.x >> 8) % PER_CU;
+    for (int i = 0; i < sl * g.stagger; ++i) __builtin_amdgcn_s_sleep(16);
+  }
   const int tiles_m = g.tiles_m, tiles_n = g.tiles_n;
   const int per_split = tiles_m * tiles_n;
   const int s = id / per_split, t = id - s * per_split;
@@ -1638,6 +1644,7 @@ int gemm_impl(int layout, int precision, int64_t M, int64_t N, int64_t K, const 
   g.stat_m = g.stat_s = nullptr; g.stat_cols = 0;
   g.rmax0 = g.rmax1 = nullptr; g.rmax_split = g.rmax_chunks = 0; g.rmax_stride = 0;
   g.xone_flags = nullptr; g.n_xone = 0; g.row_sub = nullptr;
+  g.stagger = 0;   // set below, once the tile shape is known
   if (stats) stats->slots = 0;
   g.lda = lda; g.ldb = ldb; g.ldc = ldc;
   g.M = (int)M; g.N = (int)N; g.K = (int)K;
@@ -1728,6 +1735,25 @@ int gemm_impl(int layout, int precision, int64_t M, int64_t N, int64_t K, const 
   }
   if (dma_ok) {
     dim3 grid1(tiles_m * g.tiles_n * split);
+    {   // Start-phase offset of the workgroups that share a CU (gemm_x3_kernel).  Workgroups launched together run in
+        // lock-step -- all wait for loads, all convert, all multiply, all store at the same time, and the phases add up
+        // (tools/micro/gemm_probe.hip ablations: 18 us of MFMA + 12 us of conversion + 19 us of memory = the 49.5 us of
+        // the decoder-head forward).  The short-K NT product with its long output stage (three workgroups per CU, 1.3
+        // generations) gains 10 % when the second and third workgroup of a CU start a third of a workgroup's lifetime
+        // later each (cfg2, same box: 66.5 -> 60.3 us for 12-20 units, 61.1 at 8, 62.6 at 32).  The single-generation
+        // products (two per CU: dgrad, both weight gradients, encoder forward) lose what the delay costs (measured at 8 and
+        // 24 units each: step +0 ... +8 us), so only that class is staggered.  Unit: 1024 cycles.
+      auto env = [](const char* n, int d) { const char* v = getenv(n); return v ? atoi(v) : d; };
+      static const int st_decf = env("VAE_STAG_DECF", -1), st_encf = env("VAE_STAG_ENCF", 0), st_dgrad = env("VAE_STAG_DGRAD", 0),
+                       st_decw = env("VAE_STAG_DECW", 0), st_encw = env("VAE_STAG_ENCW", 0);
+      const bool decf = layout == NT && K <= 512 && f16x2 && !xo && !(bm == 128 && bn == 128) && bn <= 160;
+      int rule = 0;
+      if (decf && grid1.x > 256 && grid1.x <= 4 * 768) {
+        rule = (int)((tiles_per_split * 4.8 + 11.0) / 3.0 + 0.5);   // lifetime ~ K steps x 4.8 k cycles + 11 k of output stage
+        if (rule > 32) rule = 32;
+      }
+      g.stagger = layout == NT ? (K <= 512 ? (st_decf >= 0 ? st_decf : rule) : st_encf) : layout == NN ? st_dgrad : (rsc ? st_decw : st_encw);
+    }
 #define VAE_DMA_LAUNCH(LAY)                                                                              \
     do {                                                                                                   \
       if (bm == 128 && bn == 128) hipLaunchKernelGGL((gemm32_dma_kernel<LAY, 128, 128, 2>), grid1, dim3(256), 0, st, g); \

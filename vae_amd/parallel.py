@@ -38,6 +38,21 @@ from .arena import ParamArena, _enc
 
 BUCKET_ORDER = ("dec_heads", "small", "enc_w0")
 
+# ONE communication stream per device and process, shared by every reducer.  Hardware queues are scarce
+# (GPU_MAX_HW_QUEUES = 4 on the MI355X boxes) and streams beyond them share queues: with a fresh high-priority stream per
+# GradAllReducer, the THIRD reducer of a process (null stream + three side streams + RCCL's own = five streams) left
+# hipDeviceSynchronize() waiting forever in its second step although every stream's query() reported completion
+# (tests/test_parallel_gpu.py, round 3; independent of buckets, payload and row slabs -- DESIGN 6).
+_COMM_STREAMS: Dict[int, "torch.cuda.Stream"] = {}
+
+
+def _comm_stream(device) -> "torch.cuda.Stream":
+    idx = torch.device(device).index
+    idx = torch.cuda.current_device() if idx is None else idx
+    if idx not in _COMM_STREAMS:
+        _COMM_STREAMS[idx] = torch.cuda.Stream(device=idx, priority=-1)
+    return _COMM_STREAMS[idx]
+
 
 class GradAllReducer:
     def __init__(self, arena: ParamArena, group: Optional["dist.ProcessGroup"] = None, payload: str = "fp32",
@@ -61,7 +76,7 @@ class GradAllReducer:
         self.host_staged = self.on_gpu and self.active and backend != "nccl"
         # RCCL averages in the collective itself (ReduceOp.AVG); gloo has no AVG: sum, then scale
         self.avg_in_collective = self.active and self.on_gpu and backend == "nccl"
-        self.comm_stream = torch.cuda.Stream(device=arena.device, priority=-1) if self.on_gpu else None
+        self.comm_stream = _comm_stream(arena.device) if self.on_gpu else None
         self._pending: List[tuple] = []
         # bucket boundaries (element offsets into flat_grad).  Under NB the dropout-head weights have no
         # gradient and fall between "dec_heads" and "small".
