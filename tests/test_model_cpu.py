@@ -129,3 +129,34 @@ def test_cell_loss_matches_oracle():
     ref.backward()
     assert torch.allclose(loss, ref, atol=1e-6)
     assert torch.allclose(z.grad, z2.grad, atol=1e-6)
+
+
+def test_group_dro_cell_loss_matches_the_reference_sequence():
+    """`use_gdro=True` (task.py:84-101, 419-451): seven consecutive `_cell_loss` calls across the step-500 switch-on, against
+    a fixture made by running the reference's `losses.GroupDRO` through the same sequence
+    (tests/golden/make_goldens_gdro.py): every step's loss and both trackers' weights / running losses after it."""
+    from vae_amd.networks import VAE
+    from vae_amd.task import LitVAE
+    gold = load_golden("gdro_sequence.npz")
+    props = {"Dementia": {"discrete": True, "values": [0, 1]}, "BRAAK_AD": {"discrete": False, "values": [-1]},
+             "Sex": {"discrete": True, "values": [0, 1, 2]}}
+    with contextlib.redirect_stdout(io.StringIO()):
+        net = VAE(32, n_hidden=16, n_hidden_decoder=16, n_hidden_library=16, n_latent=4, n_latent_cell_decoder=4, n_layers=1,
+                  cell_properties=props, grad_reverse_dict={})
+    lit = LitVAE(net, cell_properties=props, use_gdro=True, library_mean=5.0, library_var=1.0)
+    groups = [int(g) for g in gold["groups"]]
+    for t, train_step in enumerate(gold["train_steps"]):
+        lit.train_step = int(train_step)
+        pred = {k: torch.from_numpy(gold[f"s{t}/pred/{k}"]) for k in props}
+        loss = lit._cell_loss(pred, torch.from_numpy(gold[f"s{t}/vals"]), torch.from_numpy(gold[f"s{t}/mask"]),
+                              [int(g) for g in gold[f"s{t}/group_idx"]])
+        assert abs(float(loss) - float(gold[f"s{t}/cell_loss"])) < 1e-12 * abs(float(gold[f"s{t}/cell_loss"])), t
+        for k in ("Dementia", "BRAAK_AD"):
+            np.testing.assert_allclose([lit.gdro[k].weights[g] for g in groups], gold[f"s{t}/weights/{k}"], rtol=1e-13, atol=0)
+            np.testing.assert_allclose([lit.gdro[k].running_loss[g] for g in groups], gold[f"s{t}/running/{k}"], rtol=1e-13, atol=0)
+    # the weights did switch on: the last steps' losses differ from the unweighted sum
+    from vae_amd.task import cell_loss
+    t = len(gold["train_steps"]) - 1
+    plain = cell_loss({k: torch.from_numpy(gold[f"s{t}/pred/{k}"]) for k in props}, props, torch.from_numpy(gold[f"s{t}/vals"]),
+                      torch.from_numpy(gold[f"s{t}/mask"]))
+    assert abs(float(plain) - float(gold[f"s{t}/cell_loss"])) > 1e-3

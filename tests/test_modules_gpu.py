@@ -456,3 +456,54 @@ def test_grouped_encoder_forward_matches_the_reference(monkeypatch):
     for name in case["cell_properties"]:
         w = net.z_encoder.z_enc[name].encoder.fc_layers[0].weight
         assert w.grad is not None and float(w.grad.abs().max()) > 0
+
+
+def test_group_dro_on_the_fused_step_matches_the_module_path(monkeypatch):
+    """`use_gdro=True` on the fused step: the heads run through torch autograd on (B, L) with the donor groups of the batch
+    (per-cell losses go back to the host, as in the reference, task.py:431-448); loss, tracker state and every gradient equal
+    the module path's.  (The tracker itself is pinned against the reference in test_model_cpu.py.)"""
+    import vae_amd.modules as M
+    from vae_amd.losses import GroupDRO
+    case0 = E2E_CASES[4]                     # a heads case
+    names = list(case0["cell_properties"])
+    groups = GroupDRO.DEFAULT_GROUPS[:14]
+
+    def arm(task, B):
+        task.use_gdro = True
+        task.gdro = {names[0]: GroupDRO(balances=[list(groups)]), names[1]: GroupDRO()}
+        rng = np.random.default_rng(5)
+        gi = [groups[i] for i in rng.integers(0, 14, size=4 * B)]
+        for g in task.gdro.values():         # running losses from two synthetic batches: unequal weights from here on
+            for _ in range(2):
+                g.update_batch(torch.from_numpy(rng.random(4 * B) * 3), torch.ones(4 * B), gi)
+                g.update_weights()
+        task._native_heads = None
+        task.train_step = 600
+        return [groups[i] for i in np.random.default_rng(6).integers(0, 14, size=B)]
+
+    _, task_m, batch, eps_z, eps_l = build_task(case0)
+    gi = arm(task_m, batch[0].shape[0])
+    batch = batch[:6] + (gi, None)
+    task_m.network.cuda()
+    queue = [eps_z, eps_l]
+    monkeypatch.setattr(M, "reparameterize_gaussian", lambda mu, var: mu + queue.pop(0) * var.sqrt())
+    loss_m = task_m.training_step(batch, 0)
+    loss_m.backward()
+    _, task_f, batch_f, eps_z, eps_l = build_task(case0)
+    assert arm(task_f, batch_f[0].shape[0]) == gi
+    task_f.attach_arena("cuda")
+    out = task_f.training_step_fused(batch_f[:6] + (gi, None), eps_z, eps_l)
+    assert task_f._native_heads is False
+    w = task_f.gdro[names[0]].get_weights(gi)
+    assert float(w.max() - w.min()) > 0.05                           # the weights are not trivial
+    assert abs(float(out["loss"]) - float(loss_m.detach())) < TOL_CELL * abs(float(loss_m.detach()))
+    for k in task_f.gdro:
+        assert task_f.gdro[k].running_loss == pytest.approx(task_m.gdro[k].running_loss, rel=1e-5)
+    gm = dict(task_m.network.named_parameters())
+    n = 0
+    for k, p in task_f.network.named_parameters():
+        if gm[k].grad is None:
+            continue
+        assert rel_err(p.grad.cpu().numpy(), gm[k].grad.cpu().numpy()) < TOL_GRAD, k
+        n += 1
+    assert n >= 15

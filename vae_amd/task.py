@@ -120,8 +120,13 @@ class LitVAE(nn.Module):
         self._create_results_dict()
         # balance_classes (task.py:129-132): class weights of every discrete head's cross-entropy
         self.class_weights = class_balance_weights(cell_properties) if (balance_classes and cell_properties) else None
+        # GroupDRO re-weighting of two heads' per-cell losses by donor group (task.py:84-101; off in the shipped config)
+        self.gdro = None
         if use_gdro:
-            raise NotImplementedError("vae_amd: GroupDRO re-weighting (off in the shipped config) is not wired in")
+            from .losses import GroupDRO
+            paired = [[0, 1, 60, 61], [10, 11, 50, 51], [20, 21, 40, 41], [30, 31]]
+            self.gdro = {"Dementia": GroupDRO(balances=[[g for pair in paired for g in pair]]),
+                         "BRAAK_AD": GroupDRO(balances=paired)}
 
     # -- bookkeeping the reference delegates to Lightning ---------------------------------
     def log(self, name, value, **_):
@@ -165,7 +170,28 @@ class LitVAE(nn.Module):
         return loss, kl_z
 
     def _cell_loss(self, cell_pred, cell_prop_vals, cell_mask, group_idx):
-        return cell_loss(cell_pred, self.cell_properties, cell_prop_vals, cell_mask, class_weights=self.class_weights)
+        if not self.gdro:
+            return cell_loss(cell_pred, self.cell_properties, cell_prop_vals, cell_mask, class_weights=self.class_weights)
+        # task.py:419-451 with GroupDRO: the heads it tracks weight every cell's loss by its donor group's running loss
+        # (from training step 500 on) and feed the UNWEIGHTED per-cell losses back into the running statistics -- a host
+        # round trip per step, as in the reference (`loss.tolist()`)
+        total = 0.0
+        for n, (k, prop) in enumerate(self.cell_properties.items()):
+            tracked = k in self.gdro
+            w = self.gdro[k].get_weights(group_idx).to(cell_pred[k].device) if tracked and self.train_step >= 500 else 1.0
+            if prop["discrete"]:
+                cw = (self.class_weights or {}).get(k)
+                if cw is not None:
+                    cw = cw.to(device=cell_pred[k].device, dtype=cell_pred[k].dtype)
+                per = nn.functional.cross_entropy(cell_pred[k], cell_prop_vals[:, n].to(torch.int64), weight=cw,
+                                                  reduction="none", ignore_index=-100)
+            else:
+                per = (torch.squeeze(cell_pred[k]) - cell_prop_vals[:, n]) ** 2
+            total = total + (w * per * cell_mask[:, n]).mean()
+            if tracked:
+                self.gdro[k].update_batch(per, cell_mask[:, n], group_idx)
+                self.gdro[k].update_weights()
+        return total
 
     def training_step(self, batch, batch_idx):
         self.train_step += 1
@@ -393,15 +419,17 @@ class LitVAE(nn.Module):
                 hidden = any(not isinstance(m, nn.Linear) for m in dec.cell_mlp.values())
                 widths = sum(len(v["values"]) if v["discrete"] else 1 for v in self.cell_properties.values())
                 from . import _lib
-                if hidden or len(self.cell_properties) > _lib.VAE_MAX_HEADS or widths > 64 or self.network.n_latent > 64:
-                    self._native_heads = False      # hidden-layer heads / beyond the kernel's limits: torch autograd on (B, L)
+                if hidden or self.gdro or len(self.cell_properties) > _lib.VAE_MAX_HEADS or widths > 64 or self.network.n_latent > 64:
+                    self._native_heads = False      # hidden-layer heads / GroupDRO (per-cell losses go back to the host) /
+                                                    # beyond the kernel's limits: torch autograd on (B, L)
                 else:                               # any other configuration error surfaces
                     self._native_heads = CellHeads(self._arena, self.cell_properties, dec.grad_reverse_dict,
                                                    class_weights=self.class_weights)
             if self._native_heads:
                 heads = (self._native_heads, cell_prop_vals.to(torch.float32), cell_mask.to(torch.float32))
             else:
-                fn = lambda z: self._cell_loss(self.network.cell_decoder(z), cell_prop_vals, cell_mask, None)  # noqa: E731
+                group_idx = batch[6] if len(batch) > 6 else None
+                fn = lambda z: self._cell_loss(self.network.cell_decoder(z), cell_prop_vals, cell_mask, group_idx)  # noqa: E731
         l1 = None
         if self.l1_lambda > 0:   # task.py:491-496; its gradient must be in place before the buckets are reduced
             from .optim import L1Penalty
