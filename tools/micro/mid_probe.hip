@@ -4,7 +4,7 @@
 #include <stdio.h>
 #include <vector>
 int main(int argc, char** argv) {
-  const int B = argc > 1 ? atoi(argv[1]) : 512, H = 256, Hl = 128, HE = 384, L = 30, Hd = 256, NS = 21;
+  const int B = argc > 1 ? atoi(argv[1]) : 512, H = 256, Hl = 128, HE = 384, L = 30, Hd = 256, NS = argc > 2 ? atoi(argv[2]) : 42;
   vae_step_config c{};
   c.B = B; c.G = 20000; c.H = H; c.Hl = Hl; c.L = L; c.Hd = Hd; c.n_layers = 1; c.zinb = 1; c.l_mean = 9.f; c.l_var = 1.f;
   auto dmalloc = [](size_t n) { float* p; hipMalloc(&p, n * 4); hipMemset(p, 0, n * 4); return p; };
@@ -18,7 +18,7 @@ int main(int argc, char** argv) {
   float* eps_z = dmalloc(B * L); float* eps_l = dmalloc(B);
   for (int it = 0; it < 3; ++it)
     vae_mid_forward(c, &p, slabs, NS, eps_z, eps_l, buf[0], buf[1], buf[2], buf[3], buf[4], buf[5], buf[6], buf[7], buf[8], buf[9],
-                    buf[10], buf[11], buf[12], buf[13], buf[14], buf[15], buf[16], buf[17], nullptr, nullptr, nullptr);
+                    buf[10], buf[11], buf[12], buf[13], buf[14], buf[15], buf[16], buf[17], nullptr, nullptr, nullptr, nullptr, nullptr);
   hipDeviceSynchronize();
   std::vector<unsigned long long> h(4096 * 16);
   hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(vae_probe), h.size() * 8);

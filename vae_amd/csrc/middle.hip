@@ -196,6 +196,37 @@ __device__ __forceinline__ void stage_dec_w(const float* __restrict__ w, int Hd,
   }
 }
 
+// The same image filled by LDS-DMA (global_load_lds_dword: lane i of a wave-instruction copies 4 bytes from its OWN source
+// address to LDS dword base + i): no staging registers and, above all, no wait -- stage_dec_w's load -> wait -> LDS store
+// rounds were two of the three or four dependent global round trips that made up half of a cell's 16 us
+// (tools/micro/mid_probe.hip: 9.2 us before the first LayerNorm, 8.2 us with ONE slab).  The destination is contiguous, so
+// the odd stride is realised on the SOURCE side: LDS dword d = n * LP + j takes w[n * L + j] (pad columns j >= L and the
+// dwords past Hd * LP, up to the next multiple of 64, take w[0]; nobody reads them).  The copies complete with the
+// wave's vmcnt -- the slab sums that follow wait for everything issued before them -- and the workgroup's barriers before
+// the first use publish them.  `ws` needs (Hd * LP + 63) / 64 * 64 floats.
+typedef __attribute__((address_space(3))) void* mid_lds_ptr;
+__device__ __forceinline__ void stage_dec_w_dma(const float* __restrict__ w, int Hd, int L, int LP, float* ws) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int dwords = Hd * LP;
+  const float invLP = 1.f / (float)LP;
+  const uint32_t base = (uint32_t)(uintptr_t)(mid_lds_ptr)ws;
+  for (int p = wave; p * 64 < dwords; p += NWV) {
+    const int d = p * 64 + lane;
+    int n = (int)((float)d * invLP);       // d / LP for d < 2^20: the float quotient is off by at most one
+    n += (n + 1) * LP <= d ? 1 : 0;
+    n -= n * LP > d ? 1 : 0;
+    const int j = d - n * LP;
+    const float* src = (j < L && n < Hd) ? w + n * L + j : w;
+    const uint32_t dst = __builtin_amdgcn_readfirstlane(base + (uint32_t)p * 256u);
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(src), "s"(dst)
+                 : "memory");
+  }
+}
+__host__ __device__ inline size_t dec_w_lds_bytes(int Hd, int L) { return (size_t)((Hd * (L | 1) + 63) / 64 * 64) * 4; }
+
 __global__ __launch_bounds__(T) void mid_fwd_kernel(MidFwd a) {
   extern __shared__ __attribute__((aligned(16))) float dyn[];  // decoder weight, Hd x LP
   __shared__ float hs[ME * T];   // LayerNorm outputs of both encoders (H+Hl)
@@ -221,7 +252,7 @@ __global__ __launch_bounds__(T) void mid_fwd_kernel(MidFwd a) {
     dgam[i] = e < Hd ? a.gd[e] : 0.f;
     dbet[i] = e < Hd ? a.bd[e] : 0.f;
   }
-  stage_dec_w(a.d_w, Hd, L, LP, dyn);
+  stage_dec_w_dma(a.d_w, Hd, L, LP, dyn);
   // head weights of this wave's outputs o = wave + NWV r (lanes along k: coalesced row reads), k < 256
   constexpr int RH = (36 + NWV - 1) / NWV;  // outputs per wave per pass: one pass covers L + 3 <= 36
   float hw[RH][4];
@@ -329,6 +360,7 @@ __global__ __launch_bounds__(T) void mid_fwd_kernel(MidFwd a) {
     if (lane < 2) a.heads_l[(int64_t)b * 2 + lane] = hd[L + 1 + lane];
     reparam_wave(hd + L + 1, 1, epsl, a.l_mean, a.l_var, lane, a.library + b, nullptr, a.ql_v + b, a.kl_l + b);
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces of the decoder weight (long landed)
   __syncthreads();
   STAMP(5);
   // 5. first decoder layer: Linear(L -> Hd) + GELU + LayerNorm, weight rows from LDS
@@ -420,7 +452,7 @@ __global__ __launch_bounds__(T) void mid_bwd_kernel(MidBwd a) {
   const int H = a.H, Hl = a.Hl, HE = a.H + a.Hl, L = a.L, Hd = a.Hd;
 
   const int LP = L | 1;
-  stage_dec_w(a.d_w, Hd, L, LP, dyn);
+  stage_dec_w_dma(a.d_w, Hd, L, LP, dyn);
   // 1. d(dec_h): sum of the dgrad slabs; LayerNorm + GELU backward of the decoder layer
   const float mud = a.ln_md[b], rsd = a.ln_rd[b];
   const float mu0 = a.ln_mz[b], rs0 = a.ln_rz[b], mu1 = a.ln_ml[b], rs1 = a.ln_rl[b];
@@ -482,6 +514,7 @@ __global__ __launch_bounds__(T) void mid_bwd_kernel(MidBwd a) {
       a.dpre_d[(int64_t)b * Hd + n] = v;
     }
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces of the decoder weight (long landed; also the stores above)
   __syncthreads();
   // 2. dz[j] = sum_n dpre_d[n] W[n][j] (+ cell-head gradient); 8 threads per output
   {
@@ -1411,7 +1444,7 @@ int vae_mid_forward(const vae_step_config& c, const vae_step_tensors* p, const f
   MidWavePlan pl;
   if (mid_wave_plan(c, p->hz_w, &pl)) MID_WAVE_DISPATCH(mid_fwd_wave_kernel, a);
   else
-    hipLaunchKernelGGL(mid_fwd_kernel, dim3((unsigned)c.B), dim3(T), (size_t)(c.Hd * (c.L | 1) * 4), (hipStream_t)stream, a);
+    hipLaunchKernelGGL(mid_fwd_kernel, dim3((unsigned)c.B), dim3(T), dec_w_lds_bytes((int)c.Hd, (int)c.L), (hipStream_t)stream, a);
   VAE_CHECK_LAUNCH("vae_elbo_step_forward(mid)");
   return VAE_OK;
 }
@@ -1447,7 +1480,7 @@ int vae_mid_backward(const vae_step_config& c, const vae_step_tensors* p, const 
   MidWavePlan pl;
   if (mid_wave_plan(c, p->hz_w, &pl)) MID_WAVE_DISPATCH(mid_bwd_wave_kernel, a);
   else
-    hipLaunchKernelGGL(mid_bwd_kernel, dim3((unsigned)c.B), dim3(T), (size_t)(c.Hd * (c.L | 1) * 4), (hipStream_t)stream, a);
+    hipLaunchKernelGGL(mid_bwd_kernel, dim3((unsigned)c.B), dim3(T), dec_w_lds_bytes((int)c.Hd, (int)c.L), (hipStream_t)stream, a);
   VAE_CHECK_LAUNCH("vae_elbo_step_backward(mid)");
 
   // every small parameter gradient of the step, one launch
