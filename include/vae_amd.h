@@ -396,6 +396,14 @@ typedef struct {
    * forward skips its own cast of the two matrices (one launch, 6 bytes per weight) and every product streams these. */
   const void* weight_bf16_enc;
   const void* weight_bf16_heads;
+  /* != 0: the caller ALWAYS follows vae_elbo_step_forward with vae_elbo_step_backward on the same workspace and
+   * configuration (a training step).  The forward then leaves the likelihood's per-strip partial sums in the workspace and
+   * launches no ELBO reduction; the backward's first launch forms S_b from them and, in one extra workgroup, writes
+   * VAE_WS_LL / VAE_WS_RECON / VAE_WS_SCALARS (task.py:202,489) -- the same values, one launch less on the step's
+   * critical path (the sums over cells run in a different, equally fixed order).  Those three slices are valid only once
+   * the backward has been enqueued.  Batches above 1024 cells ignore it.  0: the forward is complete on its own
+   * (validation, vae_elbo_step_px_rate).                                                                            */
+  int32_t defer_elbo_reduce;
 } vae_step_config;
 
 typedef struct {

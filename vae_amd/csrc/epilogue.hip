@@ -762,6 +762,68 @@ __device__ __forceinline__ RowIn load_row(const LT* ls, int64_t ld_s, const LT* 
   return r;
 }
 
+// The ELBO reduction of a training step whose forward left it to the backward (vae_step_config.defer_elbo_reduce): the
+// likelihood forward's per-strip partials part[(s * 2 + k) * B + b] (k = 0: ll, 1: S) are still in the workspace.  Every
+// workgroup of the backward forms the S_b of its own cells from them (strip order, as vae_elbo_reduce_parts does), and the
+// first workgroup writes ll / S / recon and the five scalars before it turns to its own tile (rowops.hip,
+// elbo_reduce_kernel: same expressions; the sums over cells run over 256 threads here instead of 1024).
+struct ElboParts {
+  const float* part;   // null = off
+  int strips;
+  float *ll, *S, *recon, *out5;
+  const float *kl_z, *kl_l;
+  float kl_weight, coeff;
+};
+__device__ __forceinline__ float strip_sum(const float* __restrict__ p, int strips, int64_t st) {
+  float v = 0.f;
+  int s = 0;
+  for (; s + 8 <= strips; s += 8) {   // eight loads in flight, summed in strip order
+    float q[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) q[u] = p[(s + u) * st];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v += q[u];
+  }
+  for (; s + 4 <= strips; s += 4) {
+    const float a = p[s * st], b2 = p[(s + 1) * st], c2 = p[(s + 2) * st], d2 = p[(s + 3) * st];
+    v = (((v + a) + b2) + c2) + d2;
+  }
+  for (; s < strips; ++s) v += p[s * st];
+  return v;
+}
+__device__ __forceinline__ void elbo_from_parts(const ElboParts& e, int B) {
+  __shared__ float red4[4][4];
+  const int64_t st = (int64_t)2 * B;
+  float a = 0.f, b = 0.f, c = 0.f, d = 0.f;
+  for (int i = threadIdx.x; i < B; i += 256) {
+    const float l = strip_sum(e.part + i, e.strips, st), sb = strip_sum(e.part + B + i, e.strips, st);
+    e.ll[i] = l;
+    e.S[i] = sb;
+    if (e.recon) e.recon[i] = -l;
+    a -= l;
+    b += e.kl_z[i];
+    c += e.kl_l[i];
+    d += e.kl_l[i] + e.kl_z[i];
+  }
+  a = wave_sum_dpp(a); b = wave_sum_dpp(b); c = wave_sum_dpp(c); d = wave_sum_dpp(d);
+  if ((threadIdx.x & 63) == 0) {
+    const int w = threadIdx.x >> 6;
+    red4[0][w] = a; red4[1][w] = b; red4[2][w] = c; red4[3][w] = d;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    a = b = c = d = 0.f;
+    for (int w = 0; w < 4; ++w) { a += red4[0][w]; b += red4[1][w]; c += red4[2][w]; d += red4[3][w]; }
+    const float n = (float)B;
+    const float gl = a / n + e.kl_weight * (d / n);
+    e.out5[0] = a / n;
+    e.out5[1] = b / n;
+    e.out5[2] = c / n;
+    e.out5[3] = gl;
+    e.out5[4] = e.coeff * gl;
+  }
+}
+
 template <bool ZINB, bool VEC, bool SLAB, typename XT, typename LT>
 __global__ __launch_bounds__(256) void nbzinb_bwd_kernel(
     const LT* ls, int64_t ld_s, const LT* lp, int64_t ld_p, const XT* __restrict__ x, int64_t ld_x,
@@ -769,19 +831,25 @@ __global__ __launch_bounds__(256) void nbzinb_bwd_kernel(
     const float* __restrict__ rowsum, const float* __restrict__ S, const float* __restrict__ g_ll, float g_scalar, int B,
     int G, int rows_per_block, LT* dls, int64_t ld_ds, LT* dlp, int64_t ld_dp, float* __restrict__ dlibrary,
     float* __restrict__ dpx_r, float* __restrict__ dbias_s, float* __restrict__ dbias_p, float* __restrict__ slab,
-    float* __restrict__ absmax) {
+    float* __restrict__ absmax, ElboParts ep) {
+  // a deferred ELBO reduction is done by workgroup (0, 0) before its own tile: ~5 us of latency chain in a workgroup of the
+  // first generation, which still ends before the kernel does.  (As an extra row of workgroups it was measured slower: last
+  // in the grid it starts when the others finish and becomes the tail, +2 us; first in the grid, +7 us.)
+  const int by = (int)blockIdx.y;
+  if (ep.part && blockIdx.x == 0 && by == 0) elbo_from_parts(ep, B);
   __shared__ float4 rc[BWD_MAX_ROWS];  // per cell: {-(max + log(sumexp)) log2(e), exp(library), S_b, delta_b}
   __shared__ unsigned int wg_absmax;    // max |gradient| written by this workgroup (absmax != null), as float bits
   if (threadIdx.x == 0) wg_absmax = 0u;
   float am = 0.f;
   const int g0 = blockIdx.x * BWD_STRIP + threadIdx.x * 4;
-  const int b0 = blockIdx.y * rows_per_block;
+  const int b0 = by * rows_per_block;
   const int b1 = min(B, b0 + rows_per_block);
   for (int r = threadIdx.x; r < b1 - b0; r += 256) {
     const int b = b0 + r;
     const float delta = g_scalar * (g_ll ? g_ll[b] : 1.f);
-    rc[r] = make_float4(-(rowmax[b] + logf(rowsum[b])) * LOG2E, expf(library[b]), S[b], delta);
-    if (blockIdx.x == 0 && dlibrary) dlibrary[b] = delta * S[b];
+    const float Sb = ep.part ? strip_sum(ep.part + B + b, ep.strips, (int64_t)2 * B) : S[b];
+    rc[r] = make_float4(-(rowmax[b] + logf(rowsum[b])) * LOG2E, expf(library[b]), Sb, delta);
+    if (blockIdx.x == 0 && dlibrary) dlibrary[b] = delta * Sb;
   }
   __syncthreads();
   if (g0 >= G) return;
@@ -864,12 +932,12 @@ __global__ __launch_bounds__(256) void nbzinb_bwd_kernel(
   if (absmax) {  // threads past G have left: LDS integer max of the rest, then this workgroup's entry of the partial maxima
     atomicMax(&wg_absmax, __float_as_uint(am));
     __syncthreads();
-    if (threadIdx.x == 0) absmax[blockIdx.y * gridDim.x + blockIdx.x] = __uint_as_float(wg_absmax);
+    if (threadIdx.x == 0) absmax[by * gridDim.x + blockIdx.x] = __uint_as_float(wg_absmax);
   }
   if (SLAB) {
     // partial column sums of this cell chunk: plain coalesced stores into slab[chunk][3][G];
     // colreduce_kernel adds them up in chunk order (deterministic, no float atomics)
-    float* sl = slab + (int64_t)blockIdx.y * VAE_SLAB_ROWS * G + g0;
+    float* sl = slab + (int64_t)by * VAE_SLAB_ROWS * G + g0;
 #pragma unroll
     for (int j = 0; j < 4; ++j)
       if (j < nv) {
@@ -1071,9 +1139,9 @@ static int nbzinb_bwd_impl(int zinb, const LT* logit_scale, int64_t ld_s, const 
                            float g_scalar, int64_t B, int64_t G, LT* dlogit_scale, int64_t ld_ds,
                            LT* dlogit_dropout, int64_t ld_dp, float* dlibrary, float* dpx_r, float* dbias_scale,
                            float* dbias_dropout, float* workspace, int64_t workspace_bytes, void* stream, int overwrite,
-                           float* absmax = nullptr, VaeDeferredColreduce* defer = nullptr) {
+                           float* absmax = nullptr, VaeDeferredColreduce* defer = nullptr, const VaeElboFromParts* elbo = nullptr) {
   VAE_REQUIRE(!overwrite || workspace, "vae_nbzinb_bwd_overwrite: needs the workspace (deterministic mode)");
-  VAE_REQUIRE(logit_scale && x && library && gene_table && rowmax && rowsum && S && dlogit_scale && dpx_r,
+  VAE_REQUIRE(logit_scale && x && library && gene_table && rowmax && rowsum && (S || elbo) && dlogit_scale && dpx_r,
               "vae_nbzinb_bwd: null pointer");
   VAE_REQUIRE(!zinb || (logit_dropout && dlogit_dropout), "vae_nbzinb_bwd: ZINB needs the dropout logits and their gradient");
   VAE_REQUIRE(B > 0 && G > 0 && G < (1 << 24), "vae_nbzinb_bwd: bad shape (the gene table is addressed with 24-bit multiplies: G < 2^24)");
@@ -1092,12 +1160,19 @@ static int nbzinb_bwd_impl(int zinb, const LT* logit_scale, int64_t ld_s, const 
   const bool slab = workspace != nullptr;
   VAE_REQUIRE(!slab || workspace_bytes >= vae_nbzinb_bwd_workspace_bytes(B, G),
               "vae_nbzinb_bwd: workspace too small (see vae_nbzinb_bwd_workspace_bytes)");
+  ElboParts ep{};
+  if (elbo) {
+    VAE_REQUIRE(elbo->part && elbo->strips > 0 && elbo->ll && elbo->S && elbo->kl_z && elbo->kl_l && elbo->out5,
+                "vae_nbzinb_bwd: incomplete deferred ELBO reduction");
+    ep.part = elbo->part; ep.strips = elbo->strips; ep.ll = elbo->ll; ep.S = elbo->S; ep.recon = elbo->recon; ep.out5 = elbo->out5;
+    ep.kl_z = elbo->kl_z; ep.kl_l = elbo->kl_l; ep.kl_weight = elbo->kl_weight; ep.coeff = elbo->coeff;
+  }
   dim3 grid(strips, chunks);
   hipStream_t st = (hipStream_t)stream;
 #define LAUNCH_BWD(Z, V, S_)                                                                                          \
   hipLaunchKernelGGL((nbzinb_bwd_kernel<Z, V, S_, XT, LT>), grid, dim3(256), 0, st, logit_scale, ld_s, logit_dropout, ld_p, x,  \
                      ld_x, library, gene_table, rowmax, rowsum, S, g_ll, g_scalar, (int)B, (int)G, rows_per_block,    \
-                     dlogit_scale, ld_ds, dlogit_dropout, ld_dp, dlibrary, dpx_r, dbias_scale, dbias_dropout, workspace, absmax)
+                     dlogit_scale, ld_ds, dlogit_dropout, ld_dp, dlibrary, dpx_r, dbias_scale, dbias_dropout, workspace, absmax, ep)
 #define LAUNCH_BWD2(Z, V) do { if (slab) LAUNCH_BWD(Z, V, true); else LAUNCH_BWD(Z, V, false); } while (0)
   VAE_REQUIRE(!U8 || vec, "vae_nbzinb_bwd_u8: needs G %% 4 == 0, leading dimensions %% 4 == 0 and aligned rows");
   if (U8 || L16) { if (zinb) LAUNCH_BWD2(true, true); else LAUNCH_BWD2(false, true); }
@@ -1123,27 +1198,27 @@ int vae_nbzinb_bwd_ex(int x_dtype, int l_dtype, int zinb, const void* logit_scal
                       const float* rowsum, const float* S, const float* g_ll, float g_scalar, int64_t B, int64_t G,
                       void* dlogit_scale_v, int64_t ld_ds, void* dlogit_dropout_v, int64_t ld_dp, float* dlibrary, float* dpx_r,
                       float* dbias_scale, float* dbias_dropout, float* workspace, int64_t workspace_bytes, float* absmax,
-                      VaeDeferredColreduce* defer, void* stream) {
+                      VaeDeferredColreduce* defer, void* stream, const VaeElboFromParts* elbo) {
   if (l_dtype == VAE_L_BF16) {
     const bf16_t *ls = (const bf16_t*)logit_scale_v, *lp = (const bf16_t*)logit_dropout_v;
     bf16_t *ds = (bf16_t*)dlogit_scale_v, *dp = (bf16_t*)dlogit_dropout_v;
     if (x_dtype == VAE_X_U8)
       return nbzinb_bwd_impl<uint8_t, bf16_t>(zinb, ls, ld_s, lp, ld_p, (const uint8_t*)x, ld_x, library, gene_table, rowmax, rowsum, S,
                                               g_ll, g_scalar, B, G, ds, ld_ds, dp, ld_dp, dlibrary, dpx_r, dbias_scale,
-                                              dbias_dropout, workspace, workspace_bytes, stream, 1, absmax, defer);
+                                              dbias_dropout, workspace, workspace_bytes, stream, 1, absmax, defer, elbo);
     return nbzinb_bwd_impl<float, bf16_t>(zinb, ls, ld_s, lp, ld_p, (const float*)x, ld_x, library, gene_table, rowmax, rowsum, S, g_ll,
                                           g_scalar, B, G, ds, ld_ds, dp, ld_dp, dlibrary, dpx_r, dbias_scale, dbias_dropout,
-                                          workspace, workspace_bytes, stream, 1, absmax, defer);
+                                          workspace, workspace_bytes, stream, 1, absmax, defer, elbo);
   }
   const float *logit_scale = (const float*)logit_scale_v, *logit_dropout = (const float*)logit_dropout_v;
   float *dlogit_scale = (float*)dlogit_scale_v, *dlogit_dropout = (float*)dlogit_dropout_v;
   if (x_dtype == VAE_X_U8)
     return nbzinb_bwd_impl<uint8_t>(zinb, logit_scale, ld_s, logit_dropout, ld_p, (const uint8_t*)x, ld_x, library, gene_table,
                                     rowmax, rowsum, S, g_ll, g_scalar, B, G, dlogit_scale, ld_ds, dlogit_dropout, ld_dp,
-                                    dlibrary, dpx_r, dbias_scale, dbias_dropout, workspace, workspace_bytes, stream, 1, absmax, defer);
+                                    dlibrary, dpx_r, dbias_scale, dbias_dropout, workspace, workspace_bytes, stream, 1, absmax, defer, elbo);
   return nbzinb_bwd_impl<float>(zinb, logit_scale, ld_s, logit_dropout, ld_p, (const float*)x, ld_x, library, gene_table, rowmax,
                                 rowsum, S, g_ll, g_scalar, B, G, dlogit_scale, ld_ds, dlogit_dropout, ld_dp, dlibrary, dpx_r,
-                                dbias_scale, dbias_dropout, workspace, workspace_bytes, stream, 1, absmax, defer);
+                                dbias_scale, dbias_dropout, workspace, workspace_bytes, stream, 1, absmax, defer, elbo);
 }
 
 extern "C" int vae_nbzinb_bwd(int zinb, const float* logit_scale, int64_t ld_s, const float* logit_dropout, int64_t ld_p,
@@ -1182,6 +1257,7 @@ extern "C" int vae_nbzinb_bwd_u8(int zinb, const float* logit_scale, int64_t ld_
 }
 
 // ---- forward, streaming form (host side) ----------------------------------------------------------------------------
+int vae_nbzinb_fwd_strips(int64_t G) { return (int)((G + FWD_STRIP - 1) / FWD_STRIP); }
 namespace {
 void fwd_grid(int64_t B, int64_t G, int* strips, int* chunks, int* rows_per_block) {
   bwd_grid(B, G, strips, chunks, rows_per_block);

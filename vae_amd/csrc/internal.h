@@ -116,6 +116,18 @@ struct VaeDeferredColreduce {
   float* out[3];           // d px_r, d bias_scale, d bias_dropout (overwritten)
 };
 
+// The ELBO reduction left to the backward (vae_step_config.defer_elbo_reduce): `part` = the per-strip partials of the streaming
+// likelihood forward ([strips][2][B], still in the workspace); every workgroup of vae_nbzinb_bwd_ex forms the S_b of its cells
+// from them (its S argument may then be null) and one extra workgroup of the same launch writes ll / S / recon (nullable) and
+// the five scalars of vae_elbo_reduce.
+struct VaeElboFromParts {
+  const float* part;
+  int strips;
+  float *ll, *S, *recon, *out5;
+  const float *kl_z, *kl_l;
+  float kl_weight, coeff;
+};
+int vae_nbzinb_fwd_strips(int64_t G);   /* strips of the streaming forward's partials */
 // vae_nbzinb_bwd_overwrite / vae_nbzinb_bwd_u8(overwrite = 1) that also stores the per-workgroup maxima of |dlogits|
 // l_dtype: storage of the logits AND of their gradients (VAE_L_F32 | VAE_L_BF16; leading dimensions in elements)
 enum { VAE_L_F32 = 0, VAE_L_BF16 = 1 };
@@ -124,7 +136,7 @@ int vae_nbzinb_bwd_ex(int x_dtype, int l_dtype, int zinb, const void* logit_scal
                       const float* rowsum, const float* S, const float* g_ll, float g_scalar, int64_t B, int64_t G,
                       void* dlogit_scale, int64_t ld_ds, void* dlogit_dropout, int64_t ld_dp, float* dlibrary, float* dpx_r,
                       float* dbias_scale, float* dbias_dropout, float* workspace, int64_t workspace_bytes, float* absmax,
-                      VaeDeferredColreduce* defer, void* stream);
+                      VaeDeferredColreduce* defer, void* stream, const VaeElboFromParts* elbo = nullptr);
 
 // vae_nbzinb_fwd_ws (streaming forward) for the step: have_stats != 0 skips the statistics launch (rowmax / rowsum came
 // from the decoder-head GEMM); ll == S == null leaves the per-strip partials ([*strips_out][2][B]) in the workspace for

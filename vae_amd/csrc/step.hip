@@ -436,7 +436,7 @@ extern "C" int vae_elbo_step_forward(const vae_step_config* cfg, const vae_step_
     TRY(vae_nbzinb_fwd_finish(ws + lo.fwd_part, strips, B, ws + lo.ll, ws + lo.S, stream));
     TRY(vae_elbo_reduce(ws + lo.ll, ws + lo.kl_z, ws + lo.kl_l, B, c.kl_weight, c.gene_loss_coeff, ws + lo.scalars, ws + lo.recon,
                         stream));
-  } else
+  } else if (!c.defer_elbo_reduce)   // (deferred: the backward's first launch reduces the partials, vae_step_config)
     TRY(vae_elbo_reduce_parts(ws + lo.fwd_part, strips, ws + lo.ll, ws + lo.S, ws + lo.kl_z, ws + lo.kl_l, B, c.kl_weight,
                               c.gene_loss_coeff, ws + lo.scalars, ws + lo.recon, stream));
   return VAE_OK;
@@ -493,10 +493,14 @@ extern "C" int vae_elbo_step_backward_slabs(const vae_step_config* cfg, const va
   // its column sums (d px_r, head-bias gradients) stay as per-chunk slabs; on the fused-middle path the last launch of
   // the backward reduces them (one launch less), else a reduce launch follows at once
   VaeDeferredColreduce cr{};
+  // the forward of a defer_elbo_reduce step left its per-strip partials un-reduced (B <= 1024): this launch reduces them
+  const VaeElboFromParts ef{ws + lo.fwd_part, vae_nbzinb_fwd_strips(G), ws + lo.ll, ws + lo.S, ws + lo.recon, ws + lo.scalars,
+                            ws + lo.kl_z, ws + lo.kl_l, c.kl_weight, c.gene_loss_coeff};
   TRY(vae_nbzinb_bwd_ex(c.x_dtype, k.ldt(), c.zinb, logits, NH, lp, NH, xv, ldx, ws + lo.library, ws + lo.table, ws + lo.rowmax,
                         ws + lo.rowsum, ws + lo.S, nullptr, g_ll, B, G, logits, NH, lp, NH, ws + lo.dlibrary, g->px_r, g->heads_b,
                         c.zinb ? g->heads_b + G : nullptr, ws + lo.bwd_slabs, vae_nbzinb_bwd_workspace_bytes(B, G),
-                        k.am(AM_DLOGITS), vae_mid_supported(c) ? &cr : nullptr, stream));
+                        k.am(AM_DLOGITS), vae_mid_supported(c) ? &cr : nullptr, stream,
+                        c.defer_elbo_reduce && B <= 1024 ? &ef : nullptr));
   const float* px = ws + lo.dec_h[c.n_layers - 1];
   // dW = dlogits^T px.  In VAE_FP32_F16X2 this ONE product keeps the exact three-bf16-term split: the magnitude of a gene's
   // column of dlogits follows the gene's softmax mass, which spans > 2^20 across genes, and ONE power-of-two scale for the

@@ -360,6 +360,8 @@ class ElboStep:
             rng_step = self.rng_step
             self.rng_step += int(train and (self.dropout_rate > 0 or self.input_dropout_rate > 0))
         cfg.rng_step = int(rng_step) & 0xFFFFFFFF
+        # a training step: the ELBO reduction (recon, the scalars) rides in the backward's first launch (vae_step_config)
+        cfg.defer_elbo_reduce = int(bool(backward))
         stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         ldx = x.stride(0) if B > 1 else G
         rc = self.lib.vae_elbo_step_forward(C.byref(cfg), C.byref(self.params), x.data_ptr(), ldx, eps_z.data_ptr(),
@@ -379,7 +381,6 @@ class ElboStep:
                 raise ValueError("ElboStep: give cell_heads or cell_head_fn, not both")
             heads, t_heads, m_heads = cell_heads
             out["cell_loss"] = heads.run(v["z"], t_heads, m_heads, loss_scale, v["dz_extra"] if backward else None)
-            out["loss"] = s[4] + out["cell_loss"]
             use_extra = int(backward)
         elif cell_head_fn is not None:
             z_leaf = v["z"].detach().clone().requires_grad_(True)
@@ -391,13 +392,14 @@ class ElboStep:
                 v["dz_extra"].copy_(z_leaf.grad)
                 use_extra = 1
             out["cell_loss"] = cell_loss.detach()
-            out["loss"] = s[4] + out["cell_loss"]
         else:
             if self._zero is None:
                 self._zero = torch.zeros((), device=x.device)
             out["cell_loss"] = self._zero
             out["loss"] = s[4]
         if not backward:
+            if "loss" not in out:
+                out["loss"] = s[4] + out["cell_loss"]
             self._last_fwd = (B, cfg, ws, nbytes)
             return out
         self._last_fwd = None   # the backward overwrites the logits in place
@@ -430,6 +432,8 @@ class ElboStep:
                 use_extra, ws.data_ptr(), nbytes, C.c_void_p(ev_heads.cuda_event) if ev_heads is not None else None,
                 C.c_void_p(ev_small.cuda_event) if ev_small is not None else None, stream)
         _lib.check(rc, "elbo_step_backward")
+        if "loss" not in out:   # (after the backward's first launch: that is where a training step's scalars are written)
+            out["loss"] = s[4] + out["cell_loss"]
         if reducer is not None:
             reducer.bucket_ready("dec_heads", after_event=ev_heads)
             reducer.bucket_ready("small", after_event=ev_small)
