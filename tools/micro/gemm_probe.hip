@@ -36,9 +36,10 @@ int main(int argc, char** argv) {
   g.k_per_split = K; g.split = 1; g.vecA = g.vecB = 1; g.vecC = 1; g.group_m = getenv("GROUP") ? atoi(getenv("GROUP")) : 0; g.tiles_m = (M + 127) / 128; g.tiles_n = (N + PROBE_BN - 1) / PROBE_BN;
   if (lay == 1) { /* NN dgrad: M=512, N=256, K=40000 (A (M,K), B (K,N)) split 8 */
     g.lda = 40000; g.ldb = 256; g.ldc = 256; g.M = 512; g.N = 256; g.K = 40000;
-    g.tiles_m = 4; g.tiles_n = 2; g.split = 50; g.k_per_split = 800;
+    g.tiles_m = 4; g.tiles_n = 2; g.split = getenv("SPLIT") ? atoi(getenv("SPLIT")) : 63; g.k_per_split = ((1250 + g.split - 1) / g.split) * 32;
+    g.split = (40000 + g.k_per_split - 1) / g.k_per_split;
     hipFree(A); hipFree(C); hipMalloc(&A, (size_t)512 * 40000 * 4); hipMemset(A, 0, (size_t)512 * 40000 * 4);
-    hipMalloc(&C, (size_t)50 * 512 * 256 * 4); g.A = A; g.C = C;
+    hipMalloc(&C, (size_t)g.split * 512 * 256 * 4); g.A = A; g.C = C;
   }
   const int grid = g.tiles_m * g.tiles_n * g.split;
   if (lay == 0) run<NT>(g, grid);

@@ -835,6 +835,25 @@ __device__ __forceinline__ void x3_epilogue(const GemmArgs& g, f32x16 (&acc)[BM 
   }
 }
 
+// Two elements -> their packed f16 hi terms and (WITH_LO) packed f16 lo terms: hi = rn16(a s), lo = rn16(a s - hi).  s is a
+// power of two and a s - hi is exact in fp32, so the mixed-precision FMA (fp32 arithmetic, f16 result in one half of the
+// destination, the f16 hi term read straight from its half) gives the bits of the plain C expression -- in 4 instructions
+// per pair where the compiler spends 7-8 (it builds the packed hi through separate multiplies and a pack conversion).
+#ifndef VAE_X3_MIXCVT
+#define VAE_X3_MIXCVT 1
+#endif
+template <typename WITH_LO>
+__device__ __forceinline__ void split_pair_f16(float a0, float a1, float s0, float s1, uint32_t& hi, uint32_t& lo, WITH_LO) {
+  asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(hi) : "v"(a0), "v"(s0));
+  asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(hi) : "v"(a1), "v"(s1));
+  if constexpr (WITH_LO::value) {
+    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(lo) : "v"(a0), "v"(s0), "v"(hi));
+    asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(lo) : "v"(a1), "v"(s1), "v"(hi));
+  } else {
+    lo = 0u;
+  }
+}
+
 // IO (NP == 1 only): storage type of the operands / the output in HBM.  bit 0: A holds bf16, bit 1: B holds bf16 (staged
 // by 8-byte loads straight into the operand plane -- no conversion, half the bytes), bit 2: C is written as bf16 (rounded
 // to nearest even; the softmax statistics are then taken from the ROUNDED values, the ones the consumer will read).
@@ -850,6 +869,12 @@ __device__ __forceinline__ void x3_epilogue(const GemmArgs& g, f32x16 (&acc)[BM 
 #endif
 #ifndef VAE_X3_SCHEDB
 #define VAE_X3_SCHEDB 0
+#endif
+#ifndef VAE_X3_RELOAD
+#define VAE_X3_RELOAD 1
+#endif
+#ifndef VAE_X3_SETS
+#define VAE_X3_SETS 1
 #endif
 template <int LAYOUT, int BM, int BN, int WAVES_M, int NP, int IO = 0, bool ROWSC = false, int XONE = 0>
 __global__ __launch_bounds__(256, ((VAE_X3_PIPE && NP <= 2 && BM == 128 && BN == 128) || ROWSC || XONE != 0 || BN > 160 ? 2 : (NP <= 2 ? 3 : 2))) void gemm_x3_kernel(GemmArgs g) {
@@ -951,8 +976,11 @@ __global__ __launch_bounds__(256, ((VAE_X3_PIPE && NP <= 2 && BM == 128 && BN ==
   }
   const int64_t step_a = (A_KC ? 32 : 32 * g.lda) * (int64_t)sizeof(TA);   // bytes per K step
   const int64_t step_b = (B_KC ? 32 : 32 * g.ldb) * (int64_t)sizeof(TB);
-  RA ra[NA];   // staging registers
-  RB rb[NB];
+  constexpr int NSET = (VAE_X3_PIPE && NP <= 2 && BM == 128 && BN == 128 && VAE_X3_RELOAD) ? VAE_X3_SETS : 1;
+  RA ra_[NSET][NA];   // staging registers (pipelined loop: NSET sets, K steps of equal index mod NSET share one)
+  RB rb_[NSET][NB];
+  RA (&ra)[NA] = ra_[0];
+  RB (&rb)[NB] = rb_[0];
   auto load_to = [&](RA* ra, RB* rb) {
 #pragma unroll
     for (int i = 0; i < NA; ++i) ra[i] = *reinterpret_cast<const RA*>(bA + oa[i]);
@@ -1064,6 +1092,15 @@ __global__ __launch_bounds__(256, ((VAE_X3_PIPE && NP <= 2 && BM == 128 && BN ==
     } else {
     const float4 v = vin;
     const float f[4] = {v.x, v.y, v.z, v.w};
+    if (NP == 2 && VAE_X3_MIXCVT) {   // the same two terms, by hand: 2 instructions per element instead of the compiler's ~ 4
+      const float sc[4] = {sc4.x, sc4.y, sc4.z, sc4.w};
+      uint2 h4, l4;
+      split_pair_f16(f[0], f[1], sc[0], sc[1], h4.x, l4.x, with_lo);
+      split_pair_f16(f[2], f[3], sc[2], sc[3], h4.y, l4.y, with_lo);
+      *reinterpret_cast<uint2*>(base + off) = h4;
+      if constexpr (decltype(with_lo)::value) *reinterpret_cast<uint2*>(base + plane + off) = l4;
+      return;
+    }
     if (NP == 2) {  // two f16 terms of the scaled value: hi = rn(a s), lo = rn(a s - hi): 22 significant bits
       const float sc[4] = {sc4.x, sc4.y, sc4.z, sc4.w};
       f16x4 h4, l4;
@@ -1163,6 +1200,9 @@ __global__ __launch_bounds__(256, ((VAE_X3_PIPE && NP <= 2 && BM == 128 && BN ==
             acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ti][0], b[0], c, 0, 0, 0);
             continue;
           }
+#if defined(VAE_ABL) && (VAE_ABL & 4)
+          if (NP == 2) continue;
+#endif
           if (NP == 2) {  // f16 hi / lo: lo*hi, hi*lo, hi*hi (the dropped lo*lo is < 2^-22 of the product)
             const f16x8 ah = __builtin_bit_cast(f16x8, a[ti][0]), al = __builtin_bit_cast(f16x8, a[ti][NP > 1 ? 1 : 0]);
             const f16x8 bh = __builtin_bit_cast(f16x8, b[0]), bl = __builtin_bit_cast(f16x8, b[NP > 1 ? 1 : 0]);
@@ -1200,8 +1240,28 @@ __global__ __launch_bounds__(256, ((VAE_X3_PIPE && NP <= 2 && BM == 128 && BN ==
     --left;
   };
   (void)fetch_full;
+  // PIPE: a staging register is loaded again as soon as its contents are converted (step i converts the registers of
+  // step i + 1 and requests step i + 2 into them): a whole K step between request and use at no cost in registers
+  auto advance = [&]() {                                 // to the next full step; stays on the last one past the end
+    --left;
+    bA += left > 0 ? step_a : 0;
+    bB += left > 0 ? step_b : 0;
+  };
+  auto reload_one = [&](int pidx, auto setc) {
+    constexpr int SET = decltype(setc)::value;
+    if (pidx < NA) ra_[SET][pidx] = *reinterpret_cast<const RA*>(bA + oa[pidx]);
+    else rb_[SET][pidx - NA] = *reinterpret_cast<const RB*>(bB + ob[pidx - NA]);
+  };
+  (void)advance; (void)reload_one;
   if constexpr (PIPE) {
-    if (nfull > 0) fetch_full();
+    if (nfull > 0) {
+      load_to(ra, rb);
+      if (VAE_X3_RELOAD) advance(); else { bA += left > 1 ? step_a : 0; bB += left > 1 ? step_b : 0; --left; }
+      if constexpr (NSET == 2) {   // the second set: step 1
+        load_to(ra_[NSET - 1], rb_[NSET - 1]);
+        advance();
+      }
+    }
   } else {
     if (nfull > 0) fetch();
     else if (tail) fetch_tail(tail);
@@ -1218,31 +1278,47 @@ __global__ __launch_bounds__(256, ((VAE_X3_PIPE && NP <= 2 && BM == 128 && BN ==
 #define VAE_X3_G0 (NGRP / 2)
 #endif
       constexpr int NGRP = 2 * TNN, G0 = VAE_X3_G0, NPUT = NA + NB;
-      auto put_one = [&](int pidx, __bf16* base) {
-        if (pidx < NA) put(base, PLA, wa[pidx], ra[pidx], scale_a4(pidx), std::bool_constant<ONE != 1>{});
-        else put(base + NP * PLA, PLB, wb[pidx - NA], rb[pidx - NA], make_float4(scB, scB, scB, scB), std::bool_constant<ONE != 2>{});
+      auto put_one = [&](int pidx, __bf16* base, auto setc) {
+        constexpr int SET = decltype(setc)::value;
+        if (pidx < NA) put(base, PLA, wa[pidx], ra_[SET][pidx], scale_a4(pidx), std::bool_constant<ONE != 1>{});
+        else put(base + NP * PLA, PLB, wb[pidx - NA], rb_[SET][pidx - NA], make_float4(scB, scB, scB, scB), std::bool_constant<ONE != 2>{});
       };
-      auto step = [&](int cur) {
+      auto step = [&](auto curc) {
+        constexpr int cur = decltype(curc)::value;
+        using SetC = std::integral_constant<int, NSET == 2 ? (cur ^ 1) : 0>;   // the registers of step i + 1
         GSTAMP();
-        fetch_full();
+        if (!VAE_X3_RELOAD) fetch_full();
         __bf16* nxt = smem + (cur ^ 1) * STG;
         multiply_from(one, smem + cur * STG, smem + cur * STG + NP * PLA, [&](int grp) {
 #pragma unroll
           for (int pidx = 0; pidx < NPUT; ++pidx)
-            if (G0 + pidx * (NGRP - G0) / NPUT == grp) put_one(pidx, nxt);
+            if (G0 + pidx * (NGRP - G0) / NPUT == grp) {
+#ifdef VAE_ABL   // ablations for tools/micro/gemm_probe.hip: 1 = no conversion / LDS writes, 2 = no global loads, 4 = no multiply
+              if (!(VAE_ABL & 1)) put_one(pidx, nxt, SetC{});
+              if (VAE_X3_RELOAD && !(VAE_ABL & 2)) reload_one(pidx, SetC{});
+#else
+              put_one(pidx, nxt, SetC{});
+              if (VAE_X3_RELOAD) reload_one(pidx, SetC{});
+#endif
+            }
           if (VAE_X3_SCHEDB) __builtin_amdgcn_sched_barrier(0);   // keep a group's conversions in its own slot
         });
+        if (VAE_X3_RELOAD) advance();
         GSTAMP();
         __syncthreads();   // stage cur ^ 1 published; every wave is done reading stage cur
         GSTAMP();
       };
       if (nfull > 0) {
 #pragma unroll
-        for (int pidx = 0; pidx < NPUT; ++pidx) put_one(pidx, smem);
+        for (int pidx = 0; pidx < NPUT; ++pidx) {
+          put_one(pidx, smem, std::integral_constant<int, 0>{});
+          if (VAE_X3_RELOAD) reload_one(pidx, std::integral_constant<int, 0>{});
+        }
+        if (VAE_X3_RELOAD) advance();
         __syncthreads();
         for (int i = 0; i < nfull; i += 2) {
-          step(0);
-          if (i + 1 < nfull) step(1);
+          step(std::integral_constant<int, 0>{});
+          if (i + 1 < nfull) step(std::integral_constant<int, 1>{});
         }
         if (tail) {   // the base pointers stopped at the last full step: move on to the partial one
           bA += step_a;
