@@ -423,6 +423,13 @@ typedef struct {
  * This is the reference's autocast(bfloat16) storage (config.py:87); the parity tests pick the oracle definition with
  * it (oracle/vae_oracle.py, logits_bf16).  Environment VAE_BF16_F32_STORAGE=1 switches it off (A/B measurements). */
 int vae_elbo_step_bf16_activations(const vae_step_config* cfg);
+/* How a step of this configuration feeds the counts to the two first-layer encoder products (modules.py:264,267), given
+ * 16-byte aligned rows of float counts: 0 = a normalised x / mean - 1 matrix in the workspace (vae_normalize_rows);
+ * 1 = the raw counts as the GEMM operand behind one vae_row_stats launch; 2 = the raw counts with NO launch ahead -- the
+ * forward product takes them as exact in one unscaled f16 term (integer counts below 2048 are), gathers the cells' sums,
+ * maxima and exactness flags while they pass, and a gated launch behind it finishes the means and sum_g W and repeats the
+ * product in the scaled two-term form only when a flag came up.  (Environment VAE_NO_XOPT / VAE_NO_XDIRECT: A/B knobs.) */
+int vae_elbo_step_counts_path(const vae_step_config* cfg);
 
 /* named slices of the workspace that a caller may read after the forward (offsets in floats)      */
 enum { VAE_WS_QZ_HEADS = 0, /* (B, L+1): [:, :L] = qz_m                                            */

@@ -6,6 +6,8 @@ Tolerances (BASELINE.json north_star, fp32 mode): per-cell ELBO terms 1e-5 relat
 parameter gradients 1e-4 relative (to the largest entry of each gradient tensor)."""
 import copy
 
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -300,6 +302,57 @@ def test_midsize_against_oracle(likelihood, precision):
         if o_grads[k] is None:
             continue
         assert rel_err(v.cpu().numpy(), o_grads[k].numpy()) < TOL_GRAD, k
+
+
+@pytest.mark.parametrize("counts", ["integer", "fractional", "large", "tiny", "one_bad_cell"])
+def test_optimistic_count_product_and_its_repeat(counts):
+    """G % 32 == 0, a two-f16-term step on the fused middle: no launch reads the counts ahead of the first encoder product
+    (step.hip, xoptimistic).  The product takes them as exact in one unscaled f16 term -- true of integer counts below 2048
+    -- and gathers the cells' sums, maxima and exactness flags on the way; the gated launch behind it finishes the means and
+    sum_g W and REPEATS the product in the scaled two-term form when a flag came up: fractional counts (mixup,
+    data.py:457-477), counts beyond f16's exact integers / range, a batch of tiny values, or a single offending cell in a
+    row tile of its own.  Every case against the fp64 oracle at the step tests' tolerances."""
+    from oracle import vae_oracle as O
+    from vae_amd.arena import ParamArena
+    from vae_amd.step import ElboStep
+    B, G, H, Hd, Hl, L = 160, 4096, 128, 128, 128, 10
+    p = O.init_params(G, H, Hd, Hl, L, 1, seed=25)
+    x = O.synthetic_counts(B, G, seed=25, zero_inflate=0.3)
+    if counts == "fractional":
+        x = 0.75 * x + 0.25 * x.roll(1, 0)
+    elif counts == "large":
+        x[3, 17], x[100, 4000], x[159, 5] = 70000.0, 3001.0, 2049.0
+    elif counts == "tiny":
+        x = x * 2.0 ** -12
+    elif counts == "one_bad_cell":
+        x[150, 1234] = 0.5     # the second row tile (cells 128..159), one slab
+    g = torch.Generator().manual_seed(26)
+    eps_z, eps_l = torch.randn(B, L, generator=g), torch.randn(B, 1, generator=g)
+    lm, lv = O.library_prior(x)
+    o_out, o_grads = O.training_step_with_grads({k: v.double() for k, v in p.items()}, x.double(), eps_z.double(),
+                                                eps_l.double(), n_layers=1, likelihood="zinb", l_mean=lm, l_var=lv)
+    arena = ParamArena(p, 1, "zinb", "cuda")
+    step = ElboStep(arena, l_mean=lm, l_var=lv, precision=3)
+    assert step.counts_path(B) == 2 or os.environ.get("VAE_NO_XOPT") or os.environ.get("VAE_NO_XDIRECT")
+    xd, ezd, eld = x.cuda(), eps_z.cuda(), eps_l.cuda()
+    for rep in range(2):   # the second call finds the first one's statistics in the workspace
+        out = step.run(xd, ezd, eld)   # (the step overwrites or clears every gradient itself)
+        rec = out["recon"].cpu().double().numpy()
+        assert np.max(np.abs(rec - o_out["recon"].numpy()) / np.abs(o_out["recon"].numpy())) < TOL_CELL
+        for k in ("qz_m", "library", "kl_z", "kl_l"):
+            ref = o_out[k].double().numpy()
+            assert rel_err(out[k].cpu().numpy().reshape(ref.shape), ref) < TOL_CELL, k
+        for k, v in arena.grads().items():
+            if o_grads[k] is None:
+                continue
+            assert rel_err(v.cpu().numpy(), o_grads[k].numpy()) < TOL_GRAD, (k, rep)
+    # a clean batch after an offending one: stale flags must not survive
+    x2 = O.synthetic_counts(B, G, seed=27, zero_inflate=0.3)
+    o2, _ = O.training_step_with_grads({k: v.double() for k, v in p.items()}, x2.double(), eps_z.double(), eps_l.double(),
+                                       n_layers=1, likelihood="zinb", l_mean=lm, l_var=lv)
+    out2 = step.run(x2.cuda(), ezd, eld)
+    assert rel_err(out2["recon"].cpu().numpy(), o2["recon"].numpy()) < TOL_CELL
+    assert rel_err(out2["qz_m"].cpu().numpy(), o2["qz_m"].numpy()) < TOL_CELL
 
 
 @pytest.mark.parametrize("widths", [(256, 128, 256, 30), (192, 64, 320, 17), (512, 256, 576, 32), (128, 128, 128, 10)],

@@ -27,6 +27,7 @@ SIGNATURES = {
     "vae_gemm_noalloc_init": (_i32, []),
     "vae_gemm_noalloc": (_i32, [_i32, _i32, _i64, _i64, _i64, _ptr, _i64, _ptr, _i64, _ptr, _i64, _ptr, _ptr, _i32, _ptr]),
     "vae_elbo_step_bf16_activations": (_i32, [_ptr]),
+    "vae_elbo_step_counts_path": (_i32, [_ptr]),
     "vae_gemm_bf16_storage_ok": (_i32, [_i32, _i32, _i64, _i64, _i64]),
     "vae_gemm_bf16_storage": (_i32, [_i32, _i32, _i64, _i64, _i64, _ptr, _i64, _ptr, _i64, _ptr, _i64, _ptr, _ptr, _i64, _ptr]),
     "vae_gemm_slabs_workspace_bytes": (_i64, [_i64, _i64, _i64]),

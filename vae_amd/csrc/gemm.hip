@@ -79,6 +79,23 @@ struct GemmArgs {
   const float* xone_flags;
   int n_xone;
   const float* row_sub;
+  // XONE = 3, the OPTIMISTIC count operand (NT, pipelined 128 x 128 tiles): nobody has read the counts yet.  The kernel
+  // takes every count as exact in one UNSCALED f16 term and gathers, from the registers it stages anyway, what a statistics
+  // pass would have: per-slab row sums xs_sum[slab][M] (the column tiles of a row tile share its staging chunks), and per
+  // gathering workgroup an entry of xs_max / xs_flag (maximum of |x|; 1 when some count is NOT exact that way -- then the
+  // product is void and the gated launch below repeats it).  Entries past the writers' up to xs_n are zeroed, so the
+  // arrays read like the ones vae_row_stats fills.
+  float* xs_sum;
+  float* xs_max;
+  float* xs_flag;
+  int xs_n;
+  float* ws_sum;   // likewise the per-slab row sums of B, ws_sum[slab][N] (the row tiles share them)
+  // XONE = 1 with gate != 0, the launch behind the optimistic one: its first workgroups finish the row means
+  // (mean_out[m] = sum over slabs of xs_sum / K) and sum the rows of B (wsum_out[n], nullable); then every workgroup
+  // leaves unless some flag is set -- in which case this is the plain count-operand product, scaled by the maxima.
+  int gate;
+  float* mean_out;
+  float* wsum_out;
   int stagger;               // experiment (VAE_GEMM_STAGGER): start-phase offset of co-resident workgroups, units of 1024 cycles
 };
 
@@ -842,6 +859,24 @@ __device__ __forceinline__ void x3_epilogue(const GemmArgs& g, f32x16 (&acc)[BM 
 #ifndef VAE_X3_MIXCVT
 #define VAE_X3_MIXCVT 1
 #endif
+// p[0] + p[stride] + ... (n terms, in order): sixteen loads in flight instead of a chain of round trips
+__device__ __forceinline__ float slab_sum(const float* __restrict__ p, int n, int64_t stride) {
+  float v = 0.f;
+  int i = 0;
+  for (; i + 16 <= n; i += 16) {
+    float q[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) q[u] = p[(i + u) * stride];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) v += q[u];
+  }
+  for (; i + 4 <= n; i += 4) {
+    const float a = p[i * stride], b = p[(i + 1) * stride], c = p[(i + 2) * stride], d = p[(i + 3) * stride];
+    v = (((v + a) + b) + c) + d;
+  }
+  for (; i < n; ++i) v += p[i * stride];
+  return v;
+}
 template <typename WITH_LO>
 __device__ __forceinline__ void split_pair_f16(float a0, float a1, float s0, float s1, uint32_t& hi, uint32_t& lo, WITH_LO) {
   asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(hi) : "v"(a0), "v"(s0));
@@ -880,8 +915,10 @@ template <int LAYOUT, int BM, int BN, int WAVES_M, int NP, int IO = 0, bool ROWS
 __global__ __launch_bounds__(256, ((VAE_X3_PIPE && NP <= 2 && BM == 128 && BN == 128) || ROWSC || XONE != 0 || BN > 160 ? 2 : (NP <= 2 ? 3 : 2))) void gemm_x3_kernel(GemmArgs g) {
   static_assert(IO == 0 || NP == 1, "bf16 storage goes with the one-plane bf16 product");
   static_assert(!ROWSC || (LAYOUT == TN && NP == 2), "per-row scales: the two-f16-term wgrad");
-  static_assert(XONE == 0 || (NP == 2 && !ROWSC && ((XONE == 1 && LAYOUT == NT) || (XONE == 2 && LAYOUT == TN))),
+  static_assert(XONE == 0 || (NP == 2 && !ROWSC && (((XONE == 1 || XONE == 3) && LAYOUT == NT) || (XONE == 2 && LAYOUT == TN))),
                 "one-term count operand: A of the two-f16-term NT product or B of the TN product");
+  static_assert(XONE != 3 || (VAE_X3_PIPE && VAE_X3_RELOAD && BM == 128 && BN == 128), "optimistic counts: the pipelined 128 x 128 loop");
+  constexpr bool XOPT = XONE == 3;
   __shared__ __attribute__((aligned(16))) float row_sc[ROWSC ? BM : 4];
   __shared__ float row_inv[ROWSC ? BM : 4];
   constexpr bool PIPE = VAE_X3_PIPE && NP <= 2 && BM == 128 && BN == 128;   // the 160-wide tiles do not fit two waves per SIMD
@@ -1065,8 +1102,8 @@ __global__ __launch_bounds__(256, ((VAE_X3_PIPE && NP <= 2 && BM == 128 && BN ==
       // of LDS stage 1, which nothing writes before the barrier that follows the first conversion
       __shared__ float red_own[PIPE ? 1 : 12];
       float* red_s = PIPE ? reinterpret_cast<float*>(smem + STG) : red_own;
-      float ma = partial_max(g.sa, g.na), mb = partial_max(g.sb, g.nb);
-      float mf = XONE != 0 ? partial_max(g.xone_flags, g.n_xone) : 0.f;
+      float ma = XOPT ? 0.f : partial_max(g.sa, g.na), mb = partial_max(g.sb, g.nb);
+      float mf = (XONE != 0 && !XOPT) ? partial_max(g.xone_flags, g.n_xone) : 0.f;
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) {
         ma = fmaxf(ma, __shfl_xor(ma, o, 64));
@@ -1079,6 +1116,7 @@ __global__ __launch_bounds__(256, ((VAE_X3_PIPE && NP <= 2 && BM == 128 && BN ==
       scB = vae_scale_from_absmax(fmaxf(fmaxf(red_s[4], red_s[5]), fmaxf(red_s[6], red_s[7])));
       if (XONE != 0)
         x_one = __builtin_amdgcn_readfirstlane(fmaxf(fmaxf(red_s[8], red_s[9]), fmaxf(red_s[10], red_s[11])) > 0.f ? 0 : 1);
+      if (XOPT) { scA = 1.f; x_one = 1; }   // counts as they are; whether that was right is found out while they pass
     } else {
       if (g.sa) scA = *g.sa;
       if (g.sb) scB = *g.sb;
@@ -1253,6 +1291,62 @@ __global__ __launch_bounds__(256, ((VAE_X3_PIPE && NP <= 2 && BM == 128 && BN ==
     else rb_[SET][pidx - NA] = *reinterpret_cast<const RB*>(bB + ob[pidx - NA]);
   };
   (void)advance; (void)reload_one;
+  // XOPT, column tile 0: what this thread sees of the counts -- sums of its NA rows, maximum, OR of the bit patterns
+  float xs[XOPT ? NA : 1];
+  float xam = 0.f;
+  uint32_t xbits = 0u;
+#pragma unroll
+  for (int i = 0; i < (XOPT ? NA : 1); ++i) xs[i] = 0.f;
+  // the column tiles share the extra work: staging chunk i (rows (tid >> 3) + 32 i of the row tile) belongs to column tile
+  // i mod min(tiles_n, NA)
+  const int xown = min(tiles_n, NA);
+  auto xmine = [&](int i) { return XOPT && tn == i % xown; };
+  const bool xstat = XOPT && tn < xown;
+  // ... and the row sums of B (sum_g W of the encoder's first layer) are shared the same way among the row tiles
+  const int wown = min(tiles_m, NB);
+  auto wmine = [&](int j) { return XOPT && tm == j % wown; };
+  float wsr[XOPT ? NB : 1];
+#pragma unroll
+  for (int j = 0; j < (XOPT ? NB : 1); ++j) wsr[j] = 0.f;
+  auto ws_take = [&](int j, const RB& r) {
+    if constexpr (XOPT && std::is_same_v<RB, float4>) wsr[j] += (r.x + r.y) + (r.z + r.w);
+  };
+  (void)ws_take; (void)wmine;
+  auto xs_take = [&](int pidx, const RA& r) {
+    if constexpr (XOPT && std::is_same_v<RA, float4>) {
+      xs[pidx] += (r.x + r.y) + (r.z + r.w);
+      xam = fmaxf(fmaxf(xam, fmaxf(fabsf(r.x), fabsf(r.y))), fmaxf(fabsf(r.z), fabsf(r.w)));
+      xbits |= (__float_as_uint(r.x) | __float_as_uint(r.y)) | (__float_as_uint(r.z) | __float_as_uint(r.w));
+    }
+  };
+  (void)xs_take; (void)xstat;
+  if constexpr (XONE == 1) {
+    if (g.gate) {   // the launch behind an optimistic one (GemmArgs::gate)
+      float* red_g = reinterpret_cast<float*>(smem);   // nothing is staged yet
+      // the first few workgroups finish the means, the next few the row sums of B
+      const int n_mean = (g.M + 255) / 256;
+      if (id < n_mean) {
+        const int m = id * 256 + tid;
+        if (m < g.M) {
+          g.mean_out[m] = slab_sum(g.xs_sum + m, g.split, g.M) / (float)g.K;
+        }
+      } else if (id < n_mean + (g.N + 255) / 256) {
+        const int n = (id - n_mean) * 256 + tid;
+        if (n < g.N) {
+          g.wsum_out[n] = slab_sum(g.ws_sum + n, g.split, g.N);
+        }
+      }
+      float mf = partial_max(g.xone_flags, g.n_xone);
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) mf = fmaxf(mf, __shfl_xor(mf, o, 64));
+      __syncthreads();
+      if (lane == 0) red_g[4 + wave] = mf;
+      __syncthreads();
+      const float any = fmaxf(fmaxf(red_g[4], red_g[5]), fmaxf(red_g[6], red_g[7]));
+      __syncthreads();   // (the scale reduction borrows this LDS next)
+      if (!(any > 0.f)) return;   // the optimistic product stands
+    }
+  }
   if constexpr (PIPE) {
     if (nfull > 0) {
       load_to(ra, rb);
@@ -1266,7 +1360,11 @@ __global__ __launch_bounds__(256, ((VAE_X3_PIPE && NP <= 2 && BM == 128 && BN ==
     if (nfull > 0) fetch();
     else if (tail) fetch_tail(tail);
   }
+#if defined(VAE_ABL) && (VAE_ABL & 16)
+  (void)scales;
+#else
   scales();
+#endif
   auto run = [&](auto one) {
     constexpr int ONE = decltype(one)::value;
     if constexpr (PIPE) {
@@ -1283,12 +1381,22 @@ __global__ __launch_bounds__(256, ((VAE_X3_PIPE && NP <= 2 && BM == 128 && BN ==
         if (pidx < NA) put(base, PLA, wa[pidx], ra_[SET][pidx], scale_a4(pidx), std::bool_constant<ONE != 1>{});
         else put(base + NP * PLA, PLB, wb[pidx - NA], rb_[SET][pidx - NA], make_float4(scB, scB, scB, scB), std::bool_constant<ONE != 2>{});
       };
-      auto step = [&](auto curc) {
+      auto step = [&](auto curc, bool more) {   // more: the registers converted in this step hold a step of the K range
         constexpr int cur = decltype(curc)::value;
         using SetC = std::integral_constant<int, NSET == 2 ? (cur ^ 1) : 0>;   // the registers of step i + 1
         GSTAMP();
         if (!VAE_X3_RELOAD) fetch_full();
         __bf16* nxt = smem + (cur ^ 1) * STG;
+        if constexpr (XOPT) {   // ahead of the interleaved section, which stays one basic block (branches only here)
+          if (more) {
+#pragma unroll
+            for (int i = 0; i < NA; ++i)
+              if (xmine(i)) xs_take(i, ra_[SetC::value][i]);
+#pragma unroll
+            for (int j = 0; j < NB; ++j)
+              if (wmine(j)) ws_take(j, rb_[SetC::value][j]);
+          }
+        }
         multiply_from(one, smem + cur * STG, smem + cur * STG + NP * PLA, [&](int grp) {
 #pragma unroll
           for (int pidx = 0; pidx < NPUT; ++pidx)
@@ -1312,13 +1420,15 @@ __global__ __launch_bounds__(256, ((VAE_X3_PIPE && NP <= 2 && BM == 128 && BN ==
 #pragma unroll
         for (int pidx = 0; pidx < NPUT; ++pidx) {
           put_one(pidx, smem, std::integral_constant<int, 0>{});
+          if (XOPT && pidx < NA) { if (xmine(pidx)) xs_take(pidx, ra_[0][pidx < NA ? pidx : 0]); }
+          if (XOPT && pidx >= NA) { if (wmine(pidx - NA)) ws_take(pidx >= NA ? pidx - NA : 0, rb_[0][pidx >= NA ? pidx - NA : 0]); }
           if (VAE_X3_RELOAD) reload_one(pidx, std::integral_constant<int, 0>{});
         }
         if (VAE_X3_RELOAD) advance();
         __syncthreads();
         for (int i = 0; i < nfull; i += 2) {
-          step(std::integral_constant<int, 0>{});
-          if (i + 1 < nfull) step(std::integral_constant<int, 1>{});
+          step(std::integral_constant<int, 0>{}, i + 1 < nfull);
+          if (i + 1 < nfull) step(std::integral_constant<int, 1>{}, i + 2 < nfull);
         }
         if (tail) {   // the base pointers stopped at the last full step: move on to the partial one
           bA += step_a;
@@ -1350,16 +1460,70 @@ __global__ __launch_bounds__(256, ((VAE_X3_PIPE && NP <= 2 && BM == 128 && BN ==
       }
     }
   };
-  if constexpr (XONE != 0) {
+  if constexpr (XOPT) {
+    run(std::integral_constant<int, 1>{});
+  } else if constexpr (XONE != 0) {
     if (x_one) run(std::integral_constant<int, XONE>{});
     else run(std::integral_constant<int, 0>{});
   } else {
     run(std::integral_constant<int, 0>{});
   }
   GSTAMP();
+  if constexpr (XOPT) {
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      if (!wmine(j)) continue;
+      float v = wsr[j];
+      v += __shfl_xor(v, 1, 64);
+      v += __shfl_xor(v, 2, 64);
+      v += __shfl_xor(v, 4, 64);
+      const int row = (tid >> 3) + 32 * j;
+      if ((tid & 7) == 0 && n0 + row < g.N) g.ws_sum[(int64_t)s * g.N + n0 + row] = v;
+    }
+    if (xstat) {   // (uniform per workgroup)
+      const int writers = g.tiles_m * xown * g.split;
+#pragma unroll
+      for (int i = 0; i < NA; ++i) {   // the eight lanes that staged a row's 32 counts per step
+        if (!xmine(i)) continue;
+        float v = xs[i];
+        v += __shfl_xor(v, 1, 64);
+        v += __shfl_xor(v, 2, 64);
+        v += __shfl_xor(v, 4, 64);
+        const int row = (tid >> 3) + 32 * i;
+        if ((tid & 7) == 0 && m0 + row < g.M) g.xs_sum[(int64_t)s * g.M + m0 + row] = v;
+      }
+      float am = xam;
+      uint32_t bits = xbits;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        am = fmaxf(am, __shfl_xor(am, o, 64));
+        bits |= (uint32_t)__shfl_xor((int)bits, o, 64);
+      }
+      float* red_x = reinterpret_cast<float*>(smem);
+      __syncthreads();   // every wave is done with the operand stages
+      if (lane == 0) { red_x[wave] = am; red_x[4 + wave] = __uint_as_float(bits); }
+      __syncthreads();
+      if (tid == 0) {
+        am = fmaxf(fmaxf(red_x[0], red_x[1]), fmaxf(red_x[2], red_x[3]));
+        bits = (__float_as_uint(red_x[4]) | __float_as_uint(red_x[5])) | (__float_as_uint(red_x[6]) | __float_as_uint(red_x[7]));
+        // exact in one unscaled f16 term: at most 11 significant bits, no overflow, and nothing a scale would have had to
+        // lift out of f16's subnormal range (a batch of tiny values keeps the scaled two-term product)
+        const bool bad = (bits & 0x1fffu) != 0u || !(am < 32768.f) || (am > 0.f && am < 1.f);
+        const int w = (tm * xown + tn) * g.split + s;
+        g.xs_max[w] = am;
+        g.xs_flag[w] = bad ? 1.f : 0.f;
+        for (int e = writers + w; e < g.xs_n; e += writers) { g.xs_max[e] = 0.f; g.xs_flag[e] = 0.f; }
+      }
+      __syncthreads();   // (the output stage parks its patches in the same LDS)
+    }
+  }
 
+#if defined(VAE_ABL) && (VAE_ABL & 8)   // no output stage (one element keeps the accumulators alive)
+  if (acc[0][0][0] == 12345.f) g.C[0] = acc[TM - 1][TNN - 1][3];
+#else
   x3_epilogue<LAYOUT, BM, BN, WAVES_M, NP, CBF, (NP * (PLA + PLB) * 2 >= 4 * 32 * 40 * 4)>(g, acc, smem, m0, n0, tn, s, scA, scB,
                                                                                             ROWSC ? row_inv : nullptr, rs_pref);
+#endif
   GSTAMP();
 }
 
@@ -1748,11 +1912,14 @@ int gemm_impl(int layout, int precision, int64_t M, int64_t N, int64_t K, const 
   VAE_REQUIRE(!rsc || (f16x2 && layout == TN && dma_ok && n_max_b > 0 && rsc->max0 && rsc->chunks > 0 &&
                        (rsc->split >= M || rsc->max1)),
               "vae_gemm: per-row scales need the two-f16-term wgrad (TN) on the tile pipeline and the maxima of B");
-  VAE_REQUIRE(!xo || (f16x2 && !rsc && layout != NN && dma_ok && n_max_a > 0 && n_max_b > 0 &&
+  const bool xopt = xo && xo->mode == 1;   // optimistic count operand (GemmArgs::xs_*): no maxima of A exist yet
+  VAE_REQUIRE(!xo || (f16x2 && !rsc && layout != NN && dma_ok && (n_max_a > 0 || xopt) && n_max_b > 0 &&
                       (!xo->flags || (xo->n_flags > 0 && vae_aligned16(xo->flags))) &&
                       (!xo->row_sub || (layout == TN && !slabs_out && !accumulate))),
               "vae_gemm: the count-operand form needs a two-f16-term NT / TN product on the tile pipeline with operand maxima");
   if (xo) { g.xone_flags = xo->flags; g.n_xone = xo->n_flags; g.row_sub = xo->row_sub; }
+  g.xs_sum = g.xs_max = g.xs_flag = g.ws_sum = g.mean_out = g.wsum_out = nullptr;
+  g.xs_n = g.gate = 0;
   if (rsc) {
     g.rmax0 = rsc->max0; g.rmax1 = rsc->max1; g.rmax_split = (int)(rsc->split < M ? rsc->split : M); g.rmax_chunks = rsc->chunks;
     g.rmax_stride = rsc->stride;
@@ -1791,6 +1958,14 @@ int gemm_impl(int layout, int precision, int64_t M, int64_t N, int64_t K, const 
                 (long long)((int64_t)split * M * N * 4));
     VAE_REQUIRE(vae_aligned16(workspace), "vae_gemm: workspace must be 16-byte aligned");
     g.C = workspace;
+  }
+  if (xo && xo->mode != 0) {
+    VAE_REQUIRE(layout == NT && slabs_out && bm == 128 && bn == 128 && K % BK == 0 && xo->xs_sum && xo->xs_max && xo->xs_flag && xo->ws_sum &&
+                    tiles_m * (g.tiles_n < 4 ? g.tiles_n : 4) * split <= xo->xs_n && vae_aligned16(xo->xs_max) && vae_aligned16(xo->xs_flag) &&
+                    (xo->mode == 1 || (xo->mean_out && xo->wsum_out && xo->flags == xo->xs_flag && xo->n_flags == xo->xs_n)),
+                "vae_gemm: the optimistic count operand needs the pipelined 128 x 128 slab product (vae_gemm_counts_optimistic_ok)");
+    g.xs_sum = xo->xs_sum; g.xs_max = xo->xs_max; g.xs_flag = xo->xs_flag; g.xs_n = xo->xs_n; g.ws_sum = xo->ws_sum;
+    if (xo->mode == 2) { g.gate = 1; g.mean_out = xo->mean_out; g.wsum_out = xo->wsum_out; }
   }
   g.vecC = (N % 4 == 0) && vae_aligned16(g.C) && (split > 1 || slabs_out || ldc % 4 == 0);
   {  // grouped rasterisation of the row tiles (kernel comment): when both tile counts are large
@@ -1874,6 +2049,8 @@ int gemm_impl(int layout, int precision, int64_t M, int64_t N, int64_t K, const 
       if (layout == NT) VAE_X3_LAUNCH(NT, 1);
       else if (layout == NN) VAE_X3_LAUNCH(NN, 1);
       else VAE_X3_LAUNCH(TN, 1);
+    } else if (xopt) {   // counts taken as exact in one unscaled f16 term, checked on the way (GemmArgs::xs_*)
+      hipLaunchKernelGGL((gemm_x3_kernel<NT, 128, 128, 2, 2, 0, false, 3>), grid1, dim3(256), 0, st, g);
     } else if (xo && xo->flags && layout == NT) {   // two f16 terms, the count operand A on ONE term when every count is exact in it
       // (the TN form -- counts = B, static_assert'ed in the kernel -- is not instantiated: measured on the cfg2 weight
       // gradient it is SLOWER than the plain two-term kernel, 41.8 vs 37.5 us in-step, 38.2 vs 34.9 stand-alone; these
@@ -2006,6 +2183,17 @@ int vae_gemm_f16x2(int layout, int64_t M, int64_t N, int64_t K, const float* A, 
   return gemm_impl(layout, 3, M, N, K, A, lda, B, ldb, slabs_out ? nullptr : C, slabs_out ? N : ldc, slabs_out ? nullptr : bias,
                    nullptr, slabs_out ? 0 : accumulate, workspace, workspace_bytes, stream, slabs_out, max_a, max_b, n_max_a,
                    n_max_b, stats, 0, nullptr, counts);
+}
+// whether the NT count-operand product of this shape (left as slabs) can run optimistically: the pipelined 128 x 128 loop,
+// whole K steps, and room for its per-wave entries in arrays of n_stat floats
+bool vae_gemm_counts_optimistic_ok(int64_t M, int64_t N, int64_t K, int n_stat) {
+  if (!VAE_X3_PIPE || !VAE_X3_RELOAD || K % BK != 0 || !vae_gemm_tile_pipeline_ok(NT, M, N, K)) return false;
+  if (make_plan((int)M, (int)N, (int)K, false).tile != 128) return false;
+  const DmaPlan d = make_dma_plan((int)M, (int)N, (int)K, false);
+  if (d.bm != 128 || d.bn != 128) return false;
+  const int ktiles = (int)((K + BK - 1) / BK), tps = (ktiles + d.split - 1) / d.split, split = (ktiles + tps - 1) / tps;
+  const int64_t tn = (N + 127) / 128;
+  return (int64_t)((M + 127) / 128) * (tn < 4 ? tn : 4) * split <= n_stat;
 }
 // whether fp32 operands with 16-byte aligned rows of this shape run the 128-wide tile pipeline (split / LDS-DMA kernels)
 bool vae_gemm_tile_pipeline_ok(int layout, int64_t M, int64_t N, int64_t K) {

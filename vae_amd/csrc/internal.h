@@ -34,11 +34,27 @@ struct VaeGemmRowStats {
 // three products fall away.  flags: n_flags floats (16-byte aligned) left by the kernel that read the counts
 // (vae_row_mean_ex), any > 0 = some count needs its lo term -> the kernel runs the plain two-term loop instead (decided
 // on the device, once per workgroup); flags == null: always the two-term loop.  row_sub (nullable, TN only): C[m, n] -= row_sub[m].
+// mode 1, the OPTIMISTIC forward product (NT, slabs; vae_gemm_counts_optimistic_ok): no kernel has read the counts. They
+// are taken as exact in one UNSCALED f16 term (true of integer counts below 2048) and checked while they pass: the
+// workgroups leave per-slab row sums in xs_sum[slab][M] (and of B in ws_sum[slab][N]) and per-workgroup entries of xs_max (max |x|) and
+// xs_flag (1 = some count was not exact that way, the product is void), the rest of the xs_n entries zeroed -- the same
+// arrays vae_row_stats fills.  mode 2, the launch that must follow with the same operands and flags = xs_flag: it
+// finishes mean_out[m] = sum_slabs xs_sum / K and wsum_out[n] = sum_slabs ws_sum = sum_k B[n, k], and repeats the product in
+// the scaled form above only if a flag is set (its maxima: xs_max) -- every workgroup decides that for itself.
 struct VaeGemmCounts {
   const float* flags;
   int n_flags;
   const float* row_sub;
+  int mode = 0;
+  float* xs_sum = nullptr;
+  float* xs_max = nullptr;
+  float* xs_flag = nullptr;
+  int xs_n = 0;
+  float* ws_sum = nullptr;   // per-slab row sums of B [slab][N]
+  float* mean_out = nullptr;
+  float* wsum_out = nullptr;
 };
+bool vae_gemm_counts_optimistic_ok(int64_t M, int64_t N, int64_t K, int n_stat);
 int vae_gemm_f16x2(int layout, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* max_a, int n_max_a,
                    const float* B, int64_t ldb, const float* max_b, int n_max_b, float* C, int64_t ldc, const float* bias,
                    int accumulate, float* workspace, int64_t workspace_bytes, void* stream, int* slabs_out,

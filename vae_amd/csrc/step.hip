@@ -31,6 +31,7 @@ struct Layout {
   int64_t stat_m, stat_s, stat_cap;   // per-slot softmax statistics the decoder-head GEMM leaves (internal.h)
   int64_t w_enc16, w_heads16, px16, dpre16;   // bf16 images (bf16_storage): the two gene-sized weight matrices, px, dpre_enc0
   int64_t wsum, xflags, dpre_s;   // count-operand form of the encoder products (Ctx::xd): sum_g W, per-wave flags, dpre / mean
+  int64_t xs_sum, ws_sum;         // ... its optimistic start (xoptimistic()): per-slab row sums of the counts [64][B] and of W [64][HE]
   int64_t fwd_part;       // per-strip partials of ll[b] / S_b of the streaming likelihood pass
   int64_t bwd_slabs;      // column-sum slabs of the epilogue backward (kept until the last launch of the backward)
   int64_t scratch;        // split-K slabs (shared, used by one launch at a time)
@@ -135,6 +136,7 @@ bool make_layout(const vae_step_config& c, Layout* lo) {
   s = maxi(s, vae_gemm_slabs_workspace_bytes(B, Hd, NH));
   s = maxi(s, vae_nbzinb_bwd_workspace_bytes(B, G));
   lo->wsum = take(H + Hl); lo->xflags = take(B * VAE_NORM_WAVES); lo->dpre_s = take(B * (H + Hl));
+  lo->xs_sum = take(64 * B); lo->ws_sum = take(64 * (H + Hl));
   lo->fwd_part = take(vae_nbzinb_fwd_workspace_bytes(B, G) / 4 + 4);
   lo->stat_cap = B * ((G + 31) / 32);            // narrowest slot of the GEMM's row statistics: 32 columns
   lo->stat_m = take(lo->stat_cap); lo->stat_s = take(lo->stat_cap);
@@ -236,6 +238,15 @@ bool xdirect(const vae_step_config& c, const Ctx& k, const void* x, int64_t ldx)
   return vae_gemm_tile_pipeline_ok(VAE_NT, c.B, HE, c.G) && vae_gemm_tile_pipeline_ok(VAE_TN, HE, c.G, c.B);
 }
 
+// ... and nobody reads the counts ahead of the forward product: it takes them as exact in one unscaled f16 term, gathers
+// the cells' sums / maxima / exactness flags on the way, and a gated launch behind it finishes the means and sum_g W and
+// repeats the product in the scaled form only when a flag came up (VaeGemmCounts, internal.h).  One launch that reads
+// the batch (and the first-layer weight) less per step.  A/B knob: VAE_NO_XOPT.
+bool xoptimistic(const vae_step_config& c, const Ctx& k) {
+  static const bool off = getenv("VAE_NO_XOPT") != nullptr;
+  return !off && k.xd && vae_gemm_counts_optimistic_ok(c.B, c.H + c.Hl, c.G, (int)(c.B * VAE_NORM_WAVES));
+}
+
 int check_common(const vae_step_config* cfg, const void* a, const void* b, const void* x, int64_t ldx,
                  const float* eps_z, const float* eps_l, float* ws, int64_t ws_bytes, Layout* lo, const char* who) {
   if (!cfg || !a || !b || !x || !eps_z || !eps_l || !ws) return vae_set_error(VAE_ERR_ARG, "%s: null pointer", who);
@@ -272,6 +283,15 @@ extern "C" int64_t vae_elbo_step_workspace_bytes(const vae_step_config* cfg) {
 }
 
 extern "C" int vae_elbo_step_bf16_activations(const vae_step_config* cfg) { return cfg && bf16_storage(*cfg) ? 1 : 0; }
+
+extern "C" int vae_elbo_step_counts_path(const vae_step_config* cfg) {
+  Layout lo;
+  if (!cfg || !make_layout(*cfg, &lo)) return -1;
+  Ctx k{*cfg, nullptr, lo, nullptr, nullptr, false};
+  alignas(16) static const float aligned_rows[4] = {0.f, 0.f, 0.f, 0.f};
+  k.xd = xdirect(*cfg, k, aligned_rows, (cfg->G + 3) / 4 * 4);
+  return !k.xd ? 0 : (xoptimistic(*cfg, k) ? 2 : 1);
+}
 
 extern "C" int64_t vae_elbo_step_ws_offset(const vae_step_config* cfg, int slice) {
   Layout lo;
@@ -321,7 +341,10 @@ extern "C" int vae_elbo_step_forward(const vae_step_config* cfg, const vae_step_
     TRY(vae_cast_bf16(p->enc_w0, k.h16(lo.w_enc16), HE * k.ldw(), p->heads_w, k.h16(lo.w_heads16), NH * Hd, stream));
   }
   // encoders: x/mean-1 -> Linear(G, H+Hl) -> GELU -> LayerNorm (z and library halves)
-  if (k.xd)   // raw counts go to the products: the cells' means, maxima and exactness flags, and sum_g W (one launch)
+  const bool xopt = xoptimistic(c, k);
+  if (xopt) {
+    // (nothing here: the forward product gathers the statistics itself)
+  } else if (k.xd)   // raw counts go to the products: the cells' means, maxima and exactness flags, and sum_g W (one launch)
     TRY(vae_row_stats((const float*)xv, ldx, B, G, ws + lo.mean, k.am(AM_XN), ws + lo.xflags, p->enc_w0, k.ldw(), HE, ws + lo.wsum, stream));
   else
     TRY(vae_normalize_rows_ex(xv, c.x_dtype, ldx, B, G, ws + lo.mean, ws + lo.xn, k.hb(), lo.ld_xn, k.am(AM_XN), stream));
@@ -341,6 +364,17 @@ extern "C" int vae_elbo_step_forward(const vae_step_config* cfg, const vae_step_
       TRY(k.enc_fwd(Hl, ws + lo.xn, AM_XN, p->enc_w0 + H * k.ldw(), ws + lo.pre_enc0 + H, HE, nullptr, nullptr));
       slabs = ws + lo.pre_enc0;
       nslab = 1;
+    } else if (xopt) {   // the same, optimistically: product first, statistics on the way, repeated only if they object
+      VaeGemmCounts xc{nullptr, 0, nullptr};
+      xc.mode = 1; xc.xs_sum = ws + lo.xs_sum; xc.ws_sum = ws + lo.ws_sum; xc.xs_max = k.am(AM_XN); xc.xs_flag = ws + lo.xflags; xc.xs_n = (int)(B * VAE_NORM_WAVES);
+      TRY(vae_gemm_f16x2(VAE_NT, B, HE, G, (const float*)xv, ldx, k.am(AM_XN), k.an(AM_XN), p->enc_w0, k.ldw(), k.am(AM_WENC),
+                         k.an(AM_WENC), nullptr, HE, nullptr, 0, ws + lo.scratch, lo.scratch_floats * 4, stream, &nslab, nullptr, &xc));
+      if (nslab > 64) return vae_set_error(VAE_ERR_LAUNCH, "vae_elbo_step_forward: %d slabs of row sums", nslab);
+      int nslab2 = 0;
+      xc.mode = 2; xc.flags = ws + lo.xflags; xc.n_flags = xc.xs_n; xc.mean_out = ws + lo.mean; xc.wsum_out = ws + lo.wsum;
+      TRY(vae_gemm_f16x2(VAE_NT, B, HE, G, (const float*)xv, ldx, k.am(AM_XN), k.an(AM_XN), p->enc_w0, k.ldw(), k.am(AM_WENC),
+                         k.an(AM_WENC), nullptr, HE, nullptr, 0, ws + lo.scratch, lo.scratch_floats * 4, stream, &nslab2, nullptr, &xc));
+      if (nslab2 != nslab) return vae_set_error(VAE_ERR_LAUNCH, "vae_elbo_step_forward: slab counts differ (%d, %d)", nslab, nslab2);
     } else if (k.xd) {   // x W^T of the raw counts; the middle applies 1 / mean and - sum_g W
       const VaeGemmCounts xc{ws + lo.xflags, (int)(B * VAE_NORM_WAVES), nullptr};
       TRY(vae_gemm_f16x2(VAE_NT, B, HE, G, (const float*)xv, ldx, k.am(AM_XN), k.an(AM_XN), p->enc_w0, k.ldw(), k.am(AM_WENC),

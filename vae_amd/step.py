@@ -243,6 +243,11 @@ class ElboStep:
             t = tuple(t)
         self.weight_images = t
 
+    def counts_path(self, B: int, train: bool = True) -> int:
+        """How a step of B cells feeds float counts to the first-layer encoder products (include/vae_amd.h,
+        vae_elbo_step_counts_path): 0 normalised matrix, 1 raw counts behind a statistics launch, 2 raw counts, optimistic."""
+        return int(self.lib.vae_elbo_step_counts_path(C.byref(self._plan(B, 1.0, train)[0])))
+
     def bf16_activations(self, B: int, train: bool = False) -> bool:
         """Whether a step of batch size B keeps the logits / logit gradients as bf16 (include/vae_amd.h,
         vae_elbo_step_bf16_activations): the bf16 oracle is then the one with ``logits_bf16=True``."""
