@@ -346,6 +346,13 @@ def test_optimistic_count_product_and_its_repeat(counts):
             if o_grads[k] is None:
                 continue
             assert rel_err(v.cpu().numpy(), o_grads[k].numpy()) < TOL_GRAD, (k, rep)
+    if counts == "fractional":   # the hint that skips the optimistic attempt (vae_step_config.fractional_counts): same step
+        ref = {k: out[k].clone() for k in ("recon", "qz_m", "library")}
+        g_ref = arena.flat_grad.clone()
+        out_h = step.run(xd, ezd, eld, fractional_counts=True)
+        for k, v in ref.items():
+            assert rel_err(out_h[k].cpu().numpy(), v.cpu().numpy()) < 1e-5, k
+        assert rel_err(arena.flat_grad.cpu().numpy(), g_ref.cpu().numpy()) < 1e-5
     # a clean batch after an offending one: stale flags must not survive
     x2 = O.synthetic_counts(B, G, seed=27, zero_inflate=0.3)
     o2, _ = O.training_step_with_grads({k: v.double() for k, v in p.items()}, x2.double(), eps_z.double(), eps_l.double(),

@@ -123,7 +123,7 @@ class StepConfig(C.Structure):
                 ("input_dropout_rate", _f32), ("input_dropout_alpha", _f32), ("gene_running", _ptr),
                 ("weight_max_enc", _ptr), ("weight_max_heads", _ptr), ("weight_max_n", C.c_int32),
                 ("n_cov", C.c_int32), ("batch_cov", _ptr), ("ld_cov", _i64), ("ld_enc_w", _i64),
-                ("weight_bf16_enc", _ptr), ("weight_bf16_heads", _ptr), ("defer_elbo_reduce", C.c_int32)]
+                ("weight_bf16_enc", _ptr), ("weight_bf16_heads", _ptr), ("defer_elbo_reduce", C.c_int32), ("fractional_counts", C.c_int32)]
 
 
 VAE_MAX_HEADS = 7

@@ -244,7 +244,7 @@ bool xdirect(const vae_step_config& c, const Ctx& k, const void* x, int64_t ldx)
 // the batch (and the first-layer weight) less per step.  A/B knob: VAE_NO_XOPT.
 bool xoptimistic(const vae_step_config& c, const Ctx& k) {
   static const bool off = getenv("VAE_NO_XOPT") != nullptr;
-  return !off && k.xd && vae_gemm_counts_optimistic_ok(c.B, c.H + c.Hl, c.G, (int)(c.B * VAE_NORM_WAVES));
+  return !off && k.xd && !c.fractional_counts && vae_gemm_counts_optimistic_ok(c.B, c.H + c.Hl, c.G, (int)(c.B * VAE_NORM_WAVES));
 }
 
 int check_common(const vae_step_config* cfg, const void* a, const void* b, const void* x, int64_t ldx,

@@ -327,7 +327,7 @@ class ElboStep:
             cell_head_fn: Optional[Callable[[torch.Tensor], torch.Tensor]] = None,
             backward: bool = True, loss_scale: float = 1.0, reducer=None, train: Optional[bool] = None,
             rng_step: Optional[int] = None, batch_cov: Optional[torch.Tensor] = None,
-            cell_heads: Optional[tuple] = None) -> Dict[str, torch.Tensor]:
+            cell_heads: Optional[tuple] = None, fractional_counts: bool = False) -> Dict[str, torch.Tensor]:
         """One step.  The returned tensors are VIEWS of the step workspace: they are overwritten by
         the next ``run`` with the same batch size (clone what must survive).
 
@@ -336,6 +336,9 @@ class ElboStep:
 
         ``cell_heads`` = ``(CellHeads, targets (B, P), mask (B, P))``: linear cell-property heads on the native path, instead
         of ``cell_head_fn``.
+
+        ``fractional_counts``: the batch holds fractions (mixup / cutmix) -- a hint, never needed for correctness
+        (``vae_step_config.fractional_counts``).
 
         ``batch_cov`` (B, n_cov): the masked one-hot batch covariates (``ElboStep.covariates``) of a model built with
         ``batch_properties``; required exactly then."""
@@ -367,6 +370,7 @@ class ElboStep:
         cfg.rng_step = int(rng_step) & 0xFFFFFFFF
         # a training step: the ELBO reduction (recon, the scalars) rides in the backward's first launch (vae_step_config)
         cfg.defer_elbo_reduce = int(bool(backward))
+        cfg.fractional_counts = int(bool(fractional_counts))
         stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         ldx = x.stride(0) if B > 1 else G
         rc = self.lib.vae_elbo_step_forward(C.byref(cfg), C.byref(self.params), x.data_ptr(), ldx, eps_z.data_ptr(),

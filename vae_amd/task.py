@@ -442,7 +442,7 @@ class LitVAE(nn.Module):
         if self.batch_properties:   # modules.py:121-130: the masked one-hot block every FCLayers appends to its input
             cov = ElboStep.covariates(batch[3], batch[4], self.network.z_encoder.encoder.batch_dims)
         out = self._fused.run(gene_vals, eps_z, eps_l, cell_head_fn=fn, loss_scale=loss_scale, reducer=reducer, batch_cov=cov,
-                              cell_heads=heads)
+                              cell_heads=heads, fractional_counts=getattr(self, "fractional_counts", False))
         if self.l1_lambda > 0:
             l1 = self._l1.apply(self.l1_lambda * loss_scale)
             out["l1"] = l1

@@ -131,6 +131,7 @@ def _main_datamodule(dm, model_cfg, task_cfg, trainer_cfg, max_steps, log_every,
                   library_var=lib_var, precision=precision, batch_properties=dm.batch_properties,
                   **{k: v for k, v in tcfg.items() if k not in ("batch_properties",)})
     task.train()
+    task.fractional_counts = bool(getattr(ds, "mixup", False) or getattr(ds, "cutmix", False))   # a hint for the fused step
     if dist.is_initialized():
         task.dropout_seed += 0x9E3779B97F4A7C15 * dist.get_rank() % (2 ** 63)
         np.random.seed(rank_seed(43))              # every rank draws its own balanced batches / mixup partners
