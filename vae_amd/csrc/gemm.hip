@@ -911,6 +911,9 @@ __device__ __forceinline__ void split_pair_f16(float a0, float a1, float s0, flo
 #ifndef VAE_X3_SETS
 #define VAE_X3_SETS 1
 #endif
+#ifndef VAE_X3_RELOAD_FLAT   // the same in the unpipelined loop (the 160-wide tiles), NT products
+#define VAE_X3_RELOAD_FLAT 1
+#endif
 template <int LAYOUT, int BM, int BN, int WAVES_M, int NP, int IO = 0, bool ROWSC = false, int XONE = 0>
 __global__ __launch_bounds__(256, ((VAE_X3_PIPE && NP <= 2 && BM == 128 && BN == 128) || ROWSC || XONE != 0 || BN > 160 ? 2 : (NP <= 2 ? 3 : 2))) void gemm_x3_kernel(GemmArgs g) {
   static_assert(IO == 0 || NP == 1, "bf16 storage goes with the one-plane bf16 product");
@@ -1172,11 +1175,31 @@ __global__ __launch_bounds__(256, ((VAE_X3_PIPE && NP <= 2 && BM == 128 && BN ==
 #endif
   // `one` (a std::integral_constant<int, 0 | 1 | 2>): which operand runs on its hi term alone in this instantiation of the
   // K loop (0: none, 1: A, 2: B) -- see XONE
-  auto stage = [&](auto one) {
+  // again: the base pointers stand on the NEXT full K step and every staging register is requested anew as soon as its
+  // contents are converted (VAE_X3_RELOAD) -- the loads then travel during the rest of the conversion and the barrier too
+  auto stage = [&](auto one, bool again = false) {
     constexpr int ONE = decltype(one)::value;
     GSTAMP();
     __syncthreads();  // the previous tile's fragment reads are done
     GSTAMP();
+    if (again) {
+#pragma unroll
+      for (int i = 0; i < NA; ++i) {
+        put(sA, PLA, wa[i], ra[i], scale_a4(i), std::bool_constant<ONE != 1>{});
+        ra[i] = *reinterpret_cast<const RA*>(bA + oa[i]);
+      }
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        put(sB, PLB, wb[i], rb[i], make_float4(scB, scB, scB, scB), std::bool_constant<ONE != 2>{});
+        rb[i] = *reinterpret_cast<const RB*>(bB + ob[i]);
+      }
+      bA += step_a;
+      bB += step_b;
+      GSTAMP();
+      __syncthreads();
+      GSTAMP();
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < NA; ++i) put(sA, PLA, wa[i], ra[i], scale_a4(i), std::bool_constant<ONE != 1>{});
 #pragma unroll
@@ -1448,9 +1471,14 @@ __global__ __launch_bounds__(256, ((VAE_X3_PIPE && NP <= 2 && BM == 128 && BN ==
         if ((!(VAE_ABL & 2) || i == 0) && i + 1 < nfull) fetch();
         if (!(VAE_ABL & 4)) multiply(one);
 #else
-        stage(one);
-        if (i + 1 < nfull) fetch();  // in flight during the MFMAs below
-        else if (tail) fetch_tail(tail);
+        if (VAE_X3_RELOAD && VAE_X3_RELOAD_FLAT && LAYOUT == NT && !ROWSC) {   // (measured: decoder forward -1.8 us; the row-scaled TN weight gradient +1.5, so not there)
+          stage(one, i + 1 < nfull);
+          if (i + 1 >= nfull && tail) fetch_tail(tail);
+        } else {
+          stage(one);
+          if (i + 1 < nfull) fetch();  // in flight during the MFMAs below
+          else if (tail) fetch_tail(tail);
+        }
         multiply(one);
 #endif
       }
