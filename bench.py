@@ -89,7 +89,7 @@ def time_kernel(fn, iters=5):
     return st.elapsed_time(en) / iters
 
 
-def kernel_breakdown(arena, cfg, x, precision, bf16_storage=False):
+def kernel_breakdown(arena, cfg, x, precision, bf16_storage=False, counts_path=1):
     """Per-kernel timings of the big stages at the bench shapes, on the launch stream.  bf16_storage: the step of this
     configuration keeps xn / logits / logit gradients as bf16 and streams bf16 images of the weights: the
     same kernels are timed here on such operands, and the likelihood passes are priced at their bytes (8 / 12 per
@@ -140,7 +140,9 @@ def kernel_breakdown(arena, cfg, x, precision, bf16_storage=False):
         wmax = w_enc.abs().amax().expand(4).contiguous()
         dps = (dpre / mean[:, None]).contiguous()
         dmax, colsum = dps.abs().amax().expand(4).contiguous(), dpre.sum(dim=0)
-        ks["row_stats"] = (time_kernel(lambda: ops.row_stats(x, w_enc)), "hbm", 4.0 * (B + H + Hl) * G)
+        if counts_path != 2:   # (path 2: no statistics launch -- the forward product gathers them itself, step.hip xoptimistic;
+            #  the product timed below is then the one-term kernel WITHOUT that gathering: 3-4 us less than in the step)
+            ks["row_stats"] = (time_kernel(lambda: ops.row_stats(x, w_enc)), "hbm", 4.0 * (B + H + Hl) * G)
         ks["gemm_enc_fwd"] = (time_kernel(lambda: ops.gemm_counts(ops.NT, x, w_enc, xmax, wmax, xflags)), "mfma", fl(B, H + Hl, G), "fp32x2")
     elif mm is not None:
         ks["gemm_enc_fwd"] = (time_kernel(lambda: mm(ops.NT, xn, w_enc)), "mfma", fl(B, H + Hl, G))
@@ -157,7 +159,7 @@ def kernel_breakdown(arena, cfg, x, precision, bf16_storage=False):
             wg = lambda: mm(ops.TN, logits, px, gw_heads)  # noqa: E731
         ks["gemm_dec_wgrad"] = (time_kernel(wg), "mfma", fl(NH, Hd, B))
         ks["gemm_dec_dgrad"] = (time_kernel(lambda: mm(ops.NN, logits, w_heads)), "mfma", fl(B, Hd, NH))
-        if "row_stats" in ks:
+        if ks["gemm_enc_fwd"][-1] == "fp32x2":
             ks["gemm_enc_wgrad"] = (time_kernel(lambda: ops.gemm_counts(ops.TN, dps, x, dmax, xmax, xflags, row_sub=colsum, out=gw_enc)),
                                     "mfma", fl(H + Hl, G, B), "fp32x2")
         else:
@@ -480,6 +482,9 @@ def main():
                        "parallelism": f"dp{world}", "grad_payload": args.grad_payload if world > 1 else None,
                        "enc_slabs": reducer.enc_slabs if reducer is not None else None,
                        "counts": args.counts, "bf16_activations": bf16_st,
+                       "count_operand_path": ({0: "normalised matrix", 1: "raw counts behind a statistics launch",
+                                               2: "raw counts, optimistic (no launch ahead of the first product)"}
+                                              .get(step.counts_path(B)) if args.counts == "f32" else "uint8 -> normalised matrix"),
                        "weight_operand_scales": ("scanned by every forward" if fopt is None else
                                                  "maxima kept by the fused optimiser (vae_adamw_step_wmax)" if fopt.weight_maxima is not None
                                                  else "bf16 images kept by the fused optimiser (vae_adamw_step_bf16)")},
@@ -489,7 +494,7 @@ def main():
             result["scan_weights"] = side
     if rank == 0 and not args.no_breakdown:
         xb = x_all[:B].float()
-        ks = kernel_breakdown(arena, cfg, xb, precision, bf16_st)
+        ks = kernel_breakdown(arena, cfg, xb, precision, bf16_st, step.counts_path(B) if args.counts == "f32" else 0)
         name, rec = max(ks.items(), key=lambda kv: kv[1][0])
         t_ms, bound, work = rec[:3]
         basis = rec[3] if len(rec) > 3 else cfg["precision"]      # the product scheme this kernel runs
