@@ -1086,7 +1086,20 @@ __global__ __launch_bounds__(256, ((VAE_X3_PIPE && NP <= 2 && BM == 128 && BN ==
         float mx = 0.f;
         if (m < g.M) {
           const float* q = m < g.rmax_split ? g.rmax0 + m : g.rmax1 + (m - g.rmax_split);
-          for (int c = 0; c < g.rmax_chunks; ++c) mx = fmaxf(mx, q[(int64_t)c * g.rmax_stride]);
+          int c = 0;
+          for (; c + 16 <= g.rmax_chunks; c += 16) {   // sixteen loads in flight, not a chain of round trips
+            float t[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) t[u] = q[(int64_t)(c + u) * g.rmax_stride];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) mx = fmaxf(mx, t[u]);
+          }
+          for (; c + 4 <= g.rmax_chunks; c += 4) {
+            const float t0 = q[(int64_t)c * g.rmax_stride], t1 = q[(int64_t)(c + 1) * g.rmax_stride];
+            const float t2 = q[(int64_t)(c + 2) * g.rmax_stride], t3 = q[(int64_t)(c + 3) * g.rmax_stride];
+            mx = fmaxf(fmaxf(mx, fmaxf(t0, t1)), fmaxf(t2, t3));
+          }
+          for (; c < g.rmax_chunks; ++c) mx = fmaxf(mx, q[(int64_t)c * g.rmax_stride]);
         }
         const float sc = vae_scale_from_absmax(mx);
         row_sc[tid] = sc;
