@@ -50,6 +50,13 @@ __device__ __forceinline__ void vae_colreduce_column(const float* __restrict__ s
   const int64_t st = (int64_t)VAE_SLAB_ROWS * G;
   float s = 0.f;
   int c = 0;
+  for (; c + 16 <= chunks; c += 16) {   // sixteen loads in flight (the chunks are a chain of round trips otherwise); same order
+    float q[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) q[u] = p[(c + u) * st];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) s += q[u];
+  }
   for (; c + 4 <= chunks; c += 4) {
     const float a = p[c * st], b = p[(c + 1) * st], d = p[(c + 2) * st], e = p[(c + 3) * st];
     s = (((s + a) + b) + d) + e;

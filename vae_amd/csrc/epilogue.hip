@@ -608,11 +608,27 @@ __global__ __launch_bounds__(256) void softmax_stats_merge_kernel(const float* _
   const int lane = threadIdx.x & 63;
   const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (b >= B) return;
-  float m = -INFINITY;
-  for (int t = lane; t < slots; t += 64) m = fmaxf(m, sm[(int64_t)t * B + b]);
-  const float M = wave_max(m);
-  float s = 0.f;
-  for (int t = lane; t < slots; t += 64) s += ss[(int64_t)t * B + b] * fexp_acc(sm[(int64_t)t * B + b] - M);
+  float m = -INFINITY, s = 0.f, M;
+  constexpr int PER_LANE = 8;
+  if (slots <= 64 * PER_LANE) {   // every statistic of the row requested at once: one round trip instead of one per 64 slots and pass
+    float vm[PER_LANE], vs[PER_LANE];
+#pragma unroll
+    for (int u = 0; u < PER_LANE; ++u) {
+      const int t = lane + 64 * u;
+      vm[u] = t < slots ? sm[(int64_t)t * B + b] : -INFINITY;
+      vs[u] = t < slots ? ss[(int64_t)t * B + b] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < PER_LANE; ++u) m = fmaxf(m, vm[u]);
+    M = wave_max(m);
+#pragma unroll
+    for (int u = 0; u < PER_LANE; ++u)   // (the same terms in the same order as the loop below)
+      if (lane + 64 * u < slots) s += vs[u] * fexp_acc(vm[u] - M);
+  } else {
+    for (int t = lane; t < slots; t += 64) m = fmaxf(m, sm[(int64_t)t * B + b]);
+    M = wave_max(m);
+    for (int t = lane; t < slots; t += 64) s += ss[(int64_t)t * B + b] * fexp_acc(sm[(int64_t)t * B + b] - M);
+  }
   s = wave_sum(s);
   if (lane == 0) { rowmax[b] = M; rowsum[b] = s; }
 }

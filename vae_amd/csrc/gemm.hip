@@ -1759,6 +1759,13 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
       const float4* p = reinterpret_cast<const float4*>(ws) + i;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       int s = 0;
+      for (; s + 8 <= split; s += 8) {  // eight slabs in flight, added in slab order
+        float4 q[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) q[u] = p[(int64_t)(s + u) * total4];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { v.x += q[u].x; v.y += q[u].y; v.z += q[u].z; v.w += q[u].w; }
+      }
       for (; s + 4 <= split; s += 4) {  // fixed order: slab s, s+1, s+2, s+3
         const float4 a = p[(int64_t)s * total4], b = p[(int64_t)(s + 1) * total4];
         const float4 c = p[(int64_t)(s + 2) * total4], d = p[(int64_t)(s + 3) * total4];
