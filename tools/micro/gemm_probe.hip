@@ -41,9 +41,28 @@ int main(int argc, char** argv) {
     hipFree(A); hipFree(C); hipMalloc(&A, (size_t)512 * 40000 * 4); hipMemset(A, 0, (size_t)512 * 40000 * 4);
     hipMalloc(&C, (size_t)g.split * 512 * 256 * 4); g.A = A; g.C = C;
   }
+  if (lay == 2) { /* TN row-scaled decoder wgrad: M=40000, N=256, K=512 (A (K,M) = dlogits, B (K,N) = px); build with -DPROBE_CFG="160, 128, 1, 2, 0, true" */
+    const int G = 20000, chunks = 52;
+    g.lda = 40000; g.ldb = 256; g.ldc = 256; g.M = 40000; g.N = 256; g.K = 512;
+    g.tiles_m = 250; g.tiles_n = 2; g.split = 1; g.k_per_split = 512;
+    hipFree(A); hipFree(B); hipFree(C);
+    hipMalloc(&A, (size_t)512 * 40000 * 4); hipMemset(A, 0, (size_t)512 * 40000 * 4);
+    hipMalloc(&B, (size_t)512 * 256 * 4); hipMemset(B, 0, (size_t)512 * 256 * 4);
+    hipMalloc(&C, (size_t)40000 * 256 * 4);
+    float *rm, *sb;
+    hipMalloc(&rm, (size_t)chunks * 5 * G * 4); hipMemset(rm, 0, (size_t)chunks * 5 * G * 4);
+    hipMalloc(&sb, 4096 * 4); hipMemset(sb, 0, 4096 * 4);
+    g.A = A; g.B = B; g.C = C; g.rmax0 = rm + 3 * G; g.rmax1 = rm + 4 * G; g.rmax_split = G; g.rmax_chunks = chunks; g.rmax_stride = 5 * G;
+    g.sb = sb; g.nb = 4096;
+  }
   const int grid = g.tiles_m * g.tiles_n * g.split;
+#ifdef PROBE_TN   // (the row-scaled instantiation exists for TN only)
+  run<TN>(g, grid);
+#else
   if (lay == 0) run<NT>(g, grid);
-  else          run<NN>(g, grid);
+  else if (lay == 1) run<NN>(g, grid);
+  else run<TN>(g, grid);
+#endif
   static long long h[4][256];
   hipMemcpyFromSymbol(h, HIP_SYMBOL(g_probe), sizeof(h));
   // stamps: [0] start, then per K-step 4 (loop top, after sync1, after LDS writes, after sync2), then end of loop, end of kernel
