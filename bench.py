@@ -158,7 +158,22 @@ def kernel_breakdown(arena, cfg, x, precision, bf16_storage=False, counts_path=1
         else:
             wg = lambda: mm(ops.TN, logits, px, gw_heads)  # noqa: E731
         ks["gemm_dec_wgrad"] = (time_kernel(wg), "mfma", fl(NH, Hd, B))
-        ks["gemm_dec_dgrad"] = (time_kernel(lambda: mm(ops.NN, logits, w_heads)), "mfma", fl(B, Hd, NH))
+        if P == ops.F16X2 and cfg["n_layers"] == 1:
+            # the fused middle of a one-layer step sums the split-K slabs of this product itself: time the
+            # product as the step launches it -- slabs left in the workspace, no reduce launch behind it
+            import ctypes as C
+            from vae_amd import _lib
+            clib = _lib.load()
+            nb = clib.vae_gemm_slabs_workspace_bytes(B, Hd, NH)
+            wsl = ops.workspace(nb, dev)
+            nsl = C.c_int(0)
+            st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+            dg = lambda: _lib.check(clib.vae_gemm_scaled_slabs(ops.NN, B, Hd, NH, logits.data_ptr(), logits.stride(0), sc[id(logits)].data_ptr(),  # noqa: E731
+                                                              w_heads.data_ptr(), w_heads.stride(0), sc[id(w_heads)].data_ptr(),
+                                                              wsl.data_ptr(), nb, C.byref(nsl), st), "gemm_scaled_slabs")
+        else:
+            dg = lambda: mm(ops.NN, logits, w_heads)  # noqa: E731
+        ks["gemm_dec_dgrad"] = (time_kernel(dg), "mfma", fl(B, Hd, NH))
         if ks["gemm_enc_fwd"][-1] == "fp32x2":
             ks["gemm_enc_wgrad"] = (time_kernel(lambda: ops.gemm_counts(ops.TN, dps, x, dmax, xmax, xflags, row_sub=colsum, out=gw_enc)),
                                     "mfma", fl(H + Hl, G, B), "fp32x2")
@@ -495,7 +510,8 @@ def main():
     if rank == 0 and not args.no_breakdown:
         xb = x_all[:B].float()
         ks = kernel_breakdown(arena, cfg, xb, precision, bf16_st, step.counts_path(B) if args.counts == "f32" else 0)
-        name, rec = max(ks.items(), key=lambda kv: kv[1][0])
+        # the dominant kernel OF THE STEP (the statistics-only likelihood variant is timed beside it, not launched by this step)
+        name, rec = max(((k, v) for k, v in ks.items() if k != "nbzinb_fwd_with_own_statistics"), key=lambda kv: kv[1][0])
         t_ms, bound, work = rec[:3]
         basis = rec[3] if len(rec) > 3 else cfg["precision"]      # the product scheme this kernel runs
         if bound == "hbm":
