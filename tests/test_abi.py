@@ -120,6 +120,25 @@ def test_workspace_queries():
     assert lib.vae_elbo_step_workspace_bytes(C.byref(cfg)) == -1
 
 
+def test_counts_path_query(monkeypatch):
+    """vae_elbo_step_counts_path (a host-side decision, no launch): how float counts reach the first-layer encoder products."""
+    from vae_amd import _lib
+    if os.environ.get("VAE_NO_XOPT") or os.environ.get("VAE_NO_XDIRECT"):
+        pytest.skip("A/B knob set")
+    lib = _lib.load()
+    base = dict(B=512, G=20000, H=256, Hl=128, L=30, Hd=256, n_layers=1, zinb=1, l_mean=0.0, l_var=1.0, kl_weight=1.0,
+                gene_loss_coeff=5e-3, loss_scale=1.0)
+    path = lambda **kw: lib.vae_elbo_step_counts_path(C.byref(_lib.StepConfig(**{**base, **kw})))  # noqa: E731
+    assert path(precision=3) == 2                              # cfg2, two f16 terms: optimistic, no launch ahead of the product
+    assert path(precision=3, fractional_counts=1) == 1         # a mixup loader's hint: behind the statistics launch
+    assert path(precision=3, G=20008) == 1                     # G % 32 != 0: the optimistic kernel takes whole K steps only
+    assert path(precision=3, x_dtype=1) == 0                   # uint8 counts: normalised matrix
+    assert path(precision=3, input_dropout_rate=0.5) == 0      # GeneDropout: the z-encoder reads its own masked counts
+    assert path(precision=3, n_layers=2) == 0                  # the count operand belongs to the fused middle (one hidden layer)
+    assert path(precision=0) == 0 and path(precision=1) == 0   # exact fp32 / bf16 modes
+    assert lib.vae_elbo_step_counts_path(None) == -1
+
+
 def test_ops_refuse_cpu_tensors():
     import torch
     from vae_amd import ops
