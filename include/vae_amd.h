@@ -111,9 +111,8 @@ int vae_gemm_scaled_slabs(int layout, int64_t M, int64_t N, int64_t K, const flo
  *   weight, one launch, fixed summation order.
  * vae_gemm_counts: vae_gemm on two f16 terms (as vae_gemm_scaled, the scales derived from n_max partial maxima per
  *   operand) where the count operand is A for VAE_NT and B for VAE_TN.  VAE_NT: when every flag is 0 the counts run on their
- *   hi term alone, otherwise the kernel takes the plain two-term loop (decided on the device).  VAE_TN: always two terms
- *   (flags may be NULL; the one-term form of this product measured slower -- it is bound by the latency of its K steps,
- *   not by its matrix-core work).  row_sub (nullable, VAE_TN, M floats): C[m, n] -= row_sub[m].  Shapes outside the 128-wide tile pipeline are rejected (vae_gemm_rowscaled_ok's conditions,
+ *   hi term alone, otherwise the kernel takes the plain two-term loop (decided on the device).  VAE_TN: the same on
+ *   128 x 128 tiles when flags are given (NULL: always two terms).  row_sub (nullable, VAE_TN, M floats): C[m, n] -= row_sub[m].  Shapes outside the 128-wide tile pipeline are rejected (vae_gemm_rowscaled_ok's conditions,
  *   with the layout's own alignment: K % 4 == 0, TN: M % 4 == N % 4 == 0).                                              */
 int vae_row_stats(const float* x, int64_t ldx, int64_t B, int64_t G, float* mean, float* absmax, float* flags, const float* W,
                   int64_t ldw, int64_t HE, float* wsum, void* stream);

@@ -911,6 +911,9 @@ __device__ __forceinline__ void split_pair_f16(float a0, float a1, float s0, flo
 #ifndef VAE_X3_SETS
 #define VAE_X3_SETS 1
 #endif
+#ifndef VAE_TN_XONE   // one-term count operand in the TN weight gradient too (128 x 128 tiles)
+#define VAE_TN_XONE 1
+#endif
 #ifndef VAE_X3_RELOAD_FLAT   // the same in the unpipelined loop (the 160-wide tiles), NT products
 #define VAE_X3_RELOAD_FLAT 1
 #endif
@@ -2100,12 +2103,14 @@ int gemm_impl(int layout, int precision, int64_t M, int64_t N, int64_t K, const 
     } else if (xopt) {   // counts taken as exact in one unscaled f16 term, checked on the way (GemmArgs::xs_*)
       hipLaunchKernelGGL((gemm_x3_kernel<NT, 128, 128, 2, 2, 0, false, 3>), grid1, dim3(256), 0, st, g);
     } else if (xo && xo->flags && layout == NT) {   // two f16 terms, the count operand A on ONE term when every count is exact in it
-      // (the TN form -- counts = B, static_assert'ed in the kernel -- is not instantiated: measured on the cfg2 weight
-      // gradient it is SLOWER than the plain two-term kernel, 41.8 vs 37.5 us in-step, 38.2 vs 34.9 stand-alone; these
-      // products are bound by the latency of their K steps, not by their MFMA or conversion work.  TN runs below.)
+      // (the TN form -- counts = B -- follows below for the 128 x 128 tiles.  Before the pipelined loop asked for its
+      // staging registers again right after converting them it was SLOWER than the plain two-term kernel, 41.8 vs 37.5 us
+      // on the cfg2 weight gradient -- bound by the latency of its K steps; with the reload it is 32.9 vs 35.9.)
       if (bm == 128 && bn == 128) hipLaunchKernelGGL((gemm_x3_kernel<NT, 128, 128, 2, 2, 0, false, 1>), grid1, dim3(256), 0, st, g);
       else if (bn == 160)         hipLaunchKernelGGL((gemm_x3_kernel<NT, 128, 160, 4, 2, 0, false, 1>), grid1, dim3(256), 0, st, g);
       else                        hipLaunchKernelGGL((gemm_x3_kernel<NT, 160, 128, 1, 2, 0, false, 1>), grid1, dim3(256), 0, st, g);
+    } else if (VAE_TN_XONE && xo && xo->flags && layout == TN && bm == 128 && bn == 128) {   // ... and the count operand B of the weight gradient
+      hipLaunchKernelGGL((gemm_x3_kernel<TN, 128, 128, 2, 2, 0, false, 2>), grid1, dim3(256), 0, st, g);
     } else if (rsc) {   // two f16 terms, one scale per product row (the decoder weight gradient)
       if (bm == 128 && bn == 128) hipLaunchKernelGGL((gemm_x3_kernel<TN, 128, 128, 2, 2, 0, true>), grid1, dim3(256), 0, st, g);
       else if (bn == 160)         hipLaunchKernelGGL((gemm_x3_kernel<TN, 128, 160, 4, 2, 0, true>), grid1, dim3(256), 0, st, g);

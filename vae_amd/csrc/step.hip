@@ -713,7 +713,7 @@ extern "C" int vae_elbo_step_backward_slabs(const vae_step_config* cfg, const va
     if (c.input_dropout_rate > 0.f) {  // GeneDropout: each encoder's weight gradient over its own input
       TRY(k.enc_wgrad(rows, dpre_i, HE, r0 < H ? ws + lo.xn_z : ws + lo.xn, r0 < H ? AM_XNZ : AM_XN, dw_i));
     } else if (k.xd) {   // dW = (dpre / mean)^T x - colsum(dpre) 1^T; colsum(dpre) = the first-layer bias gradient, final by now
-      const VaeGemmCounts xc{nullptr, 0, g->enc_b0 + r0};   // (two terms of x: gemm.hip, the one-term TN form measured slower)
+      const VaeGemmCounts xc{ws + lo.xflags, (int)(B * VAE_NORM_WAVES), g->enc_b0 + r0};   // (the flags the forward left: one term of x when all clear)
       TRY(vae_gemm_f16x2(VAE_TN, rows, G, B, ws + lo.dpre_s + r0, HE, k.am(AM_DPRE), k.an(AM_DPRE), (const float*)xv, ldx, k.am(AM_XN),
                          k.an(AM_XN), dw_i, k.ldw(), nullptr, 0, ws + lo.scratch, lo.scratch_floats * 4, stream, nullptr, nullptr, &xc));
     } else {
