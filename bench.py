@@ -499,7 +499,7 @@ def main():
                        "counts": args.counts, "bf16_activations": bf16_st,
                        "count_operand_path": ({0: "normalised matrix", 1: "raw counts behind a statistics launch",
                                                2: "raw counts, optimistic (no launch ahead of the first product)"}
-                                              .get(step.counts_path(B)) if args.counts == "f32" else "uint8 -> normalised matrix"),
+                                              .get(step.counts_path(B)) + ("" if args.counts == "f32" else " over an fp32 copy of the uint8 batch (one cast launch)")),
                        "weight_operand_scales": ("scanned by every forward" if fopt is None else
                                                  "maxima kept by the fused optimiser (vae_adamw_step_wmax)" if fopt.weight_maxima is not None
                                                  else "bf16 images kept by the fused optimiser (vae_adamw_step_bf16)")},
@@ -509,7 +509,7 @@ def main():
             result["scan_weights"] = side
     if rank == 0 and not args.no_breakdown:
         xb = x_all[:B].float()
-        ks = kernel_breakdown(arena, cfg, xb, precision, bf16_st, step.counts_path(B) if args.counts == "f32" else 0)
+        ks = kernel_breakdown(arena, cfg, xb, precision, bf16_st, step.counts_path(B))
         # the dominant kernel OF THE STEP (the statistics-only likelihood variant is timed beside it, not launched by this step)
         name, rec = max(((k, v) for k, v in ks.items() if k != "nbzinb_fwd_with_own_statistics"), key=lambda kv: kv[1][0])
         t_ms, bound, work = rec[:3]

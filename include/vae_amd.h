@@ -432,7 +432,9 @@ int vae_elbo_step_bf16_activations(const vae_step_config* cfg);
  * 1 = the raw counts as the GEMM operand behind one vae_row_stats launch; 2 = the raw counts with NO launch ahead -- the
  * forward product takes them as exact in one unscaled f16 term (integer counts below 2048 are), gathers the cells' sums,
  * maxima and exactness flags while they pass, and a gated launch behind it finishes the means and sum_g W and repeats the
- * product in the scaled two-term form only when a flag came up.  (Environment VAE_NO_XOPT / VAE_NO_XDIRECT: A/B knobs.) */
+ * product in the scaled two-term form only when a flag came up.  uint8 counts (x_dtype = VAE_X_U8, 4-byte aligned rows)
+ * take forms 1 / 2 over an fp32 copy that one cast launch leaves in the workspace (the likelihood kernels keep reading
+ * the uint8 rows).  (Environment VAE_NO_XOPT / VAE_NO_XDIRECT: A/B knobs.)                                           */
 int vae_elbo_step_counts_path(const vae_step_config* cfg);
 
 /* named slices of the workspace that a caller may read after the forward (offsets in floats)      */

@@ -120,6 +120,8 @@ int vae_nbzinb_bwd_chunks(int64_t B, int64_t G);           /* cell chunks = slab
 int vae_normalize_rows_ex(const void* x, int x_dtype, int64_t ldx, int64_t B, int64_t G, float* mean, void* xn, int xn_bf16,
                           int64_t ld_xn, float* absmax, void* stream);
 // (vae_row_stats: include/vae_amd.h)
+// fp32 copy of a uint8 batch (G % 4 == 0, 4-byte aligned rows in, 16-byte aligned rows out)
+int vae_cast_u8_f32(const void* x, int64_t ldx, int64_t B, int64_t G, float* out, int64_t ldo, void* stream);
 // vae_gene_dropout that also stores the per-wave maxima of |xn| of the masked, normalised counts
 int vae_gene_dropout_ex(const void* x, int x_dtype, int64_t ldx, int64_t B, int64_t G, float p, float alpha, uint64_t seed,
                         uint32_t step, float* running, int32_t* counts, uint32_t* threshold, float* stats, float* mean,

@@ -729,6 +729,48 @@ extern "C" int vae_normalize_rows_u8(const uint8_t* x, int64_t ldx, int64_t B, i
 }
 
 // mean[b] of the raw fp32 counts, absmax / flags [B * VAE_NORM_WAVES] and wsum[h] = sum_g W[h, g], h < HE (row_stats_kernel)
+namespace {
+// uint8 counts -> fp32 counts, V bytes per thread (16: one 16-byte load, four 16-byte stores; 4: rows that are only
+// 4-byte aligned).  Grid: (column blocks, rows).
+template <int V>
+__global__ __launch_bounds__(256) void cast_u8_f32_kernel(const uint8_t* __restrict__ x, int64_t ldx, int G, float* __restrict__ out,
+                                                          int64_t ldo) {
+  const int b = blockIdx.y;
+  const int g0 = (blockIdx.x * 256 + threadIdx.x) * V;
+  if (g0 >= G) return;
+  const uint8_t* p = x + (int64_t)b * ldx + g0;
+  float* o = out + (int64_t)b * ldo + g0;
+  uint32_t w[V / 4];
+  if (V == 16) {
+    const uint4 q = *reinterpret_cast<const uint4*>(p);
+    w[0] = q.x; w[V / 4 > 1 ? 1 : 0] = q.y; w[V / 4 > 2 ? 2 : 0] = q.z; w[V / 4 > 3 ? 3 : 0] = q.w;
+  } else {
+    w[0] = *reinterpret_cast<const uint32_t*>(p);
+  }
+#pragma unroll
+  for (int i = 0; i < V / 4; ++i)
+    if (g0 + 4 * i < G)   // (G % 4 == 0: whole quads)
+      reinterpret_cast<float4*>(o)[i] = make_float4((float)(w[i] & 0xffu), (float)((w[i] >> 8) & 0xffu), (float)((w[i] >> 16) & 0xffu),
+                                                    (float)(w[i] >> 24));
+}
+}  // namespace
+// out[b, g] = (float) x[b, g], g < G (G % 4 == 0, rows of x 4-byte aligned, rows of out 16-byte aligned): the fp32 copy of a
+// uint8 batch that the count-operand encoder products read (step.hip)
+int vae_cast_u8_f32(const void* x, int64_t ldx, int64_t B, int64_t G, float* out, int64_t ldo, void* stream) {
+  VAE_REQUIRE(x && out && B > 0 && G > 0 && G % 4 == 0 && ldx >= G && ldo >= G && ldx % 4 == 0 && ldo % 4 == 0 && vae_aligned16(out) &&
+                  (reinterpret_cast<uintptr_t>(x) & 3u) == 0 && B < 65536,
+              "vae_cast_u8_f32: bad arguments");
+  const bool v16 = ldx % 16 == 0 && vae_aligned16(x);
+  if (v16)
+    hipLaunchKernelGGL(cast_u8_f32_kernel<16>, dim3((unsigned)((G + 4095) / 4096), (unsigned)B), dim3(256), 0, (hipStream_t)stream,
+                       (const uint8_t*)x, ldx, (int)G, out, ldo);
+  else
+    hipLaunchKernelGGL(cast_u8_f32_kernel<4>, dim3((unsigned)((G + 1023) / 1024), (unsigned)B), dim3(256), 0, (hipStream_t)stream,
+                       (const uint8_t*)x, ldx, (int)G, out, ldo);
+  VAE_CHECK_LAUNCH("vae_cast_u8_f32");
+  return VAE_OK;
+}
+
 extern "C" int vae_row_stats(const float* x, int64_t ldx, int64_t B, int64_t G, float* mean, float* absmax, float* flags, const float* W,
                   int64_t ldw, int64_t HE, float* wsum, void* stream) {
   VAE_REQUIRE(x && mean && absmax && flags && W && wsum && B > 0 && G > 0 && HE > 0 && ldx >= G && ldw >= G && B + HE < (1 << 30),

@@ -166,6 +166,8 @@ struct Ctx {
   void* st;
   const vae_step_tensors* par;   // the parameters (for offsets into their bf16 images)
   bool xd;                       // count-operand form of the two encoder products (xdirect() below)
+  const float* xf = nullptr;     // ... the fp32 counts they read: the caller's, or the copy of a uint8 batch in lo.xn
+  int64_t ldxf = 0;
   uint16_t* h16(int64_t off) const { return reinterpret_cast<uint16_t*>(ws + off); }
   // the two-f16-term pipeline needs 16-byte rows everywhere; ragged shapes run as VAE_FP32
   bool hb() const { return bf16_storage(c); }   // logits / logit gradients held as bf16
@@ -232,10 +234,18 @@ struct Ctx {
 // internal.h): no x / mean - 1 matrix is written or read, and integer counts run on one f16 term.  A/B knob: VAE_NO_XDIRECT.
 bool xdirect(const vae_step_config& c, const Ctx& k, const void* x, int64_t ldx) {
   static const bool off = getenv("VAE_NO_XDIRECT") != nullptr;
-  if (off || !k.fx() || !vae_mid_supported(c) || c.input_dropout_rate > 0.f || c.x_dtype != VAE_X_F32) return false;
-  if (ldx % 4 != 0 || !vae_aligned16(x) || ldx >= (1 << 22)) return false;
+  if (off || !k.fx() || !vae_mid_supported(c) || c.input_dropout_rate > 0.f) return false;
+  if (c.x_dtype == VAE_X_U8) {   // the products read an fp32 copy made in the workspace (one cast launch; B bounds its grid)
+    if (ldx % 4 != 0 || (reinterpret_cast<uintptr_t>(x) & 3u) != 0 || c.B >= 65536) return false;
+  } else if (ldx % 4 != 0 || !vae_aligned16(x) || ldx >= (1 << 22)) return false;
   const int64_t HE = c.H + c.Hl;
   return vae_gemm_tile_pipeline_ok(VAE_NT, c.B, HE, c.G) && vae_gemm_tile_pipeline_ok(VAE_TN, HE, c.G, c.B);
+}
+
+// the fp32 counts of a count-operand step: the caller's rows, or (uint8 batch) their copy in the slice that otherwise holds x / mean - 1
+void set_count_rows(Ctx& k, const void* xv, int64_t ldx) {
+  if (k.c.x_dtype == VAE_X_U8) { k.xf = k.ws + k.lo.xn; k.ldxf = k.lo.ld_xn; }
+  else { k.xf = (const float*)xv; k.ldxf = ldx; }
 }
 
 // ... and nobody reads the counts ahead of the forward product: it takes them as exact in one unscaled f16 term, gathers
@@ -324,6 +334,10 @@ extern "C" int vae_elbo_step_forward(const vae_step_config* cfg, const vae_step_
   k.xd = xdirect(c, k, xv, ldx);
   const int64_t B = c.B, G = c.G, H = c.H, Hl = c.Hl, L = c.L, Hd = c.Hd, HE = c.H + c.Hl;
   const int64_t NH = c.zinb ? 2 * G : G;
+  if (k.xd) {
+    set_count_rows(k, xv, ldx);
+    if (c.x_dtype == VAE_X_U8) TRY(vae_cast_u8_f32(xv, ldx, B, G, ws + lo.xn, lo.ld_xn, stream));
+  }
 
   bool table_built = false;   // the gene table rides in another launch where one is at hand
   if (k.fx() && k.wext()) {  // the caller keeps the weight maxima current: only the gene table is left to build (below)
@@ -345,7 +359,7 @@ extern "C" int vae_elbo_step_forward(const vae_step_config* cfg, const vae_step_
   if (xopt) {
     // (nothing here: the forward product gathers the statistics itself)
   } else if (k.xd)   // raw counts go to the products: the cells' means, maxima and exactness flags, and sum_g W (one launch)
-    TRY(vae_row_stats((const float*)xv, ldx, B, G, ws + lo.mean, k.am(AM_XN), ws + lo.xflags, p->enc_w0, k.ldw(), HE, ws + lo.wsum, stream));
+    TRY(vae_row_stats(k.xf, k.ldxf, B, G, ws + lo.mean, k.am(AM_XN), ws + lo.xflags, p->enc_w0, k.ldw(), HE, ws + lo.wsum, stream));
   else
     TRY(vae_normalize_rows_ex(xv, c.x_dtype, ldx, B, G, ws + lo.mean, ws + lo.xn, k.hb(), lo.ld_xn, k.am(AM_XN), stream));
   // GeneDropout (training): the z-encoder reads its own masked + normalised counts, the library encoder xn
@@ -367,17 +381,17 @@ extern "C" int vae_elbo_step_forward(const vae_step_config* cfg, const vae_step_
     } else if (xopt) {   // the same, optimistically: product first, statistics on the way, repeated only if they object
       VaeGemmCounts xc{nullptr, 0, nullptr};
       xc.mode = 1; xc.xs_sum = ws + lo.xs_sum; xc.ws_sum = ws + lo.ws_sum; xc.xs_max = k.am(AM_XN); xc.xs_flag = ws + lo.xflags; xc.xs_n = (int)(B * VAE_NORM_WAVES);
-      TRY(vae_gemm_f16x2(VAE_NT, B, HE, G, (const float*)xv, ldx, k.am(AM_XN), k.an(AM_XN), p->enc_w0, k.ldw(), k.am(AM_WENC),
+      TRY(vae_gemm_f16x2(VAE_NT, B, HE, G, k.xf, k.ldxf, k.am(AM_XN), k.an(AM_XN), p->enc_w0, k.ldw(), k.am(AM_WENC),
                          k.an(AM_WENC), nullptr, HE, nullptr, 0, ws + lo.scratch, lo.scratch_floats * 4, stream, &nslab, nullptr, &xc));
       if (nslab > 64) return vae_set_error(VAE_ERR_LAUNCH, "vae_elbo_step_forward: %d slabs of row sums", nslab);
       int nslab2 = 0;
       xc.mode = 2; xc.flags = ws + lo.xflags; xc.n_flags = xc.xs_n; xc.mean_out = ws + lo.mean; xc.wsum_out = ws + lo.wsum;
-      TRY(vae_gemm_f16x2(VAE_NT, B, HE, G, (const float*)xv, ldx, k.am(AM_XN), k.an(AM_XN), p->enc_w0, k.ldw(), k.am(AM_WENC),
+      TRY(vae_gemm_f16x2(VAE_NT, B, HE, G, k.xf, k.ldxf, k.am(AM_XN), k.an(AM_XN), p->enc_w0, k.ldw(), k.am(AM_WENC),
                          k.an(AM_WENC), nullptr, HE, nullptr, 0, ws + lo.scratch, lo.scratch_floats * 4, stream, &nslab2, nullptr, &xc));
       if (nslab2 != nslab) return vae_set_error(VAE_ERR_LAUNCH, "vae_elbo_step_forward: slab counts differ (%d, %d)", nslab, nslab2);
     } else if (k.xd) {   // x W^T of the raw counts; the middle applies 1 / mean and - sum_g W
       const VaeGemmCounts xc{ws + lo.xflags, (int)(B * VAE_NORM_WAVES), nullptr};
-      TRY(vae_gemm_f16x2(VAE_NT, B, HE, G, (const float*)xv, ldx, k.am(AM_XN), k.an(AM_XN), p->enc_w0, k.ldw(), k.am(AM_WENC),
+      TRY(vae_gemm_f16x2(VAE_NT, B, HE, G, k.xf, k.ldxf, k.am(AM_XN), k.an(AM_XN), p->enc_w0, k.ldw(), k.am(AM_WENC),
                          k.an(AM_WENC), nullptr, HE, nullptr, 0, ws + lo.scratch, lo.scratch_floats * 4, stream, &nslab, nullptr, &xc));
     } else {
       TRY(k.enc_fwd(HE, ws + lo.xn, AM_XN, p->enc_w0, nullptr, HE, nullptr, &nslab));
@@ -515,6 +529,7 @@ extern "C" int vae_elbo_step_backward_slabs(const vae_step_config* cfg, const va
   const vae_step_config& c = *cfg;
   Ctx k{c, ws, lo, stream, p, false};
   k.xd = xdirect(c, k, xv, ldx);
+  if (k.xd) set_count_rows(k, xv, ldx);   // (a uint8 batch: the forward's fp32 copy is still in the workspace)
   const int64_t B = c.B, G = c.G, H = c.H, Hl = c.Hl, L = c.L, Hd = c.Hd, HE = c.H + c.Hl;
   const int64_t NH = c.zinb ? 2 * G : G;
   // d loss / d ll[b] = -coeff/B ; d loss / d kl[b] = coeff*kl_weight/B   (task.py:202,489)
@@ -714,7 +729,7 @@ extern "C" int vae_elbo_step_backward_slabs(const vae_step_config* cfg, const va
       TRY(k.enc_wgrad(rows, dpre_i, HE, r0 < H ? ws + lo.xn_z : ws + lo.xn, r0 < H ? AM_XNZ : AM_XN, dw_i));
     } else if (k.xd) {   // dW = (dpre / mean)^T x - colsum(dpre) 1^T; colsum(dpre) = the first-layer bias gradient, final by now
       const VaeGemmCounts xc{ws + lo.xflags, (int)(B * VAE_NORM_WAVES), g->enc_b0 + r0};   // (the flags the forward left: one term of x when all clear)
-      TRY(vae_gemm_f16x2(VAE_TN, rows, G, B, ws + lo.dpre_s + r0, HE, k.am(AM_DPRE), k.an(AM_DPRE), (const float*)xv, ldx, k.am(AM_XN),
+      TRY(vae_gemm_f16x2(VAE_TN, rows, G, B, ws + lo.dpre_s + r0, HE, k.am(AM_DPRE), k.an(AM_DPRE), k.xf, k.ldxf, k.am(AM_XN),
                          k.an(AM_XN), dw_i, k.ldw(), nullptr, 0, ws + lo.scratch, lo.scratch_floats * 4, stream, nullptr, nullptr, &xc));
     } else {
       TRY(k.enc_wgrad(rows, dpre_i, HE, ws + lo.xn, AM_XN, dw_i));
