@@ -499,7 +499,8 @@ def main():
                        "counts": args.counts, "bf16_activations": bf16_st,
                        "count_operand_path": ({0: "normalised matrix", 1: "raw counts behind a statistics launch",
                                                2: "raw counts, optimistic (no launch ahead of the first product)"}
-                                              .get(step.counts_path(B)) + ("" if args.counts == "f32" else " over an fp32 copy of the uint8 batch (one cast launch)")),
+                                              .get(step.counts_path(B)) + ("" if args.counts == "f32" else ", read from the uint8 rows" if step.counts_path(B) == 2 and not os.environ.get("VAE_NO_XU8")
+                                                 else " over an fp32 copy of the uint8 batch (one cast launch)")),
                        "weight_operand_scales": ("scanned by every forward" if fopt is None else
                                                  "maxima kept by the fused optimiser (vae_adamw_step_wmax)" if fopt.weight_maxima is not None
                                                  else "bf16 images kept by the fused optimiser (vae_adamw_step_bf16)")},

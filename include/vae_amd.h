@@ -433,8 +433,10 @@ int vae_elbo_step_bf16_activations(const vae_step_config* cfg);
  * forward product takes them as exact in one unscaled f16 term (integer counts below 2048 are), gathers the cells' sums,
  * maxima and exactness flags while they pass, and a gated launch behind it finishes the means and sum_g W and repeats the
  * product in the scaled two-term form only when a flag came up.  uint8 counts (x_dtype = VAE_X_U8, 4-byte aligned rows)
- * take forms 1 / 2 over an fp32 copy that one cast launch leaves in the workspace (the likelihood kernels keep reading
- * the uint8 rows).  (Environment VAE_NO_XOPT / VAE_NO_XDIRECT: A/B knobs.)                                           */
+ * take the same forms: in form 2 the two products read the uint8 rows as their operand (four counts per 4-byte load,
+ * expanded in registers), in form 1 -- and for shapes without those kernels -- over an fp32 copy that one cast launch
+ * leaves in the workspace; the likelihood kernels read the uint8 rows in every case.
+ * (Environment VAE_NO_XOPT / VAE_NO_XDIRECT / VAE_NO_XU8: A/B knobs.)                                                */
 int vae_elbo_step_counts_path(const vae_step_config* cfg);
 
 /* named slices of the workspace that a caller may read after the forward (offsets in floats)      */

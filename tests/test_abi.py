@@ -132,7 +132,7 @@ def test_counts_path_query(monkeypatch):
     assert path(precision=3) == 2                              # cfg2, two f16 terms: optimistic, no launch ahead of the product
     assert path(precision=3, fractional_counts=1) == 1         # a mixup loader's hint: behind the statistics launch
     assert path(precision=3, G=20008) == 1                     # G % 32 != 0: the optimistic kernel takes whole K steps only
-    assert path(precision=3, x_dtype=1) == 2                   # uint8 counts: the same, over an fp32 copy made by one cast launch
+    assert path(precision=3, x_dtype=1) == 2                   # uint8 counts: the same (the products read the uint8 rows)
     assert path(precision=3, input_dropout_rate=0.5) == 0      # GeneDropout: the z-encoder reads its own masked counts
     assert path(precision=3, n_layers=2) == 0                  # the count operand belongs to the fused middle (one hidden layer)
     assert path(precision=0) == 0 and path(precision=1) == 0   # exact fp32 / bf16 modes

@@ -346,6 +346,15 @@ def test_optimistic_count_product_and_its_repeat(counts):
             if o_grads[k] is None:
                 continue
             assert rel_err(v.cpu().numpy(), o_grads[k].numpy()) < TOL_GRAD, (k, rep)
+    if counts == "integer":   # the same batch as uint8 rows: the products expand them in registers -- the same bits
+        xc = x.clamp(max=255)
+        out_f = step.run(xc.cuda(), ezd, eld)
+        ref = {k: out_f[k].clone() for k in ("recon", "qz_m", "library", "kl_z")}
+        g_ref = arena.flat_grad.clone()
+        out_8 = step.run(xc.to(torch.uint8).cuda(), ezd, eld)
+        for k, v in ref.items():
+            assert torch.equal(out_8[k], v), k
+        assert torch.equal(arena.flat_grad, g_ref)
     if counts == "fractional":   # the hint that skips the optimistic attempt (vae_step_config.fractional_counts): same step
         ref = {k: out[k].clone() for k in ("recon", "qz_m", "library")}
         g_ref = arena.flat_grad.clone()

@@ -919,7 +919,9 @@ __device__ __forceinline__ void split_pair_f16(float a0, float a1, float s0, flo
 #endif
 template <int LAYOUT, int BM, int BN, int WAVES_M, int NP, int IO = 0, bool ROWSC = false, int XONE = 0>
 __global__ __launch_bounds__(256, ((VAE_X3_PIPE && NP <= 2 && BM == 128 && BN == 128) || ROWSC || XONE != 0 || BN > 160 ? 2 : (NP <= 2 ? 3 : 2))) void gemm_x3_kernel(GemmArgs g) {
-  static_assert(IO == 0 || NP == 1, "bf16 storage goes with the one-plane bf16 product");
+  static_assert((IO & 7) == 0 || NP == 1, "bf16 storage goes with the one-plane bf16 product");
+  static_assert((IO & 24) == 0 || (NP == 2 && (IO & 7) == 0 && ((IO == 8 && LAYOUT == NT) || (IO == 16 && LAYOUT == TN))),
+                "uint8 counts: the A operand of the NT or the B operand of the TN two-f16-term product");
   static_assert(!ROWSC || (LAYOUT == TN && NP == 2), "per-row scales: the two-f16-term wgrad");
   static_assert(XONE == 0 || (NP == 2 && !ROWSC && (((XONE == 1 || XONE == 3) && LAYOUT == NT) || (XONE == 2 && LAYOUT == TN))),
                 "one-term count operand: A of the two-f16-term NT product or B of the TN product");
@@ -930,10 +932,13 @@ __global__ __launch_bounds__(256, ((VAE_X3_PIPE && NP <= 2 && BM == 128 && BN ==
   constexpr bool PIPE = VAE_X3_PIPE && NP <= 2 && BM == 128 && BN == 128;   // the 160-wide tiles do not fit two waves per SIMD
   constexpr int STAGES = PIPE ? 2 : 1;
   constexpr bool ABF = (IO & 1) != 0, BBF = (IO & 2) != 0, CBF = (IO & 4) != 0;
-  using TA = std::conditional_t<ABF, uint16_t, float>;
-  using TB = std::conditional_t<BBF, uint16_t, float>;
-  using RA = std::conditional_t<ABF, uint2, float4>;   // four consecutive elements
-  using RB = std::conditional_t<BBF, uint2, float4>;
+  // IO bits 8 / 16: the count operand (A of NT / B of TN) is the uint8 store itself (create_dataset.py:131-142): four counts
+  // per 4-byte load, expanded in registers on their way into the f16 plane -- no fp32 copy of the batch exists
+  constexpr bool AU8 = (IO & 8) != 0, BU8 = (IO & 16) != 0;
+  using TA = std::conditional_t<AU8, uint8_t, std::conditional_t<ABF, uint16_t, float>>;
+  using TB = std::conditional_t<BU8, uint8_t, std::conditional_t<BBF, uint16_t, float>>;
+  using RA = std::conditional_t<AU8, uint32_t, std::conditional_t<ABF, uint2, float4>>;   // four consecutive elements
+  using RB = std::conditional_t<BU8, uint32_t, std::conditional_t<BBF, uint2, float4>>;
   constexpr bool A_KC = (LAYOUT != TN);
   constexpr bool B_KC = (LAYOUT == NT);
   constexpr int WAVES_N = 4 / WAVES_M;
@@ -1147,8 +1152,13 @@ __global__ __launch_bounds__(256, ((VAE_X3_PIPE && NP <= 2 && BM == 128 && BN ==
       *reinterpret_cast<uint2*>(base + off) = vin;
       return;
     } else {
-    const float4 v = vin;
-    const float f[4] = {v.x, v.y, v.z, v.w};
+    float f[4];
+    if constexpr (std::is_same_v<std::decay_t<decltype(vin)>, uint32_t>) {   // four uint8 counts
+      f[0] = (float)(vin & 0xffu); f[1] = (float)((vin >> 8) & 0xffu); f[2] = (float)((vin >> 16) & 0xffu); f[3] = (float)(vin >> 24);
+    } else {
+      const float4 v = vin;
+      f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
+    }
     if (NP == 2 && VAE_X3_MIXCVT) {   // the same two terms, by hand: 2 instructions per element instead of the compiler's ~ 4
       const float sc[4] = {sc4.x, sc4.y, sc4.z, sc4.w};
       uint2 h4, l4;
@@ -1351,8 +1361,13 @@ __global__ __launch_bounds__(256, ((VAE_X3_PIPE && NP <= 2 && BM == 128 && BN ==
     if constexpr (XOPT && std::is_same_v<RB, float4>) wsr[j] += (r.x + r.y) + (r.z + r.w);
   };
   (void)ws_take; (void)wmine;
-  auto xs_take = [&](int pidx, const RA& r) {
-    if constexpr (XOPT && std::is_same_v<RA, float4>) {
+  auto xs_take = [&](int pidx, const RA& rr) {
+    if constexpr (XOPT && (std::is_same_v<RA, float4> || std::is_same_v<RA, uint32_t>)) {
+      float4 r;
+      if constexpr (std::is_same_v<RA, uint32_t>)
+        r = make_float4((float)(rr & 0xffu), (float)((rr >> 8) & 0xffu), (float)((rr >> 16) & 0xffu), (float)(rr >> 24));
+      else
+        r = rr;
       xs[pidx] += (r.x + r.y) + (r.z + r.w);
       xam = fmaxf(fmaxf(xam, fmaxf(fabsf(r.x), fabsf(r.y))), fmaxf(fabsf(r.z), fabsf(r.w)));
       xbits |= (__float_as_uint(r.x) | __float_as_uint(r.y)) | (__float_as_uint(r.z) | __float_as_uint(r.w));
@@ -1940,8 +1955,9 @@ int gemm_impl(int layout, int precision, int64_t M, int64_t N, int64_t K, const 
   g.lda = lda; g.ldb = ldb; g.ldc = ldc;
   g.M = (int)M; g.N = (int)N; g.K = (int)K;
   g.accumulate = accumulate;
-  g.vecA = (lda % 4 == 0) && ((io & 1) ? (reinterpret_cast<uintptr_t>(A) & 7u) == 0 : vae_aligned16(A));
-  g.vecB = (ldb % 4 == 0) && ((io & 2) ? (reinterpret_cast<uintptr_t>(B) & 7u) == 0 : vae_aligned16(B));
+  const bool a_u8 = xo && xo->x_u8 && layout == NT, b_u8 = xo && xo->x_u8 && layout == TN;   // the count operand is the uint8 store
+  g.vecA = (lda % 4 == 0) && (a_u8 ? (reinterpret_cast<uintptr_t>(A) & 3u) == 0 : (io & 1) ? (reinterpret_cast<uintptr_t>(A) & 7u) == 0 : vae_aligned16(A));
+  g.vecB = (ldb % 4 == 0) && (b_u8 ? (reinterpret_cast<uintptr_t>(B) & 3u) == 0 : (io & 2) ? (reinterpret_cast<uintptr_t>(B) & 7u) == 0 : vae_aligned16(B));
   g.group_m = 0;
   const Plan plan = make_plan(g.M, g.N, g.K, io == 0 && !rsc && !xo);   // (bf16 storage and per-row scales exist on the 128-wide tiles only)
   static const int no_dma = getenv("VAE_GEMM_NO_DMA") ? atoi(getenv("VAE_GEMM_NO_DMA")) : 0;  // tuning knob
@@ -1968,6 +1984,8 @@ int gemm_impl(int layout, int precision, int64_t M, int64_t N, int64_t K, const 
                       (!xo->flags || (xo->n_flags > 0 && vae_aligned16(xo->flags))) &&
                       (!xo->row_sub || (layout == TN && !slabs_out && !accumulate))),
               "vae_gemm: the count-operand form needs a two-f16-term NT / TN product on the tile pipeline with operand maxima");
+  VAE_REQUIRE(!(a_u8 || b_u8) || (dma_ok && bm == 128 && bn == 128 && io == 0 && (a_u8 ? xopt : (VAE_TN_XONE && xo->flags != nullptr))),
+              "vae_gemm: uint8 counts as the operand need the 128 x 128 count kernels (vae_gemm_counts_u8_ok)");
   if (xo) { g.xone_flags = xo->flags; g.n_xone = xo->n_flags; g.row_sub = xo->row_sub; }
   g.xs_sum = g.xs_max = g.xs_flag = g.ws_sum = g.mean_out = g.wsum_out = nullptr;
   g.xs_n = g.gate = 0;
@@ -2100,6 +2118,8 @@ int gemm_impl(int layout, int precision, int64_t M, int64_t N, int64_t K, const 
       if (layout == NT) VAE_X3_LAUNCH(NT, 1);
       else if (layout == NN) VAE_X3_LAUNCH(NN, 1);
       else VAE_X3_LAUNCH(TN, 1);
+    } else if (xopt && a_u8) {   // ... straight from the uint8 store
+      hipLaunchKernelGGL((gemm_x3_kernel<NT, 128, 128, 2, 2, 8, false, 3>), grid1, dim3(256), 0, st, g);
     } else if (xopt) {   // counts taken as exact in one unscaled f16 term, checked on the way (GemmArgs::xs_*)
       hipLaunchKernelGGL((gemm_x3_kernel<NT, 128, 128, 2, 2, 0, false, 3>), grid1, dim3(256), 0, st, g);
     } else if (xo && xo->flags && layout == NT) {   // two f16 terms, the count operand A on ONE term when every count is exact in it
@@ -2110,7 +2130,8 @@ int gemm_impl(int layout, int precision, int64_t M, int64_t N, int64_t K, const 
       else if (bn == 160)         hipLaunchKernelGGL((gemm_x3_kernel<NT, 128, 160, 4, 2, 0, false, 1>), grid1, dim3(256), 0, st, g);
       else                        hipLaunchKernelGGL((gemm_x3_kernel<NT, 160, 128, 1, 2, 0, false, 1>), grid1, dim3(256), 0, st, g);
     } else if (VAE_TN_XONE && xo && xo->flags && layout == TN && bm == 128 && bn == 128) {   // ... and the count operand B of the weight gradient
-      hipLaunchKernelGGL((gemm_x3_kernel<TN, 128, 128, 2, 2, 0, false, 2>), grid1, dim3(256), 0, st, g);
+      if (b_u8) hipLaunchKernelGGL((gemm_x3_kernel<TN, 128, 128, 2, 2, 16, false, 2>), grid1, dim3(256), 0, st, g);
+      else      hipLaunchKernelGGL((gemm_x3_kernel<TN, 128, 128, 2, 2, 0, false, 2>), grid1, dim3(256), 0, st, g);
     } else if (rsc) {   // two f16 terms, one scale per product row (the decoder weight gradient)
       if (bm == 128 && bn == 128) hipLaunchKernelGGL((gemm_x3_kernel<TN, 128, 128, 2, 2, 0, true>), grid1, dim3(256), 0, st, g);
       else if (bn == 160)         hipLaunchKernelGGL((gemm_x3_kernel<TN, 128, 160, 4, 2, 0, true>), grid1, dim3(256), 0, st, g);
@@ -2247,6 +2268,13 @@ bool vae_gemm_counts_optimistic_ok(int64_t M, int64_t N, int64_t K, int n_stat) 
   const int ktiles = (int)((K + BK - 1) / BK), tps = (ktiles + d.split - 1) / d.split, split = (ktiles + tps - 1) / tps;
   const int64_t tn = (N + 127) / 128;
   return (int64_t)((M + 127) / 128) * (tn < 4 ? tn : 4) * split <= n_stat;
+}
+// whether the TN count-operand product (M, N, K) = (rows of the first-layer weight, genes, cells) runs on the 128 x 128 tiles
+// without a K split -- where the kernel exists that reads its count operand from the uint8 store
+bool vae_gemm_counts_u8_tn_ok(int64_t M, int64_t N, int64_t K) {
+  if (!VAE_TN_XONE || !vae_gemm_tile_pipeline_ok(TN, M, N, K) || make_plan((int)M, (int)N, (int)K, false).tile != 128) return false;
+  const DmaPlan d = make_dma_plan((int)M, (int)N, (int)K, false);
+  return d.bm == 128 && d.bn == 128;
 }
 // whether fp32 operands with 16-byte aligned rows of this shape run the 128-wide tile pipeline (split / LDS-DMA kernels)
 bool vae_gemm_tile_pipeline_ok(int layout, int64_t M, int64_t N, int64_t K) {

@@ -51,10 +51,15 @@ struct VaeGemmCounts {
   float* xs_flag = nullptr;
   int xs_n = 0;
   float* ws_sum = nullptr;   // per-slab row sums of B [slab][N]
+  // != 0: the count operand (A of NT in mode 1, B of TN with flags) is the uint8 store itself (elements = bytes, rows 4-byte
+  // aligned): it is expanded in registers on its way into the f16 plane.  The mode 2 launch never reads it (uint8 counts
+  // are exact, its gate stays shut); shapes: vae_gemm_counts_optimistic_ok (NT), vae_gemm_counts_u8_tn_ok (TN).
+  int x_u8 = 0;
   float* mean_out = nullptr;
   float* wsum_out = nullptr;
 };
 bool vae_gemm_counts_optimistic_ok(int64_t M, int64_t N, int64_t K, int n_stat);
+bool vae_gemm_counts_u8_tn_ok(int64_t M, int64_t N, int64_t K);
 int vae_gemm_f16x2(int layout, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* max_a, int n_max_a,
                    const float* B, int64_t ldb, const float* max_b, int n_max_b, float* C, int64_t ldc, const float* bias,
                    int accumulate, float* workspace, int64_t workspace_bytes, void* stream, int* slabs_out,

@@ -168,6 +168,7 @@ struct Ctx {
   bool xd;                       // count-operand form of the two encoder products (xdirect() below)
   const float* xf = nullptr;     // ... the fp32 counts they read: the caller's, or the copy of a uint8 batch in lo.xn
   int64_t ldxf = 0;
+  bool xu8 = false;              // ... or no copy at all: the products expand the uint8 rows themselves (xcounts_u8() below)
   uint16_t* h16(int64_t off) const { return reinterpret_cast<uint16_t*>(ws + off); }
   // the two-f16-term pipeline needs 16-byte rows everywhere; ragged shapes run as VAE_FP32
   bool hb() const { return bf16_storage(c); }   // logits / logit gradients held as bf16
@@ -257,6 +258,13 @@ bool xoptimistic(const vae_step_config& c, const Ctx& k) {
   return !off && k.xd && !c.fractional_counts && vae_gemm_counts_optimistic_ok(c.B, c.H + c.Hl, c.G, (int)(c.B * VAE_NORM_WAVES));
 }
 
+// A uint8 batch whose forward product runs optimistically needs no fp32 copy: that kernel and the 128 x 128 weight-gradient
+// kernel read the uint8 rows as their operand (four counts per 4-byte load).  A/B knob: VAE_NO_XU8 (then: one cast launch).
+bool xcounts_u8(const vae_step_config& c, const Ctx& k) {
+  static const bool off = getenv("VAE_NO_XU8") != nullptr;
+  return !off && c.x_dtype == VAE_X_U8 && xoptimistic(c, k);
+}
+
 int check_common(const vae_step_config* cfg, const void* a, const void* b, const void* x, int64_t ldx,
                  const float* eps_z, const float* eps_l, float* ws, int64_t ws_bytes, Layout* lo, const char* who) {
   if (!cfg || !a || !b || !x || !eps_z || !eps_l || !ws) return vae_set_error(VAE_ERR_ARG, "%s: null pointer", who);
@@ -336,7 +344,8 @@ extern "C" int vae_elbo_step_forward(const vae_step_config* cfg, const vae_step_
   const int64_t NH = c.zinb ? 2 * G : G;
   if (k.xd) {
     set_count_rows(k, xv, ldx);
-    if (c.x_dtype == VAE_X_U8) TRY(vae_cast_u8_f32(xv, ldx, B, G, ws + lo.xn, lo.ld_xn, stream));
+    k.xu8 = xcounts_u8(c, k);
+    if (c.x_dtype == VAE_X_U8 && !k.xu8) TRY(vae_cast_u8_f32(xv, ldx, B, G, ws + lo.xn, lo.ld_xn, stream));
   }
 
   bool table_built = false;   // the gene table rides in another launch where one is at hand
@@ -381,8 +390,11 @@ extern "C" int vae_elbo_step_forward(const vae_step_config* cfg, const vae_step_
     } else if (xopt) {   // the same, optimistically: product first, statistics on the way, repeated only if they object
       VaeGemmCounts xc{nullptr, 0, nullptr};
       xc.mode = 1; xc.xs_sum = ws + lo.xs_sum; xc.ws_sum = ws + lo.ws_sum; xc.xs_max = k.am(AM_XN); xc.xs_flag = ws + lo.xflags; xc.xs_n = (int)(B * VAE_NORM_WAVES);
-      TRY(vae_gemm_f16x2(VAE_NT, B, HE, G, k.xf, k.ldxf, k.am(AM_XN), k.an(AM_XN), p->enc_w0, k.ldw(), k.am(AM_WENC),
-                         k.an(AM_WENC), nullptr, HE, nullptr, 0, ws + lo.scratch, lo.scratch_floats * 4, stream, &nslab, nullptr, &xc));
+      xc.x_u8 = k.xu8 ? 1 : 0;
+      TRY(vae_gemm_f16x2(VAE_NT, B, HE, G, k.xu8 ? (const float*)xv : k.xf, k.xu8 ? ldx : k.ldxf, k.am(AM_XN), k.an(AM_XN), p->enc_w0,
+                         k.ldw(), k.am(AM_WENC), k.an(AM_WENC), nullptr, HE, nullptr, 0, ws + lo.scratch, lo.scratch_floats * 4, stream,
+                         &nslab, nullptr, &xc));
+      xc.x_u8 = 0;   // (the gated launch never reads the counts of a uint8 batch -- they are exact: k.xf is its placeholder)
       if (nslab > 64) return vae_set_error(VAE_ERR_LAUNCH, "vae_elbo_step_forward: %d slabs of row sums", nslab);
       int nslab2 = 0;
       xc.mode = 2; xc.flags = ws + lo.xflags; xc.n_flags = xc.xs_n; xc.mean_out = ws + lo.mean; xc.wsum_out = ws + lo.wsum;
@@ -529,7 +541,10 @@ extern "C" int vae_elbo_step_backward_slabs(const vae_step_config* cfg, const va
   const vae_step_config& c = *cfg;
   Ctx k{c, ws, lo, stream, p, false};
   k.xd = xdirect(c, k, xv, ldx);
-  if (k.xd) set_count_rows(k, xv, ldx);   // (a uint8 batch: the forward's fp32 copy is still in the workspace)
+  if (k.xd) {   // (a uint8 batch: the forward's fp32 copy is still in the workspace -- unless the products read the uint8 rows)
+    set_count_rows(k, xv, ldx);
+    k.xu8 = xcounts_u8(c, k);
+  }
   const int64_t B = c.B, G = c.G, H = c.H, Hl = c.Hl, L = c.L, Hd = c.Hd, HE = c.H + c.Hl;
   const int64_t NH = c.zinb ? 2 * G : G;
   // d loss / d ll[b] = -coeff/B ; d loss / d kl[b] = coeff*kl_weight/B   (task.py:202,489)
@@ -721,6 +736,7 @@ extern "C" int vae_elbo_step_backward_slabs(const vae_step_config* cfg, const va
     nsl = n_enc_slabs;
     rb = enc_row_bounds;
   }
+  bool u8_copied = false;
   for (int i = 0; i < nsl; ++i) {
     const int64_t r0 = rb[i], rows = rb[i + 1] - rb[i];
     const float* dpre_i = ws + lo.dpre_enc0 + r0;
@@ -728,8 +744,16 @@ extern "C" int vae_elbo_step_backward_slabs(const vae_step_config* cfg, const va
     if (c.input_dropout_rate > 0.f) {  // GeneDropout: each encoder's weight gradient over its own input
       TRY(k.enc_wgrad(rows, dpre_i, HE, r0 < H ? ws + lo.xn_z : ws + lo.xn, r0 < H ? AM_XNZ : AM_XN, dw_i));
     } else if (k.xd) {   // dW = (dpre / mean)^T x - colsum(dpre) 1^T; colsum(dpre) = the first-layer bias gradient, final by now
-      const VaeGemmCounts xc{ws + lo.xflags, (int)(B * VAE_NORM_WAVES), g->enc_b0 + r0};   // (the flags the forward left: one term of x when all clear)
-      TRY(vae_gemm_f16x2(VAE_TN, rows, G, B, ws + lo.dpre_s + r0, HE, k.am(AM_DPRE), k.an(AM_DPRE), k.xf, k.ldxf, k.am(AM_XN),
+      VaeGemmCounts xc{ws + lo.xflags, (int)(B * VAE_NORM_WAVES), g->enc_b0 + r0};   // (the flags the forward left: one term of x when all clear)
+      bool u8_rows = k.xu8 && vae_gemm_counts_u8_tn_ok(rows, G, B);
+      if (k.xu8 && !u8_rows && !u8_copied) {   // a row slab whose plan has no uint8 kernel: the fp32 copy after all, made once
+        TRY(vae_cast_u8_f32(xv, ldx, B, G, ws + lo.xn, lo.ld_xn, stream));
+        u8_copied = true;
+      }
+      xc.x_u8 = u8_rows ? 1 : 0;
+      const float* xrows = u8_rows ? (const float*)xv : k.xf;
+      const int64_t ldrows = u8_rows ? ldx : k.ldxf;
+      TRY(vae_gemm_f16x2(VAE_TN, rows, G, B, ws + lo.dpre_s + r0, HE, k.am(AM_DPRE), k.an(AM_DPRE), xrows, ldrows, k.am(AM_XN),
                          k.an(AM_XN), dw_i, k.ldw(), nullptr, 0, ws + lo.scratch, lo.scratch_floats * 4, stream, nullptr, nullptr, &xc));
     } else {
       TRY(k.enc_wgrad(rows, dpre_i, HE, ws + lo.xn, AM_XN, dw_i));
