@@ -481,6 +481,18 @@ def main():
                         "right after it"}
     loss = float(out["loss"])
     bf16_st = step.bf16_activations(B)
+    # Row f2 beside the headline: the same K steps fed the reference's ON-DISK format -- uint8 counts (create_dataset.py:131-142)
+    u8_side = None
+    if args.counts == "f32" and world == 1 and reducer is None and cell_decoder is None and not args.scan_weights:
+        x_keep = x_all
+        x_all = x_keep.clamp(max=255).to(torch.uint8)
+        for i in range(2):
+            one_step(i)
+        ms_u8 = timed_loop()
+        x_all = x_keep
+        u8_side = {"ms_per_step": ms_u8, "value": B / (ms_u8 * 1e-3),
+                   "note": "the same K steps right after the headline loops, batches handed over as uint8 (counts clamped to 255, as "
+                           "the reference's store is); gradients are bit-identical to fp32 counts of the same values"}
 
     result = None
     if rank == 0:
@@ -508,6 +520,8 @@ def main():
         }
         if side is not None:
             result["scan_weights"] = side
+        if u8_side is not None:
+            result["uint8_counts"] = u8_side
     if rank == 0 and not args.no_breakdown:
         xb = x_all[:B].float()
         ks = kernel_breakdown(arena, cfg, xb, precision, bf16_st, step.counts_path(B))
