@@ -131,7 +131,8 @@ def test_counts_path_query(monkeypatch):
     path = lambda **kw: lib.vae_elbo_step_counts_path(C.byref(_lib.StepConfig(**{**base, **kw})))  # noqa: E731
     assert path(precision=3) == 2                              # cfg2, two f16 terms: optimistic, no launch ahead of the product
     assert path(precision=3, fractional_counts=1) == 1         # a mixup loader's hint: behind the statistics launch
-    assert path(precision=3, G=20008) == 1                     # G % 32 != 0: the optimistic kernel takes whole K steps only
+    assert path(precision=3, G=20008) == 2                     # (a partial last K step is fine)
+    assert path(precision=3, G=20006) == 0                     # rows that are not 16-byte multiples: the exact fp32 mode altogether
     assert path(precision=3, x_dtype=1) == 2                   # uint8 counts: the same (the products read the uint8 rows)
     assert path(precision=3, input_dropout_rate=0.5) == 0      # GeneDropout: the z-encoder reads its own masked counts
     assert path(precision=3, n_layers=2) == 0                  # the count operand belongs to the fused middle (one hidden layer)

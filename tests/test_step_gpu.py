@@ -304,9 +304,9 @@ def test_midsize_against_oracle(likelihood, precision):
         assert rel_err(v.cpu().numpy(), o_grads[k].numpy()) < TOL_GRAD, k
 
 
-@pytest.mark.parametrize("counts", ["integer", "fractional", "large", "tiny", "one_bad_cell"])
+@pytest.mark.parametrize("counts", ["integer", "fractional", "large", "tiny", "one_bad_cell", "ragged_genes"])
 def test_optimistic_count_product_and_its_repeat(counts):
-    """G % 32 == 0, a two-f16-term step on the fused middle: no launch reads the counts ahead of the first encoder product
+    """A two-f16-term step on the fused middle: no launch reads the counts ahead of the first encoder product
     (step.hip, xoptimistic).  The product takes them as exact in one unscaled f16 term -- true of integer counts below 2048
     -- and gathers the cells' sums, maxima and exactness flags on the way; the gated launch behind it finishes the means and
     sum_g W and REPEATS the product in the scaled two-term form when a flag came up: fractional counts (mixup,
@@ -316,6 +316,8 @@ def test_optimistic_count_product_and_its_repeat(counts):
     from vae_amd.arena import ParamArena
     from vae_amd.step import ElboStep
     B, G, H, Hd, Hl, L = 160, 4096, 128, 128, 128, 10
+    if counts == "ragged_genes":
+        G = 4100      # G % 32 = 4: the last slab ends in a partial K step, whose counts enter the statistics too
     p = O.init_params(G, H, Hd, Hl, L, 1, seed=25)
     x = O.synthetic_counts(B, G, seed=25, zero_inflate=0.3)
     if counts == "fractional":
@@ -346,7 +348,7 @@ def test_optimistic_count_product_and_its_repeat(counts):
             if o_grads[k] is None:
                 continue
             assert rel_err(v.cpu().numpy(), o_grads[k].numpy()) < TOL_GRAD, (k, rep)
-    if counts == "integer":   # the same batch as uint8 rows: the products expand them in registers -- the same bits
+    if counts in ("integer", "ragged_genes"):   # the same batch as uint8 rows: the products expand them in registers -- the same bits
         xc = x.clamp(max=255)
         out_f = step.run(xc.cuda(), ezd, eld)
         ref = {k: out_f[k].clone() for k in ("recon", "qz_m", "library", "kl_z")}

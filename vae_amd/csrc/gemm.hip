@@ -1491,6 +1491,14 @@ __global__ __launch_bounds__(256, ((VAE_X3_PIPE && NP <= 2 && BM == 128 && BN ==
       }
       if (tail) {
         fetch_tail(tail);
+        if constexpr (XOPT) {   // the partial last K step of the last slab (zero-filled past K) counts too
+#pragma unroll
+          for (int i = 0; i < NA; ++i)
+            if (xmine(i)) xs_take(i, ra[i]);
+#pragma unroll
+          for (int j = 0; j < NB; ++j)
+            if (wmine(j)) ws_take(j, rb[j]);
+        }
         stage(one);
         multiply(one);
         __syncthreads();
@@ -2029,7 +2037,7 @@ int gemm_impl(int layout, int precision, int64_t M, int64_t N, int64_t K, const 
     g.C = workspace;
   }
   if (xo && xo->mode != 0) {
-    VAE_REQUIRE(layout == NT && slabs_out && bm == 128 && bn == 128 && K % BK == 0 && xo->xs_sum && xo->xs_max && xo->xs_flag && xo->ws_sum &&
+    VAE_REQUIRE(layout == NT && slabs_out && bm == 128 && bn == 128 && K % 4 == 0 && xo->xs_sum && xo->xs_max && xo->xs_flag && xo->ws_sum &&
                     tiles_m * (g.tiles_n < 4 ? g.tiles_n : 4) * split <= xo->xs_n && vae_aligned16(xo->xs_max) && vae_aligned16(xo->xs_flag) &&
                     (xo->mode == 1 || (xo->mean_out && xo->wsum_out && xo->flags == xo->xs_flag && xo->n_flags == xo->xs_n)),
                 "vae_gemm: the optimistic count operand needs the pipelined 128 x 128 slab product (vae_gemm_counts_optimistic_ok)");
@@ -2259,9 +2267,9 @@ int vae_gemm_f16x2(int layout, int64_t M, int64_t N, int64_t K, const float* A, 
                    n_max_b, stats, 0, nullptr, counts);
 }
 // whether the NT count-operand product of this shape (left as slabs) can run optimistically: the pipelined 128 x 128 loop,
-// whole K steps, and room for its per-wave entries in arrays of n_stat floats
+// and room for its per-workgroup entries in arrays of n_stat floats
 bool vae_gemm_counts_optimistic_ok(int64_t M, int64_t N, int64_t K, int n_stat) {
-  if (!VAE_X3_PIPE || !VAE_X3_RELOAD || K % BK != 0 || !vae_gemm_tile_pipeline_ok(NT, M, N, K)) return false;
+  if (!VAE_X3_PIPE || !VAE_X3_RELOAD || K % 4 != 0 || !vae_gemm_tile_pipeline_ok(NT, M, N, K)) return false;
   if (make_plan((int)M, (int)N, (int)K, false).tile != 128) return false;
   const DmaPlan d = make_dma_plan((int)M, (int)N, (int)K, false);
   if (d.bm != 128 || d.bn != 128) return false;
