@@ -1379,15 +1379,14 @@ __global__ __launch_bounds__(256, ((VAE_X3_PIPE && NP <= 2 && BM == 128 && BN ==
       float* red_g = reinterpret_cast<float*>(smem);   // nothing is staged yet
       // the first few workgroups finish the means, the next few the row sums of B
       const int n_mean = (g.M + 255) / 256;
-      if (id < n_mean) {
-        const int m = id * 256 + tid;
-        if (m < g.M) {
-          g.mean_out[m] = slab_sum(g.xs_sum + m, g.split, g.M) / (float)g.K;
-        }
-      } else if (id < n_mean + (g.N + 255) / 256) {
-        const int n = (id - n_mean) * 256 + tid;
-        if (n < g.N) {
-          g.wsum_out[n] = slab_sum(g.ws_sum + n, g.split, g.N);
+      const int n_jobs = n_mean + (g.N + 255) / 256;
+      for (int job = id; job < n_jobs; job += nwg) {   // (one job per workgroup unless the grid is tiny)
+        if (job < n_mean) {
+          const int m = job * 256 + tid;
+          if (m < g.M) g.mean_out[m] = slab_sum(g.xs_sum + m, g.split, g.M) / (float)g.K;
+        } else {
+          const int n = (job - n_mean) * 256 + tid;
+          if (n < g.N) g.wsum_out[n] = slab_sum(g.ws_sum + n, g.split, g.N);
         }
       }
       float mf = partial_max(g.xone_flags, g.n_xone);
