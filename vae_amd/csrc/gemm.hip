@@ -798,8 +798,11 @@ __device__ __forceinline__ void x3_epilogue(const GemmArgs& g, f32x16 (&acc)[BM 
             constexpr int MI = STAT_OK ? 1 : 0;   // (index 0 when the registers are not carried)
             constexpr float L2E = 1.44269504088896341f;
             const int c0 = nb + 4 * (lane & 7);
-            const float a0 = c0 < g.stat_cols ? v.x : -INFINITY, a1 = c0 + 1 < g.stat_cols ? v.y : -INFINITY;
-            const float a2 = c0 + 2 < g.stat_cols ? v.z : -INFINITY, a3 = c0 + 3 < g.stat_cols ? v.w : -INFINITY;
+            float a0 = v.x, a1 = v.y, a2 = v.z, a3 = v.w;
+            if (nb + 32 > g.stat_cols) {   // (uniform) only the block that straddles the last statistics column masks
+              a0 = c0 < g.stat_cols ? v.x : -INFINITY; a1 = c0 + 1 < g.stat_cols ? v.y : -INFINITY;
+              a2 = c0 + 2 < g.stat_cols ? v.z : -INFINITY; a3 = c0 + 3 < g.stat_cols ? v.w : -INFINITY;
+            }
             const float om = rmax[mi * MI][i];
             const float nm = fmaxf(fmaxf(fmaxf(a0, a1), fmaxf(a2, a3)), om);
             const float nb2 = -nm * L2E;   // nm is finite unless every column so far was masked (then the terms are exp2(nan)?)
