@@ -914,6 +914,9 @@ __device__ __forceinline__ void split_pair_f16(float a0, float a1, float s0, flo
 #ifndef VAE_X3_SETS
 #define VAE_X3_SETS 1
 #endif
+#ifndef VAE_STAT_INTERLEAVE   // decoder forward: statistics and plain column tiles alternate in launch order
+#define VAE_STAT_INTERLEAVE 1
+#endif
 #ifndef VAE_TN_XONE   // one-term count operand in the TN weight gradient too (128 x 128 tiles)
 #define VAE_TN_XONE 1
 #endif
@@ -980,6 +983,14 @@ __global__ __launch_bounds__(256, ((VAE_X3_PIPE && NP <= 2 && BM == 128 && BN ==
     tn = r / rows;
   } else if (tiles_m <= tiles_n) { tm = t % tiles_m; tn = t / tiles_m; }
   else                           { tn = t % tiles_n; tm = t / tiles_n; }
+  if (VAE_STAT_INTERLEAVE && LAYOUT == NT && g.stat_m != nullptr) {
+    // the column tiles that carry the softmax statistics in their output stage (the first stat_cols columns) take longer than
+    // the others: alternate the two kinds along the launch order, so that the workgroups sharing a CU are a mix of both
+    const int ns = min(tiles_n, (g.stat_cols + BN - 1) / BN), both = 2 * min(ns, tiles_n - ns);
+    if (tn < both) tn = (tn & 1) ? ns + (tn >> 1) : (tn >> 1);
+    else if (ns < tiles_n - ns) tn = tn;                 // the tail: plain tiles only, already in place (tn >= 2 ns)
+    else tn = tn - (tiles_n - ns);                       // the tail: statistics tiles only
+  }
   const int m0 = tm * BM, n0 = tn * BN;
   const int kbeg = s * g.k_per_split;
   const int kend = min(g.K, kbeg + g.k_per_split);
