@@ -726,7 +726,15 @@ __global__ __launch_bounds__(256) void fwd_partials_finish_kernel(const float* _
   const int b = blockIdx.x * 256 + threadIdx.x;
   if (b >= B) return;
   float a = 0.f, c = 0.f;
-  for (int s = 0; s < strips; ++s) {
+  int s = 0;
+  for (; s + 8 <= strips; s += 8) {   // sixteen loads in flight, added in strip order
+    float qa[8], qc[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { qa[u] = part[((int64_t)(s + u) * 2 + 0) * B + b]; qc[u] = part[((int64_t)(s + u) * 2 + 1) * B + b]; }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { a += qa[u]; c += qc[u]; }
+  }
+  for (; s < strips; ++s) {
     a += part[((int64_t)s * 2 + 0) * B + b];
     c += part[((int64_t)s * 2 + 1) * B + b];
   }
