@@ -556,9 +556,9 @@ __global__ __launch_bounds__(THREADS, 4) void nbzinb_fwd_kernel(
 // pipeline over the cells of a chunk.  Per-cell sums (ll and S_b) leave as per-strip partials, added up in strip order
 // by the ELBO reduction (deterministic).
 constexpr int BWD_STRIP = 1024;   // 256 threads x float4
-constexpr int BWD_MAX_ROWS = 64;  // cells per workgroup (per-cell constants staged in LDS)
+constexpr int BWD_MAX_ROWS = 128; // cells per workgroup (per-cell constants staged in LDS)
 constexpr int FWD_STRIP = BWD_STRIP;
-constexpr int FWD_MAX_ROWS = 64;  // cells per workgroup of the streaming forward
+constexpr int FWD_MAX_ROWS = 128; // cells per workgroup of the streaming forward
 // (98 registers = 4 waves per SIMD; compiled for 5 (8 spills) or 6 (24 spills) the pass takes the same 40.6 us at
 // B = 512: occupancy is not what bounds it -- profiles/r02_pmc_epilogue.txt)
 
@@ -633,6 +633,20 @@ __global__ __launch_bounds__(256) void softmax_stats_merge_kernel(const float* _
   if (lane == 0) { rowmax[b] = M; rowsum[b] = s; }
 }
 
+// The cells [b0, b1) of grid row blockIdx.y: rows_per_block > 0 -- uniform chunks, the last one short; 0 -- the B cells dealt
+// out evenly over the gridDim.y chunks, the first B % chunks of them one cell longer (bwd_grid).
+__device__ __forceinline__ void chunk_cells(int B, int rows_per_block, int& b0, int& b1) {
+  const int by = (int)blockIdx.y;
+  if (rows_per_block > 0) {
+    b0 = by * rows_per_block;
+    b1 = min(B, b0 + rows_per_block);
+  } else {
+    const int c = (int)gridDim.y, q = B / c, r = B - q * c;
+    b0 = by * q + min(by, r);
+    b1 = b0 + q + (by < r ? 1 : 0);
+  }
+}
+
 struct RowInF { float4 l, p, x; };
 
 template <bool ZINB, bool VEC, typename XT, typename LT>
@@ -645,8 +659,8 @@ __global__ __launch_bounds__(256) void nbzinb_fwd_tiled_kernel(
   // 41 us, and 32 KB of LDS per workgroup caps the occupancy at four workgroups.)
   __shared__ float2 red[FWD_MAX_ROWS][4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int b0 = blockIdx.y * rows_per_block;
-  const int b1 = min(B, b0 + rows_per_block);
+  int b0, b1;
+  chunk_cells(B, rows_per_block, b0, b1);
   for (int r = tid; r < b1 - b0; r += 256)
     rc[r] = make_float2(-(rowmax[b0 + r] + logf(rowsum[b0 + r])) * LOG2E, expf(library[b0 + r]));
   __syncthreads();
@@ -866,8 +880,8 @@ __global__ __launch_bounds__(256) void nbzinb_bwd_kernel(
   if (threadIdx.x == 0) wg_absmax = 0u;
   float am = 0.f;
   const int g0 = blockIdx.x * BWD_STRIP + threadIdx.x * 4;
-  const int b0 = by * rows_per_block;
-  const int b1 = min(B, b0 + rows_per_block);
+  int b0, b1;
+  chunk_cells(B, rows_per_block, b0, b1);
   for (int r = threadIdx.x; r < b1 - b0; r += 256) {
     const int b = b0 + r;
     const float delta = g_scalar * (g_ll ? g_ll[b] : 1.f);
@@ -1129,12 +1143,31 @@ namespace {
 void bwd_grid(int64_t B, int64_t G, int* strips, int* chunks, int* rows_per_block) {
   *strips = (int)((G + BWD_STRIP - 1) / BWD_STRIP);
   static const int target = getenv("VAE_BWD_WORKGROUPS") ? atoi(getenv("VAE_BWD_WORKGROUPS")) : 1024;  // tuning knob
-  int c = (target + *strips - 1) / *strips;  // default ~4 workgroups per CU
+  static const bool uniform = getenv("VAE_LL_UNIFORM_CHUNKS") != nullptr;   // A/B knob: the chunking before the balanced one
+  // uniform chunks: ~4 workgroups per CU, every chunk rows_per_block cells, the last one what is left
+  int c = (target + *strips - 1) / *strips;
   if (c > 64) c = 64;                        // bounds the slab reduction for small gene counts
   if (c > B) c = (int)B;
-  *rows_per_block = (int)((B + c - 1) / c);
-  if (*rows_per_block > BWD_MAX_ROWS) *rows_per_block = BWD_MAX_ROWS;
-  *chunks = (int)((B + *rows_per_block - 1) / *rows_per_block);
+  int rpb = (int)((B + c - 1) / c);
+  if (rpb > (uniform ? 64 : BWD_MAX_ROWS)) rpb = uniform ? 64 : BWD_MAX_ROWS;
+  const int cu = (int)((B + rpb - 1) / rpb);
+  const int64_t rem = B - (int64_t)(cu - 1) * rpb;
+  *rows_per_block = rpb;
+  *chunks = cu;
+  if (uniform || (int64_t)*strips * cu <= target || rem * 4 <= rpb) return;
+  // The kernels run four workgroups per CU (128 registers): 1024 slots.  A grid beyond them leaves its last workgroups to
+  // start when the others end -- a second generation at a quarter of the occupancy (B = 4096, 20 strips: 1280 workgroups of
+  // 64 cells, backward 349 us; 1020 of 80 or 81 cells: 295 us).  Harmless only where that tail is a short remainder chunk
+  // (B = 512: 1040 workgroups, the last twenty of 2 cells, measured 0.5 us FASTER than 1020 balanced ones).  Otherwise: as
+  // many chunks as fit in ONE generation (rounded down), the cells dealt out evenly -- the first B % chunks chunks take one
+  // cell more (rows_per_block = 0 tells the kernels, which derive the deal from gridDim.y: chunk_cells).
+  c = target / *strips;
+  if (c > 64) c = 64;
+  if (c < 1) c = 1;
+  if (c > B) c = (int)B;
+  if ((B + c - 1) / c > BWD_MAX_ROWS) c = (int)((B + BWD_MAX_ROWS - 1) / BWD_MAX_ROWS);
+  *chunks = c;
+  *rows_per_block = 0;
 }
 }  // namespace
 
@@ -1285,6 +1318,7 @@ int vae_nbzinb_fwd_strips(int64_t G) { return (int)((G + FWD_STRIP - 1) / FWD_ST
 namespace {
 void fwd_grid(int64_t B, int64_t G, int* strips, int* chunks, int* rows_per_block) {
   bwd_grid(B, G, strips, chunks, rows_per_block);
+  if (*rows_per_block == 0) return;   // balanced deal: at most BWD_MAX_ROWS = FWD_MAX_ROWS cells per chunk
   if (*rows_per_block > FWD_MAX_ROWS) *rows_per_block = FWD_MAX_ROWS;
   *chunks = (int)((B + *rows_per_block - 1) / *rows_per_block);
 }
