@@ -452,6 +452,65 @@ __device__ __forceinline__ void st4(bf16_t* p, float a, float b, float c, float 
 __device__ __forceinline__ void st1(float* p, float v) { *p = v; }
 __device__ __forceinline__ void st1(bf16_t* p, float v) { *p = bf16_rn(v); }
 
+// EPT (4 or 2) consecutive elements of a row from element g0 on, for the streaming kernels whose threads own EPT genes:
+// one 16 / 8-byte load of fp32, 4 / 2 bytes of uint8 counts, 8 / 4 bytes of bf16 logits (VEC), or guarded scalar loads.
+template <bool VEC, int EPT>
+__device__ __forceinline__ void ldv(const float* __restrict__ row, int g0, int G, float fill, float (&o)[EPT]) {
+  if (VEC && EPT == 4) {
+    const float4 v = *reinterpret_cast<const float4*>(row + g0);
+    o[0] = v.x; o[1] = v.y; o[EPT - 2] = v.z; o[EPT - 1] = v.w;
+  } else if (VEC) {
+    const float2 v = *reinterpret_cast<const float2*>(row + g0);
+    o[0] = v.x; o[1] = v.y;
+  } else {
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) o[j] = g0 + j < G ? row[g0 + j] : fill;
+  }
+}
+template <bool VEC, int EPT>
+__device__ __forceinline__ void ldv(const uint8_t* __restrict__ row, int g0, int G, float fill, float (&o)[EPT]) {
+  if (VEC && EPT == 4) {
+    const uchar4 u = *reinterpret_cast<const uchar4*>(row + g0);
+    o[0] = (float)u.x; o[1] = (float)u.y; o[EPT - 2] = (float)u.z; o[EPT - 1] = (float)u.w;
+  } else if (VEC) {
+    const uchar2 u = *reinterpret_cast<const uchar2*>(row + g0);
+    o[0] = (float)u.x; o[1] = (float)u.y;
+  } else {
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) o[j] = g0 + j < G ? (float)row[g0 + j] : fill;
+  }
+}
+template <bool VEC, int EPT>
+__device__ __forceinline__ void ldv(const bf16_t* __restrict__ row, int g0, int G, float fill, float (&o)[EPT]) {
+  if (VEC && EPT == 4) {
+    const uint2 u = *reinterpret_cast<const uint2*>(row + g0);
+    o[0] = bf16_up(u.x & 0xffffu); o[1] = __uint_as_float(u.x & 0xffff0000u);
+    o[EPT - 2] = bf16_up(u.y & 0xffffu); o[EPT - 1] = __uint_as_float(u.y & 0xffff0000u);
+  } else if (VEC) {
+    const uint32_t u = *reinterpret_cast<const uint32_t*>(row + g0);
+    o[0] = bf16_up(u & 0xffffu); o[1] = __uint_as_float(u & 0xffff0000u);
+  } else {
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) o[j] = g0 + j < G ? bf16_up(row[g0 + j]) : fill;
+  }
+}
+template <int EPT>
+__device__ __forceinline__ void stv(float* p, const float (&v)[EPT]) {
+  if (EPT == 4) *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[EPT - 2], v[EPT - 1]);
+  else *reinterpret_cast<float2*>(p) = make_float2(v[0], v[1]);
+}
+template <int EPT>
+__device__ __forceinline__ void stv(bf16_t* p, const float (&v)[EPT]) {
+  if (EPT == 4) {
+    uint2 u;
+    u.x = (uint32_t)bf16_rn(v[0]) | ((uint32_t)bf16_rn(v[1]) << 16);
+    u.y = (uint32_t)bf16_rn(v[EPT - 2]) | ((uint32_t)bf16_rn(v[EPT - 1]) << 16);
+    *reinterpret_cast<uint2*>(p) = u;
+  } else {
+    *reinterpret_cast<uint32_t*>(p) = (uint32_t)bf16_rn(v[0]) | ((uint32_t)bf16_rn(v[1]) << 16);
+  }
+}
+
 template <bool ZINB, bool VEC, int EPT, int THREADS, typename XT>
 __global__ __launch_bounds__(THREADS, 4) void nbzinb_fwd_kernel(
     const float* __restrict__ ls, int64_t ld_s, const float* __restrict__ lp, int64_t ld_p, const XT* __restrict__ x,
@@ -647,9 +706,25 @@ __device__ __forceinline__ void chunk_cells(int B, int rows_per_block, int& b0, 
   }
 }
 
-struct RowInF { float4 l, p, x; };
+template <int EPT>
+struct RowIn { float l[EPT], p[EPT], x[EPT]; };
 
-template <bool ZINB, bool VEC, typename XT, typename LT>
+template <bool ZINB, bool VEC, int EPT, typename XT, typename LT>
+__device__ __forceinline__ RowIn<EPT> load_row(const LT* ls, int64_t ld_s, const LT* lp, int64_t ld_p,
+                                               const XT* __restrict__ x, int64_t ld_x, int b, int g0, int G) {
+  RowIn<EPT> r;
+  ldv<VEC, EPT>(ls + (int64_t)b * ld_s, g0, G, 0.f, r.l);
+  ldv<VEC, EPT>(x + (int64_t)b * ld_x, g0, G, 0.f, r.x);
+  if (ZINB) ldv<VEC, EPT>(lp + (int64_t)b * ld_p, g0, G, 0.f, r.p);
+  else {
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) r.p[j] = 0.f;
+  }
+  return r;
+}
+
+
+template <bool ZINB, bool VEC, int EPT, typename XT, typename LT>
 __global__ __launch_bounds__(256) void nbzinb_fwd_tiled_kernel(
     const LT* __restrict__ ls, int64_t ld_s, const LT* __restrict__ lp, int64_t ld_p, const XT* __restrict__ x,
     int64_t ld_x, const float* __restrict__ library, const float* __restrict__ T, const float* __restrict__ rowmax,
@@ -665,14 +740,14 @@ __global__ __launch_bounds__(256) void nbzinb_fwd_tiled_kernel(
     rc[r] = make_float2(-(rowmax[b0 + r] + logf(rowsum[b0 + r])) * LOG2E, expf(library[b0 + r]));
   __syncthreads();
   // lanes past the last gene keep running (the wave reductions need every lane): clamped addresses, zero weight
-  const int g_raw = blockIdx.x * FWD_STRIP + tid * 4;
-  const int nv = g_raw < G ? min(4, G - g_raw) : 0;
+  const int g_raw = blockIdx.x * (256 * EPT) + tid * EPT;
+  const int nv = g_raw < G ? min(EPT, G - g_raw) : 0;
   const int g0 = nv > 0 ? g_raw : 0;
-  float th[4], lt[4], it[4];
-  const float* Tg[4];
-  const float* Tk[4];   // + first row of the count-indexed rows (tab_load)
+  float th[EPT], lt[EPT], it[EPT];
+  const float* Tg[EPT];
+  const float* Tk[EPT];   // + first row of the count-indexed rows (tab_load)
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
+  for (int j = 0; j < EPT; ++j) {
     const int g = min(g0 + j, G - 1);
     Tg[j] = T + g;
     Tk[j] = T + (int64_t)ROW_LGD * G + g;
@@ -680,38 +755,32 @@ __global__ __launch_bounds__(256) void nbzinb_fwd_tiled_kernel(
     lt[j] = T[ROW_LTE * G + g];
     it[j] = T[ROW_ITE * G + g];
   }
-  auto load = [&](int b) {
-    RowInF r;
-    r.l = ld4<VEC>(ls + (int64_t)b * ld_s, g0 >> 2, G, 0.f);
-    r.x = ld4<VEC>(x + (int64_t)b * ld_x, g0 >> 2, G, 0.f);
-    r.p = ZINB ? ld4<VEC>(lp + (int64_t)b * ld_p, g0 >> 2, G, 0.f) : make_float4(0.f, 0.f, 0.f, 0.f);
-    return r;
-  };
+  auto load = [&](int b) { return load_row<ZINB, VEC, EPT, XT, LT>(ls, ld_s, lp, ld_p, x, ld_x, b, g0, G); };
   // stage A (cell b+2): HBM loads; stage B (cell b+1): count-indexed table loads (L2); stage C (cell b): evaluate.
   // vmcnt retires in issue order: the table loads of b+1 are issued BEFORE the HBM loads of b+2.
-  RowInF c0 = load(b0);
-  RowInF c1 = b0 + 1 < b1 ? load(b0 + 1) : c0;
-  float d0[4], d1[4] = {0.f, 0.f, 0.f, 0.f};
-  {
-    const float xv[4] = {c0.x.x, c0.x.y, c0.x.z, c0.x.w};
+  RowIn<EPT> c0 = load(b0);
+  RowIn<EPT> c1 = b0 + 1 < b1 ? load(b0 + 1) : c0;
+  float d0[EPT], d1[EPT];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) d0[j] = tab_load(Tk[j], tab_index(xv[j]), G);
+  for (int j = 0; j < EPT; ++j) d1[j] = 0.f;
+  {
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) d0[j] = tab_load(Tk[j], tab_index(c0.x[j]), G);
   }
   for (int b = b0; b < b1; ++b) {
     if (b + 1 < b1) {
-      const float xv[4] = {c1.x.x, c1.x.y, c1.x.z, c1.x.w};
 #pragma unroll
-      for (int j = 0; j < 4; ++j) d1[j] = tab_load(Tk[j], tab_index(xv[j]), G);
+      for (int j = 0; j < EPT; ++j) d1[j] = tab_load(Tk[j], tab_index(c1.x[j]), G);
     }
-    RowInF c2 = c1;
+    RowIn<EPT> c2 = c1;
     if (b + 2 < b1) c2 = load(b + 2);
     const float2 k = rc[b - b0];
-    const float l4[4] = {c0.l.x, c0.l.y, c0.l.z, c0.l.w};
-    const float p4[4] = {c0.p.x, c0.p.y, c0.p.z, c0.p.w};
-    const float x4[4] = {c0.x.x, c0.x.y, c0.x.z, c0.x.w};
+    const float (&l4)[EPT] = c0.l;
+    const float (&p4)[EPT] = c0.p;
+    const float (&x4)[EPT] = c0.x;
     float sll = 0.f, sa = 0.f;
 #pragma unroll
-    for (int j = 0; j < 4; j += 2) {              // two genes per packed instruction (elem_fwd2)
+    for (int j = 0; j < EPT; j += 2) {              // two genes per packed instruction (elem_fwd2)
       const f2 p = mk2(softmax_w(l4[j], k.x), softmax_w(l4[j + 1], k.x));   // softmax weights, as the backward evaluates them
       const Fwd2 f = elem_fwd2<ZINB>(mk2(x4[j], x4[j + 1]), k.y * p, mk2(p4[j], p4[j + 1]), mk2(th[j], th[j + 1]),
                                      mk2(lt[j], lt[j + 1]), mk2(it[j], it[j + 1]), mk2(d0[j], d0[j + 1]), Tg[j], Tg[j + 1], G);
@@ -724,7 +793,7 @@ __global__ __launch_bounds__(256) void nbzinb_fwd_tiled_kernel(
     c0 = c1;
     c1 = c2;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) d0[j] = d1[j];
+    for (int j = 0; j < EPT; ++j) d0[j] = d1[j];
   }
   __syncthreads();
   for (int r = tid; r < b1 - b0; r += 256) {   // this strip's share of ll[b] and S_b, waves in a fixed order
@@ -788,18 +857,6 @@ __global__ __launch_bounds__(256) void px_rate_kernel(const LT* __restrict__ ls,
 
 // ---- backward: (gene strip of 1024) x (chunk of cells) per workgroup ----------------------
 
-struct RowIn { float4 l, p, x; };
-
-template <bool ZINB, bool VEC, typename XT, typename LT>
-__device__ __forceinline__ RowIn load_row(const LT* ls, int64_t ld_s, const LT* lp, int64_t ld_p,
-                                          const XT* __restrict__ x, int64_t ld_x, int b, int g0, int G) {
-  RowIn r;
-  r.l = ld4<VEC>(ls + (int64_t)b * ld_s, g0 >> 2, G, 0.f);
-  r.x = ld4<VEC>(x + (int64_t)b * ld_x, g0 >> 2, G, 0.f);
-  r.p = ZINB ? ld4<VEC>(lp + (int64_t)b * ld_p, g0 >> 2, G, 0.f) : make_float4(0.f, 0.f, 0.f, 0.f);
-  return r;
-}
-
 // The ELBO reduction of a training step whose forward left it to the backward (vae_step_config.defer_elbo_reduce): the
 // likelihood forward's per-strip partials part[(s * 2 + k) * B + b] (k = 0: ll, 1: S) are still in the workspace.  Every
 // workgroup of the backward forms the S_b of its own cells from them (strip order, as vae_elbo_reduce_parts does), and the
@@ -862,7 +919,8 @@ __device__ __forceinline__ void elbo_from_parts(const ElboParts& e, int B) {
   }
 }
 
-template <bool ZINB, bool VEC, bool SLAB, typename XT, typename LT>
+// EPT: genes per thread (4: a strip of 1024 genes per workgroup; 2: 512 -- fewer registers, more waves per SIMD)
+template <bool ZINB, bool VEC, bool SLAB, int EPT, typename XT, typename LT>
 __global__ __launch_bounds__(256) void nbzinb_bwd_kernel(
     const LT* ls, int64_t ld_s, const LT* lp, int64_t ld_p, const XT* __restrict__ x, int64_t ld_x,
     const float* __restrict__ library, const float* __restrict__ T, const float* __restrict__ rowmax,
@@ -879,7 +937,7 @@ __global__ __launch_bounds__(256) void nbzinb_bwd_kernel(
   __shared__ unsigned int wg_absmax;    // max |gradient| written by this workgroup (absmax != null), as float bits
   if (threadIdx.x == 0) wg_absmax = 0u;
   float am = 0.f;
-  const int g0 = blockIdx.x * BWD_STRIP + threadIdx.x * 4;
+  const int g0 = blockIdx.x * (256 * EPT) + threadIdx.x * EPT;
   int b0, b1;
   chunk_cells(B, rows_per_block, b0, b1);
   for (int r = threadIdx.x; r < b1 - b0; r += 256) {
@@ -891,12 +949,12 @@ __global__ __launch_bounds__(256) void nbzinb_bwd_kernel(
   }
   __syncthreads();
   if (g0 >= G) return;
-  const int nv = min(4, G - g0);  // valid columns of this thread
-  float th[4], lt[4], it[4], acc_t[4], acc_s[4], acc_p[4], max_s[4], max_p[4];
-  const float* Tg[4];
-  const float* Tk[4];   // + first row of the count-indexed rows (tab_load)
+  const int nv = min(EPT, G - g0);  // valid columns of this thread
+  float th[EPT], lt[EPT], it[EPT], acc_t[EPT], acc_s[EPT], acc_p[EPT], max_s[EPT], max_p[EPT];
+  const float* Tg[EPT];
+  const float* Tk[EPT];   // + first row of the count-indexed rows (tab_load)
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
+  for (int j = 0; j < EPT; ++j) {
     const int g = min(g0 + j, G - 1);
     Tg[j] = T + g;
     Tk[j] = T + (int64_t)ROW_DGD * G + g;
@@ -907,31 +965,31 @@ __global__ __launch_bounds__(256) void nbzinb_bwd_kernel(
   //   stage A (cell b+2): HBM loads of (logit_scale, logit_dropout, x)
   //   stage B (cell b+1): x has landed -> issue the count-indexed table loads (L2)
   //   stage C (cell b)  : evaluate, store both gradients (they alias the logits of cell b only)
-  RowIn c0 = load_row<ZINB, VEC, XT, LT>(ls, ld_s, lp, ld_p, x, ld_x, b0, g0, G);
-  RowIn c1 = c0;
-  if (b0 + 1 < b1) c1 = load_row<ZINB, VEC, XT, LT>(ls, ld_s, lp, ld_p, x, ld_x, b0 + 1, g0, G);
-  float d0[4], d1[4] = {0.f, 0.f, 0.f, 0.f};
-  {
-    const float xv[4] = {c0.x.x, c0.x.y, c0.x.z, c0.x.w};
+  RowIn<EPT> c0 = load_row<ZINB, VEC, EPT, XT, LT>(ls, ld_s, lp, ld_p, x, ld_x, b0, g0, G);
+  RowIn<EPT> c1 = c0;
+  if (b0 + 1 < b1) c1 = load_row<ZINB, VEC, EPT, XT, LT>(ls, ld_s, lp, ld_p, x, ld_x, b0 + 1, g0, G);
+  float d0[EPT], d1[EPT];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) d0[j] = tab_load(Tk[j], tab_index(xv[j]), G);
+  for (int j = 0; j < EPT; ++j) d1[j] = 0.f;
+  {
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) d0[j] = tab_load(Tk[j], tab_index(c0.x[j]), G);
   }
   for (int b = b0; b < b1; ++b) {
     // vmcnt retires in issue order: table loads of cell b+1 FIRST, HBM loads of cell b+2 after them
     if (b + 1 < b1) {
-      const float xv[4] = {c1.x.x, c1.x.y, c1.x.z, c1.x.w};
 #pragma unroll
-      for (int j = 0; j < 4; ++j) d1[j] = tab_load(Tk[j], tab_index(xv[j]), G);
+      for (int j = 0; j < EPT; ++j) d1[j] = tab_load(Tk[j], tab_index(c1.x[j]), G);
     }
-    RowIn c2 = c1;
-    if (b + 2 < b1) c2 = load_row<ZINB, VEC, XT, LT>(ls, ld_s, lp, ld_p, x, ld_x, b + 2, g0, G);
+    RowIn<EPT> c2 = c1;
+    if (b + 2 < b1) c2 = load_row<ZINB, VEC, EPT, XT, LT>(ls, ld_s, lp, ld_p, x, ld_x, b + 2, g0, G);
     const float4 k = rc[b - b0];
-    const float l4[4] = {c0.l.x, c0.l.y, c0.l.z, c0.l.w};
-    const float p4[4] = {c0.p.x, c0.p.y, c0.p.z, c0.p.w};
-    const float x4[4] = {c0.x.x, c0.x.y, c0.x.z, c0.x.w};
-    float o_s[4], o_p[4];
+    const float (&l4)[EPT] = c0.l;
+    const float (&p4)[EPT] = c0.p;
+    const float (&x4)[EPT] = c0.x;
+    float o_s[EPT], o_p[EPT];
 #pragma unroll
-    for (int j = 0; j < 4; j += 2) {              // two genes per packed instruction (elem_bwd2)
+    for (int j = 0; j < EPT; j += 2) {              // two genes per packed instruction (elem_bwd2)
       const f2 p = mk2(softmax_w(l4[j], k.x), softmax_w(l4[j + 1], k.x));
       const f2 th2 = mk2(th[j], th[j + 1]);
       const Bwd2 e = elem_bwd2<ZINB>(mk2(x4[j], x4[j + 1]), k.y * p, mk2(p4[j], p4[j + 1]), th2, mk2(lt[j], lt[j + 1]),
@@ -952,11 +1010,11 @@ __global__ __launch_bounds__(256) void nbzinb_bwd_kernel(
     LT* w_s = dls + (int64_t)b * ld_ds + g0;
     LT* w_p = ZINB ? dlp + (int64_t)b * ld_dp + g0 : nullptr;
     if (VEC) {
-      st4(w_s, o_s[0], o_s[1], o_s[2], o_s[3]);
-      if (ZINB) st4(w_p, o_p[0], o_p[1], o_p[2], o_p[3]);
+      stv<EPT>(w_s, o_s);
+      if (ZINB) stv<EPT>(w_p, o_p);
     } else {
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+      for (int j = 0; j < EPT; ++j)
         if (j < nv) {
           st1(w_s + j, o_s[j]);
           if (ZINB) st1(w_p + j, o_p[j]);
@@ -965,7 +1023,7 @@ __global__ __launch_bounds__(256) void nbzinb_bwd_kernel(
     c0 = c1;
     c1 = c2;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) d0[j] = d1[j];
+    for (int j = 0; j < EPT; ++j) d0[j] = d1[j];
   }
   if (absmax) {  // threads past G have left: LDS integer max of the rest, then this workgroup's entry of the partial maxima
     atomicMax(&wg_absmax, __float_as_uint(am));
@@ -977,7 +1035,7 @@ __global__ __launch_bounds__(256) void nbzinb_bwd_kernel(
     // colreduce_kernel adds them up in chunk order (deterministic, no float atomics)
     float* sl = slab + (int64_t)by * VAE_SLAB_ROWS * G + g0;
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < EPT; ++j)
       if (j < nv) {
         sl[j] = acc_t[j];
         sl[G + j] = acc_s[j];
@@ -986,7 +1044,7 @@ __global__ __launch_bounds__(256) void nbzinb_bwd_kernel(
       }
   } else {
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < EPT; ++j)
       if (j < nv) {
         atomicAdd(dpx_r + g0 + j, acc_t[j]);
         if (dbias_s) atomicAdd(dbias_s + g0 + j, acc_s[j]);
@@ -1140,9 +1198,16 @@ extern "C" int vae_px_rate(const float* logit_scale, int64_t ld_s, const float* 
 }
 
 namespace {
-void bwd_grid(int64_t B, int64_t G, int* strips, int* chunks, int* rows_per_block) {
-  *strips = (int)((G + BWD_STRIP - 1) / BWD_STRIP);
-  static const int target = getenv("VAE_BWD_WORKGROUPS") ? atoi(getenv("VAE_BWD_WORKGROUPS")) : 1024;  // tuning knob
+// Genes per thread of the backward (nbzinb_bwd_kernel's EPT).  Four: 128 registers, four waves per SIMD.  Two: 80
+// registers, six waves -- the kernel is bound by its arithmetic, yet loses 20 % when a fifth register over 128 takes a wave
+// away, and gains 3-6 % from the two more (same box: cfg2 45.4 -> 42.9 us, cfg3 296 -> 288).  The forward was built the same
+// way (66 registers, seven waves) and is no faster (35.3-37.4 against 35.2 us; 246-260 against 244): it stays at four.
+int bwd_ept() {
+  static const int e = getenv("VAE_LL_BWD_EPT") ? atoi(getenv("VAE_LL_BWD_EPT")) : 2;   // A/B knob
+  return e == 4 ? 4 : 2;
+}
+void ll_grid(int64_t B, int64_t G, int strip, int target, int* strips, int* chunks, int* rows_per_block) {
+  *strips = (int)((G + strip - 1) / strip);
   static const bool uniform = getenv("VAE_LL_UNIFORM_CHUNKS") != nullptr;   // A/B knob: the chunking before the balanced one
   // uniform chunks: ~4 workgroups per CU, every chunk rows_per_block cells, the last one what is left
   int c = (target + *strips - 1) / *strips;
@@ -1168,6 +1233,18 @@ void bwd_grid(int64_t B, int64_t G, int* strips, int* chunks, int* rows_per_bloc
   if ((B + c - 1) / c > BWD_MAX_ROWS) c = (int)((B + BWD_MAX_ROWS - 1) / BWD_MAX_ROWS);
   *chunks = c;
   *rows_per_block = 0;
+}
+int ll_target() {
+  static const int target = getenv("VAE_BWD_WORKGROUPS") ? atoi(getenv("VAE_BWD_WORKGROUPS")) : 1024;  // tuning knob
+  return target;
+}
+void bwd_grid(int64_t B, int64_t G, int* strips, int* chunks, int* rows_per_block) {
+  // two genes per thread: 1536 slots.  Long chunks fill them (B = 4096, 40 strips: 38 chunks of 108 cells 288 us, 32 of
+  // 128 cells 319); short ones (B = 512: 14-16 cells) pay more for a workgroup's start than the sixth wave brings, and 1280
+  // workgroups are five per CU exactly (42.9 us; 1160 / 1400 / 1480 workgroups: 45.6 / 45.7 / 44.7).
+  static const int target2 = getenv("VAE_BWD_WORKGROUPS2") ? atoi(getenv("VAE_BWD_WORKGROUPS2")) : 0;  // tuning knob (EPT 2)
+  if (bwd_ept() == 2) ll_grid(B, G, 512, target2 > 0 ? target2 : (B >= 2048 ? 1536 : 1280), strips, chunks, rows_per_block);
+  else ll_grid(B, G, BWD_STRIP, ll_target(), strips, chunks, rows_per_block);
 }
 }  // namespace
 
@@ -1226,10 +1303,18 @@ static int nbzinb_bwd_impl(int zinb, const LT* logit_scale, int64_t ld_s, const 
   }
   dim3 grid(strips, chunks);
   hipStream_t st = (hipStream_t)stream;
+  const int ept = bwd_ept();
 #define LAUNCH_BWD(Z, V, S_)                                                                                          \
-  hipLaunchKernelGGL((nbzinb_bwd_kernel<Z, V, S_, XT, LT>), grid, dim3(256), 0, st, logit_scale, ld_s, logit_dropout, ld_p, x,  \
-                     ld_x, library, gene_table, rowmax, rowsum, S, g_ll, g_scalar, (int)B, (int)G, rows_per_block,    \
-                     dlogit_scale, ld_ds, dlogit_dropout, ld_dp, dlibrary, dpx_r, dbias_scale, dbias_dropout, workspace, absmax, ep)
+  do {                                                                                                                \
+    if (ept == 2)                                                                                                     \
+      hipLaunchKernelGGL((nbzinb_bwd_kernel<Z, V, S_, 2, XT, LT>), grid, dim3(256), 0, st, logit_scale, ld_s, logit_dropout, ld_p, x, \
+                         ld_x, library, gene_table, rowmax, rowsum, S, g_ll, g_scalar, (int)B, (int)G, rows_per_block,  \
+                         dlogit_scale, ld_ds, dlogit_dropout, ld_dp, dlibrary, dpx_r, dbias_scale, dbias_dropout, workspace, absmax, ep); \
+    else                                                                                                              \
+      hipLaunchKernelGGL((nbzinb_bwd_kernel<Z, V, S_, 4, XT, LT>), grid, dim3(256), 0, st, logit_scale, ld_s, logit_dropout, ld_p, x, \
+                         ld_x, library, gene_table, rowmax, rowsum, S, g_ll, g_scalar, (int)B, (int)G, rows_per_block,  \
+                         dlogit_scale, ld_ds, dlogit_dropout, ld_dp, dlibrary, dpx_r, dbias_scale, dbias_dropout, workspace, absmax, ep); \
+  } while (0)
 #define LAUNCH_BWD2(Z, V) do { if (slab) LAUNCH_BWD(Z, V, true); else LAUNCH_BWD(Z, V, false); } while (0)
   VAE_REQUIRE(!U8 || vec, "vae_nbzinb_bwd_u8: needs G %% 4 == 0, leading dimensions %% 4 == 0 and aligned rows");
   if (U8 || L16) { if (zinb) LAUNCH_BWD2(true, true); else LAUNCH_BWD2(false, true); }
@@ -1314,15 +1399,15 @@ extern "C" int vae_nbzinb_bwd_u8(int zinb, const float* logit_scale, int64_t ld_
 }
 
 // ---- forward, streaming form (host side) ----------------------------------------------------------------------------
-int vae_nbzinb_fwd_strips(int64_t G) { return (int)((G + FWD_STRIP - 1) / FWD_STRIP); }
 namespace {
 void fwd_grid(int64_t B, int64_t G, int* strips, int* chunks, int* rows_per_block) {
-  bwd_grid(B, G, strips, chunks, rows_per_block);
+  ll_grid(B, G, FWD_STRIP, ll_target(), strips, chunks, rows_per_block);
   if (*rows_per_block == 0) return;   // balanced deal: at most BWD_MAX_ROWS = FWD_MAX_ROWS cells per chunk
   if (*rows_per_block > FWD_MAX_ROWS) *rows_per_block = FWD_MAX_ROWS;
   *chunks = (int)((B + *rows_per_block - 1) / *rows_per_block);
 }
 }  // namespace
+int vae_nbzinb_fwd_strips(int64_t G) { return (int)((G + FWD_STRIP - 1) / FWD_STRIP); }
 extern "C" int64_t vae_nbzinb_fwd_workspace_bytes(int64_t B, int64_t G) {
   int strips, chunks, rpb;
   fwd_grid(B, G, &strips, &chunks, &rpb);
@@ -1362,7 +1447,7 @@ int vae_nbzinb_fwd_tiled_ex(int x_dtype, int l_dtype, int zinb, const void* logi
   VAE_REQUIRE(chunks <= 65535, "vae_nbzinb_fwd_ws: batch too large for one launch (B <= 16 * 65535)");
   const dim3 grid(strips, chunks);
 #define LAUNCH_FT(Z, V, XT_, LT_)                                                                                         \
-  hipLaunchKernelGGL((nbzinb_fwd_tiled_kernel<Z, V, XT_, LT_>), grid, dim3(256), 0, st, (const LT_*)logit_scale, ld_s,       \
+  hipLaunchKernelGGL((nbzinb_fwd_tiled_kernel<Z, V, 4, XT_, LT_>), grid, dim3(256), 0, st, (const LT_*)logit_scale, ld_s,    \
                      (const LT_*)logit_dropout, ld_p, (const XT_*)x, ld_x, library, gene_table, rowmax, rowsum, (int)B, (int)G, \
                      rows_per_block, workspace)
   if (l16) {
