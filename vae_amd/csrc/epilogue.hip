@@ -736,9 +736,6 @@ __global__ __launch_bounds__(256) void nbzinb_fwd_tiled_kernel(
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int b0, b1;
   chunk_cells(B, rows_per_block, b0, b1);
-  for (int r = tid; r < b1 - b0; r += 256)
-    rc[r] = make_float2(-(rowmax[b0 + r] + logf(rowsum[b0 + r])) * LOG2E, expf(library[b0 + r]));
-  __syncthreads();
   // lanes past the last gene keep running (the wave reductions need every lane): clamped addresses, zero weight
   const int g_raw = blockIdx.x * (256 * EPT) + tid * EPT;
   const int nv = g_raw < G ? min(EPT, G - g_raw) : 0;
@@ -758,8 +755,13 @@ __global__ __launch_bounds__(256) void nbzinb_fwd_tiled_kernel(
   auto load = [&](int b) { return load_row<ZINB, VEC, EPT, XT, LT>(ls, ld_s, lp, ld_p, x, ld_x, b, g0, G); };
   // stage A (cell b+2): HBM loads; stage B (cell b+1): count-indexed table loads (L2); stage C (cell b): evaluate.
   // vmcnt retires in issue order: the table loads of b+1 are issued BEFORE the HBM loads of b+2.
+  // The first two cells' rows are requested BEFORE the per-cell constants are formed: the workgroups of this grid are one
+  // generation, and constants -> barrier -> rows -> table was a chain of three round trips ahead of the first evaluation.
   RowIn<EPT> c0 = load(b0);
   RowIn<EPT> c1 = b0 + 1 < b1 ? load(b0 + 1) : c0;
+  for (int r = tid; r < b1 - b0; r += 256)
+    rc[r] = make_float2(-(rowmax[b0 + r] + logf(rowsum[b0 + r])) * LOG2E, expf(library[b0 + r]));
+  __syncthreads();
   float d0[EPT], d1[EPT];
 #pragma unroll
   for (int j = 0; j < EPT; ++j) d1[j] = 0.f;
@@ -872,7 +874,14 @@ struct ElboParts {
 __device__ __forceinline__ float strip_sum(const float* __restrict__ p, int strips, int64_t st) {
   float v = 0.f;
   int s = 0;
-  for (; s + 8 <= strips; s += 8) {   // eight loads in flight, summed in strip order
+  for (; s + 16 <= strips; s += 16) {   // sixteen loads in flight, summed in strip order
+    float q[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) q[u] = p[(s + u) * st];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) v += q[u];
+  }
+  for (; s + 8 <= strips; s += 8) {   // eight
     float q[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) q[u] = p[(s + u) * st];
@@ -940,22 +949,19 @@ __global__ __launch_bounds__(256) void nbzinb_bwd_kernel(
   const int g0 = blockIdx.x * (256 * EPT) + threadIdx.x * EPT;
   int b0, b1;
   chunk_cells(B, rows_per_block, b0, b1);
-  for (int r = threadIdx.x; r < b1 - b0; r += 256) {
-    const int b = b0 + r;
-    const float delta = g_scalar * (g_ll ? g_ll[b] : 1.f);
-    const float Sb = ep.part ? strip_sum(ep.part + B + b, ep.strips, (int64_t)2 * B) : S[b];
-    rc[r] = make_float4(-(rowmax[b] + logf(rowsum[b])) * LOG2E, expf(library[b]), Sb, delta);
-    if (blockIdx.x == 0 && dlibrary) dlibrary[b] = delta * Sb;
-  }
-  __syncthreads();
-  if (g0 >= G) return;
-  const int nv = min(EPT, G - g0);  // valid columns of this thread
+  // Requested BEFORE the per-cell constants are formed (the workgroups of this grid are one generation; S_b from the
+  // forward's partials -> barrier -> rows -> table was a chain of five round trips ahead of the first evaluation): the
+  // per-gene constants and the first two cells' rows.  Threads past the last gene read the head of the row and leave
+  // after the barrier.
+  const bool live = g0 < G;
+  const int gl = live ? g0 : 0;
+  const int nv = min(EPT, G - gl);  // valid columns of this thread
   float th[EPT], lt[EPT], it[EPT], acc_t[EPT], acc_s[EPT], acc_p[EPT], max_s[EPT], max_p[EPT];
   const float* Tg[EPT];
   const float* Tk[EPT];   // + first row of the count-indexed rows (tab_load)
 #pragma unroll
   for (int j = 0; j < EPT; ++j) {
-    const int g = min(g0 + j, G - 1);
+    const int g = min(gl + j, G - 1);
     Tg[j] = T + g;
     Tk[j] = T + (int64_t)ROW_DGD * G + g;
     th[j] = T[ROW_TH * G + g]; lt[j] = T[ROW_LTE * G + g]; it[j] = T[ROW_ITE * G + g];
@@ -965,9 +971,18 @@ __global__ __launch_bounds__(256) void nbzinb_bwd_kernel(
   //   stage A (cell b+2): HBM loads of (logit_scale, logit_dropout, x)
   //   stage B (cell b+1): x has landed -> issue the count-indexed table loads (L2)
   //   stage C (cell b)  : evaluate, store both gradients (they alias the logits of cell b only)
-  RowIn<EPT> c0 = load_row<ZINB, VEC, EPT, XT, LT>(ls, ld_s, lp, ld_p, x, ld_x, b0, g0, G);
+  RowIn<EPT> c0 = load_row<ZINB, VEC, EPT, XT, LT>(ls, ld_s, lp, ld_p, x, ld_x, b0, gl, G);
   RowIn<EPT> c1 = c0;
-  if (b0 + 1 < b1) c1 = load_row<ZINB, VEC, EPT, XT, LT>(ls, ld_s, lp, ld_p, x, ld_x, b0 + 1, g0, G);
+  if (b0 + 1 < b1) c1 = load_row<ZINB, VEC, EPT, XT, LT>(ls, ld_s, lp, ld_p, x, ld_x, b0 + 1, gl, G);
+  for (int r = threadIdx.x; r < b1 - b0; r += 256) {
+    const int b = b0 + r;
+    const float delta = g_scalar * (g_ll ? g_ll[b] : 1.f);
+    const float Sb = ep.part ? strip_sum(ep.part + B + b, ep.strips, (int64_t)2 * B) : S[b];
+    rc[r] = make_float4(-(rowmax[b] + logf(rowsum[b])) * LOG2E, expf(library[b]), Sb, delta);
+    if (blockIdx.x == 0 && dlibrary) dlibrary[b] = delta * Sb;
+  }
+  __syncthreads();
+  if (!live) return;
   float d0[EPT], d1[EPT];
 #pragma unroll
   for (int j = 0; j < EPT; ++j) d1[j] = 0.f;
