@@ -552,19 +552,33 @@ def test_fused_epilogue_against_the_oracle_likelihood(ops, zinb, G, counts, stre
     (modules.py:362,404, distributions.py:22-90, task.py:156-165) in fp64 autograd, on counts that hit every branch:
     zeros, table counts (< 16), Stirling counts (16..255, thousands) and -- float counts only -- fractional ones;
     extreme dropout logits on both sides of the softplus threshold."""
-    from oracle import vae_oracle as O
     if counts == "u8" and G % 4:
         pytest.skip("uint8 counts need the vector path")
-    B = 9
+    _epilogue_against_the_oracle(ops, zinb, 9, G, counts, streaming)
+
+
+@pytest.mark.parametrize("B", [490, 508])
+def test_fused_epilogue_with_evenly_dealt_cell_chunks(ops, B):
+    """The same comparison at shapes whose (gene strip x cell chunk) grid would overflow one generation of workgroups, so
+    that the kernels deal the cells out evenly instead (ll_grid / chunk_cells in epilogue.hip: the first B % chunks
+    chunks take one cell more): 20 992 genes = 21 strips of the forward, 41 of the two-gene backward.  B = 490 -> the
+    forward runs 48 chunks of 10 or 11 cells; B = 508 -> the backward runs 31 chunks of 16 or 17.  (The bench shapes
+    B = 2048 / 4096 take this path; the step tests' small gene counts do not.)"""
+    _epilogue_against_the_oracle(ops, True, B, 20992, "f32", True)
+
+
+def _epilogue_against_the_oracle(ops, zinb, B, G, counts, streaming):
+    from oracle import vae_oracle as O
     g = torch.Generator().manual_seed(77)
     x = torch.poisson(torch.rand(B, G, generator=g) * 3, generator=g)
     x[torch.rand(B, G, generator=g) < 0.4] = 0
-    x[:, 5] = torch.tensor([0, 1, 15, 16, 17, 100, 255, 40, 3.0])
+    rep = lambda v: torch.tensor(v).repeat((B + 8) // 9)[:B]
+    x[:, 5] = rep([0, 1, 15, 16, 17, 100, 255, 40, 3.0])
     if counts == "f32":
-        x[:, 6] = torch.tensor([2500.0, 0.5, 7.25, 1e-9, 30000.0, 15.5, 16.5, 0.0, 1.0])   # large, fractional, below eps
+        x[:, 6] = rep([2500.0, 0.5, 7.25, 1e-9, 30000.0, 15.5, 16.5, 0.0, 1.0])   # large, fractional, below eps
     ls = torch.randn(B, G, generator=g) * 2
     lp = torch.randn(B, G, generator=g) * 3
-    lp[:, 7] = torch.tensor([-30.0, 30.0, -21.0, 21.0, -19.0, 19.0, 0.0, -50.0, 50.0])
+    lp[:, 7] = rep([-30.0, 30.0, -21.0, 21.0, -19.0, 19.0, 0.0, -50.0, 50.0])
     lib = torch.randn(B, generator=g) * 0.5 + 6
     px_r = torch.randn(G, generator=g) * 0.7
     leaves = [t.double().requires_grad_(True) for t in (ls, lp, lib, px_r)]
