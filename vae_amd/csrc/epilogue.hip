@@ -23,7 +23,7 @@
 // softmax statistics (wavefront shuffles + LDS) and the likelihood pass, and also reduces
 // S_b = sum_g mu * dll/dmu, which makes the backward a single element-wise pass:
 //   dlogit_scale = delta_b * (a_g - p_g * S_b).
-// Backward: (strip of 1024 genes) x (chunk of cells) per workgroup; per-gene column sums
+// Backward: (strip of 512 genes: two per thread; 1024 with VAE_LL_BWD_EPT=4) x (chunk of cells) per workgroup; per-gene column sums
 // (d px_r, both bias gradients) stay in registers across the chunk and are flushed with one
 // float atomic per gene per workgroup; the next cell's loads are issued before the current
 // cell's stores so that HBM latency is overlapped although the gradients alias the logits.
@@ -857,7 +857,7 @@ __global__ __launch_bounds__(256) void px_rate_kernel(const LT* __restrict__ ls,
   }
 }
 
-// ---- backward: (gene strip of 1024) x (chunk of cells) per workgroup ----------------------
+// ---- backward: (gene strip of 256 x EPT) x (chunk of cells) per workgroup -------------------
 
 // The ELBO reduction of a training step whose forward left it to the backward (vae_step_config.defer_elbo_reduce): the
 // likelihood forward's per-strip partials part[(s * 2 + k) * B + b] (k = 0: ll, 1: S) are still in the workspace.  Every
