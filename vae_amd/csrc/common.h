@@ -97,6 +97,14 @@ __device__ __forceinline__ float row_total(float v) {   // lanes 0, 16, 32, 48 h
   return (__int_as_float(__builtin_amdgcn_readlane(i, 0)) + __int_as_float(__builtin_amdgcn_readlane(i, 16))) +
          (__int_as_float(__builtin_amdgcn_readlane(i, 32)) + __int_as_float(__builtin_amdgcn_readlane(i, 48)));
 }
+// the first half of wave_sum_dpp: every lane ends with the total of its 16-lane row
+__device__ __forceinline__ float row_sum_dpp(float v) {
+  v += dpp_move<0xB1>(v);    // quad_perm [1, 0, 3, 2]
+  v += dpp_move<0x4E>(v);    // quad_perm [2, 3, 0, 1]
+  v += dpp_move<0x124>(v);   // row_ror:4
+  v += dpp_move<0x128>(v);   // row_ror:8
+  return v;
+}
 __device__ __forceinline__ float wave_sum_dpp(float v) {
   v += dpp_move<0xB1>(v);    // quad_perm [1, 0, 3, 2]
   v += dpp_move<0x4E>(v);    // quad_perm [2, 3, 0, 1]

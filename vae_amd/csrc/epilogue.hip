@@ -732,7 +732,7 @@ __global__ __launch_bounds__(256) void nbzinb_fwd_tiled_kernel(
   __shared__ float2 rc[FWD_MAX_ROWS];         // per cell: {-(max + log(sum exp)) log2(e), exp(library)}
   // per cell and wave: {sum ll, sum a}.  (Per-THREAD partials in LDS, reduced once at the end, were measured: the same
   // 41 us, and 32 KB of LDS per workgroup caps the occupancy at four workgroups.)
-  __shared__ float2 red[FWD_MAX_ROWS][4];
+  __shared__ float2 red[FWD_MAX_ROWS][16];   // [wave * 4 + 16-lane row of the wave]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int b0, b1;
   chunk_cells(B, rows_per_block, b0, b1);
@@ -789,9 +789,12 @@ __global__ __launch_bounds__(256) void nbzinb_fwd_tiled_kernel(
       sll += ((VEC || j < nv) ? f.ll.x : 0.f) + ((VEC || j + 1 < nv) ? f.ll.y : 0.f);   // VEC: all four genes valid, or none
       sa += ((VEC || j < nv) ? f.a.x : 0.f) + ((VEC || j + 1 < nv) ? f.a.y : 0.f);
     }
-    sll = wave_sum_dpp(nv > 0 ? sll : 0.f);   // DPP butterfly + four row totals: no LDS round trips in the cell loop
-    sa = wave_sum_dpp(nv > 0 ? sa : 0.f);
-    if (lane == 0) red[b - b0][wave] = make_float2(sll, sa);
+    // DPP butterfly inside the 16-lane rows; the four row totals of a wave go to LDS as they are (one 8-byte store by four
+    // lanes) and are added after the cell loop in wave_sum_dpp's order -- the same bits, without the eight v_readlane and six
+    // additions per cell that brought them through scalar registers
+    sll = row_sum_dpp(nv > 0 ? sll : 0.f);
+    sa = row_sum_dpp(nv > 0 ? sa : 0.f);
+    if ((lane & 15) == 0) red[b - b0][wave * 4 + (lane >> 4)] = make_float2(sll, sa);
     c0 = c1;
     c1 = c2;
 #pragma unroll
@@ -799,9 +802,14 @@ __global__ __launch_bounds__(256) void nbzinb_fwd_tiled_kernel(
   }
   __syncthreads();
   for (int r = tid; r < b1 - b0; r += 256) {   // this strip's share of ll[b] and S_b, waves in a fixed order
-    const float2 a = red[r][0], b2 = red[r][1], c = red[r][2], d = red[r][3];
-    part[((int64_t)blockIdx.x * 2 + 0) * B + b0 + r] = ((a.x + b2.x) + c.x) + d.x;
-    part[((int64_t)blockIdx.x * 2 + 1) * B + b0 + r] = ((a.y + b2.y) + c.y) + d.y;
+    float2 w4[4];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const float2 q0 = red[r][4 * w], q1 = red[r][4 * w + 1], q2 = red[r][4 * w + 2], q3 = red[r][4 * w + 3];
+      w4[w] = make_float2((q0.x + q1.x) + (q2.x + q3.x), (q0.y + q1.y) + (q2.y + q3.y));
+    }
+    part[((int64_t)blockIdx.x * 2 + 0) * B + b0 + r] = ((w4[0].x + w4[1].x) + w4[2].x) + w4[3].x;
+    part[((int64_t)blockIdx.x * 2 + 1) * B + b0 + r] = ((w4[0].y + w4[1].y) + w4[2].y) + w4[3].y;
   }
 }
 
