@@ -1020,8 +1020,10 @@ __global__ __launch_bounds__(256) void nbzinb_bwd_kernel(
       const f2 os = k.w * (e.a - p * k.z), op = k.w * e.dpi, ot = (k.w * e.dth) * th2;
       o_s[j] = os.x; o_s[j + 1] = os.y;
       o_p[j] = op.x; o_p[j + 1] = op.y;
-      if (j < nv) am = fmaxf(am, fmaxf(fabsf(os.x), ZINB ? fabsf(op.x) : 0.f));
-      if (j + 1 < nv) am = fmaxf(am, fmaxf(fabsf(os.y), ZINB ? fabsf(op.y) : 0.f));
+      if (!SLAB) {   // (with slabs the per-gene maxima below hold the same information: folded into am after the loop)
+        if (j < nv) am = fmaxf(am, fmaxf(fabsf(os.x), ZINB ? fabsf(op.x) : 0.f));
+        if (j + 1 < nv) am = fmaxf(am, fmaxf(fabsf(os.y), ZINB ? fabsf(op.y) : 0.f));
+      }
       acc_t[j] += ot.x; acc_t[j + 1] += ot.y;
       acc_s[j] += os.x; acc_s[j + 1] += os.y;
       acc_p[j] += op.x; acc_p[j + 1] += op.y;
@@ -1047,6 +1049,11 @@ __global__ __launch_bounds__(256) void nbzinb_bwd_kernel(
     c1 = c2;
 #pragma unroll
     for (int j = 0; j < EPT; ++j) d0[j] = d1[j];
+  }
+  if (SLAB) {
+#pragma unroll
+    for (int j = 0; j < EPT; ++j)
+      if (j < nv) am = fmaxf(am, fmaxf(max_s[j], ZINB ? max_p[j] : 0.f));
   }
   if (absmax) {  // threads past G have left: LDS integer max of the rest, then this workgroup's entry of the partial maxima
     atomicMax(&wg_absmax, __float_as_uint(am));
