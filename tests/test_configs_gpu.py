@@ -161,6 +161,17 @@ def test_bench_batch_composition_against_oracle(precision, n_layers):
     assert abs(float(out["cell_loss"]) - float(o_out["cell_loss"])) < (1e-2 if bf16 else 1e-5) * abs(float(o_out["cell_loss"]))
 
 
+@pytest.mark.parametrize("precision", [3, 1], ids=["f16x2", "bf16"])
+def test_cfg3_batch_composition_against_oracle(precision):
+    """The same composition at B = 4096, the batch cfg3 / cfg4 bench at: here the small weight-gradient reduction no longer
+    fits one generation of workgroups with 512-cell chunks and takes longer chunks of whole 256-cell rounds
+    (launch_wgrad_batch in middle.hip), and the wave-per-cell middle runs eight waves per workgroup (B > 1024)."""
+    o_out, o_grads, out, arena = _run_both(4096, 4096, 256, 256, 128, 30, 1, precision=precision, heads=True, seed=33,
+                                           native_heads=True)
+    bf16 = precision == 1
+    _check(o_out, o_grads, out, arena, TOL_CELL_BF16 if bf16 else TOL_CELL, TOL_GRAD_BF16 if bf16 else TOL_GRAD, 33)
+
+
 @pytest.mark.parametrize("precision", [0, 3], ids=["bf16x3", "f16x2"])
 def test_gene_count_not_a_multiple_of_four(precision):
     """G % 4 == 2 puts the step outside the two-f16-term pipeline (16-byte rows) while 2G and Hd

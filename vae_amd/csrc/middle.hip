@@ -1236,8 +1236,18 @@ int launch_wgrad_batch(WgradBatch& wb, int tiles, int ptotal, float* space, int6
   const int split_min_b = getenv("VAE_SMALL_WGRAD_SPLIT_MIN_B") ? atoi(getenv("VAE_SMALL_WGRAD_SPLIT_MIN_B")) : 2048;   // A/B knob
   wb.nsplit = 1; wb.chunk = wb.B; wb.part = nullptr; wb.part_total = ptotal;
   if (wb.B >= split_min_b && space) {
-    const int ns = (wb.B + 511) / 512;
-    if ((int64_t)ns * ptotal <= capacity) { wb.nsplit = ns; wb.chunk = 512; wb.part = space; }
+    // chunks of 512 cells (two staging rounds) -- unless that many chunks overflow ONE generation of workgroups (two of
+    // these 1024-thread workgroups per CU: 512 slots; only the task tiles multiply with the chunks, the column-reduction
+    // tiles work in grid row 0): then fewer, longer chunks of whole 256-cell rounds (B = 4096, ~70 task tiles: 6 chunks
+    // of 768 cells = three rounds for everyone instead of two rounds twice for the overflow)
+    static const int chunk_env = getenv("VAE_SMALL_WGRAD_CHUNK") ? atoi(getenv("VAE_SMALL_WGRAD_CHUNK")) : 0;   // A/B knob
+    int chunk = 512;
+    const int task_tiles = wb.cr_tile0 > 0 ? wb.cr_tile0 : tiles, other = tiles - task_tiles;
+    if (chunk_env > 0) chunk = (chunk_env + 255) / 256 * 256;
+    else
+      while (chunk < wb.B && (int64_t)task_tiles * ((wb.B + chunk - 1) / chunk) + other > 512) chunk += 256;
+    const int ns = (wb.B + chunk - 1) / chunk;
+    if (ns > 1 && (int64_t)ns * ptotal <= capacity) { wb.nsplit = ns; wb.chunk = chunk; wb.part = space; }
   }
   hipLaunchKernelGGL(small_wgrad_kernel, dim3((unsigned)tiles, (unsigned)wb.nsplit), dim3(TW), 0, (hipStream_t)stream, wb);
   VAE_CHECK_LAUNCH("small_wgrad");
