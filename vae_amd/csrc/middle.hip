@@ -1236,10 +1236,11 @@ int launch_wgrad_batch(WgradBatch& wb, int tiles, int ptotal, float* space, int6
   const int split_min_b = getenv("VAE_SMALL_WGRAD_SPLIT_MIN_B") ? atoi(getenv("VAE_SMALL_WGRAD_SPLIT_MIN_B")) : 2048;   // A/B knob
   wb.nsplit = 1; wb.chunk = wb.B; wb.part = nullptr; wb.part_total = ptotal;
   if (wb.B >= split_min_b && space) {
-    // chunks of 512 cells (two staging rounds) -- unless that many chunks overflow ONE generation of workgroups (two of
-    // these 1024-thread workgroups per CU: 512 slots; only the task tiles multiply with the chunks, the column-reduction
-    // tiles work in grid row 0): then fewer, longer chunks of whole 256-cell rounds (B = 4096, ~70 task tiles: 6 chunks
-    // of 768 cells = three rounds for everyone instead of two rounds twice for the overflow)
+    // chunks of 512 cells (two staging rounds) -- unless that many chunks need more than TWO generations of workgroups
+    // (1024 threads at 68 registers: one workgroup per CU, 256 slots; only the task tiles multiply with the chunks, the
+    // column-reduction tiles work in grid row 0): then longer chunks of whole 256-cell rounds.  cfg3 (B = 4096), same box:
+    // 512 cells 28.1 us, 768 (this rule) 26.0, 1024 30.2, 2048 (one generation) 29.0.  (Capped at 64 registers the kernel
+    // runs two workgroups per CU with 12 bytes of scratch: 24.3 us there, but 11.2 -> 11.6 at B = 512 -- not taken.)
     static const int chunk_env = getenv("VAE_SMALL_WGRAD_CHUNK") ? atoi(getenv("VAE_SMALL_WGRAD_CHUNK")) : 0;   // A/B knob
     int chunk = 512;
     const int task_tiles = wb.cr_tile0 > 0 ? wb.cr_tile0 : tiles, other = tiles - task_tiles;
