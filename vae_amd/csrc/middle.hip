@@ -442,6 +442,28 @@ __device__ __forceinline__ void reparam_bwd_wave(const float* dz_lds, const floa
   }
 }
 
+// The same with the wave's inputs already in registers (requested at the top of the kernel, so that no global round trip
+// sits between the barriers of the chain): hr = lane's head output (lane L: the variance pre-activation), ep = lane's eps.
+__device__ __forceinline__ void reparam_bwd_regs(const float* dz_lds, float hr, float ep, float v, float gk, int L, float pm,
+                                                 float pv, int lane, float* dq_row, float* dq_lds) {
+  const float sq = sqrtf(v);
+  float dv = 0.f;
+  if (lane < L) {
+    const float d = dz_lds[lane];
+    const float o = d + gk * (hr - pm) / pv;
+    dq_row[lane] = o;
+    dq_lds[lane] = o;
+    dv = d * ep;
+  }
+  dv = wave_sum_dpp(dv);
+  dv = dv * 0.5f / sq + gk * (float)L * 0.5f * (1.f / pv - 1.f / v);
+  const float o = dv * softplus20_grad(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(hr), L)));
+  if (lane == 0) {
+    dq_row[L] = o;
+    dq_lds[L] = o;
+  }
+}
+
 __global__ __launch_bounds__(T) void mid_bwd_kernel(MidBwd a) {
   extern __shared__ __attribute__((aligned(16))) float dyn[];  // decoder weight, Hd x LP
   __shared__ float ds[ME * T];   // d pre-activation of the decoder layer
@@ -482,6 +504,22 @@ __global__ __launch_bounds__(T) void mid_bwd_kernel(MidBwd a) {
     hlc[i][0] = lh ? a.hl_w[e - H] : 0.f;
     hlc[i][1] = lh ? a.hl_w[Hl + e - H] : 0.f;
   }
+  // what the later stages of the chain read per cell, requested now: the reparameterisation inputs of waves 0 / 1, the
+  // cell-head gradient of this thread's latent, 1 / mean (each was a global round trip between two barriers)
+  float r_h = 0.f, r_e = 0.f, r_v = 1.f, r_dlib = 0.f;
+  if ((t >> 6) == 0) {
+    if (t <= L) r_h = a.heads_z[(int64_t)b * (L + 1) + t];
+    if (t < L) r_e = a.eps_z[(int64_t)b * L + t];
+    r_v = a.qz_v[b];
+  } else if ((t >> 6) == 1) {
+    const int lane = t & 63;
+    if (lane < 2) r_h = a.heads_l[(int64_t)b * 2 + lane];
+    if (lane < 1) r_e = a.eps_l[b];
+    r_v = a.ql_v[b];
+    r_dlib = a.dlibrary[b];
+  }
+  const float dze0 = (a.dz_extra && (t & 7) == 0 && (t >> 3) < L) ? a.dz_extra[(int64_t)b * L + (t >> 3)] : 0.f;
+  const float x_mean_b = a.x_mean ? a.x_mean[b] : 1.f;
   float dx[ME], xh[ME], pv[ME], dyv[ME];
   float s[2] = {0.f, 0.f};
   slab_sum(a.slabs + (int64_t)b * Hd, a.nslab, a.slab_stride, Hd, dyv);
@@ -525,7 +563,7 @@ __global__ __launch_bounds__(T) void mid_bwd_kernel(MidBwd a) {
       acc += __shfl_xor(acc, 1, WAVE);
       acc += __shfl_xor(acc, 2, WAVE);
       acc += __shfl_xor(acc, 4, WAVE);
-      if (part == 0) dzs[j] = acc + (a.dz_extra ? a.dz_extra[(int64_t)b * L + j] : 0.f);
+      if (part == 0) dzs[j] = acc + (a.dz_extra ? (j == (t >> 3) ? dze0 : a.dz_extra[(int64_t)b * L + j]) : 0.f);
     }
   }
   __syncthreads();
@@ -533,13 +571,11 @@ __global__ __launch_bounds__(T) void mid_bwd_kernel(MidBwd a) {
   {
     const int lane = t & 63, wave = t >> 6;
     if (wave == 0) {
-      reparam_bwd_wave(dzs, a.heads_z + (int64_t)b * (L + 1), a.eps_z + (int64_t)b * L, a.qz_v[b], a.g_kl, L, 0.f, 1.f,
-                       lane, a.dq_z + (int64_t)b * (L + 1), dq);
+      reparam_bwd_regs(dzs, r_h, r_e, r_v, a.g_kl, L, 0.f, 1.f, lane, a.dq_z + (int64_t)b * (L + 1), dq);
     } else if (wave == 1) {
       __shared__ float dlib[1];
-      if (lane == 0) dlib[0] = a.dlibrary[b];
-      reparam_bwd_wave(dlib, a.heads_l + (int64_t)b * 2, a.eps_l + b, a.ql_v[b], a.g_kl, 1, a.l_mean, a.l_var, lane,
-                       a.dq_l + (int64_t)b * 2, dq + L + 1);
+      if (lane == 0) dlib[0] = r_dlib;
+      reparam_bwd_regs(dlib, r_h, r_e, r_v, a.g_kl, 1, a.l_mean, a.l_var, lane, a.dq_l + (int64_t)b * 2, dq + L + 1);
     }
   }
   __syncthreads();
@@ -572,7 +608,7 @@ __global__ __launch_bounds__(T) void mid_bwd_kernel(MidBwd a) {
   }
   block_sums<4>(q4, red);
   float am = 0.f;
-  const float inv_m = a.x_mean ? 1.f / a.x_mean[b] : 1.f;
+  const float inv_m = a.x_mean ? 1.f / x_mean_b : 1.f;
   q4[0] /= (float)H; q4[1] /= (float)H;
   q4[2] /= (float)Hl; q4[3] /= (float)Hl;
 #pragma unroll
