@@ -959,6 +959,7 @@ __global__ __launch_bounds__(64 * WPB) void mid_bwd_wave_kernel(MidBwd a) {
     const float dzx = (a.dz_extra && lane < L) ? a.dz_extra[(int64_t)b * L + lane] : 0.f;
     const float qzv = a.qz_v[b], qlv = a.ql_v[b], dlib = a.dlibrary[b], epl = a.eps_l[b];
     const float hl0 = a.heads_l[(int64_t)b * 2], hl1 = a.heads_l[(int64_t)b * 2 + 1];
+    const float x_mean_b = a.x_mean ? a.x_mean[b] : 1.f;
     // 1. d(dec_h): sum of the dgrad slabs; LayerNorm + GELU backward of the decoder layer
     float dyv[NED], dx[NED], xh[NED], ds[NED];
     slab_sum_wave<NED, WPB>(a.slabs + (int64_t)b * Hd, a.nslab, a.slab_stride, Hd, lane, dyv);
@@ -1072,7 +1073,7 @@ __global__ __launch_bounds__(64 * WPB) void mid_bwd_wave_kernel(MidBwd a) {
     q4[0] /= (float)H; q4[1] /= (float)H;
     q4[2] /= (float)Hl; q4[3] /= (float)Hl;
     float am = 0.f;
-    const float inv_m = a.x_mean ? 1.f / a.x_mean[b] : 1.f;
+    const float inv_m = a.x_mean ? 1.f / x_mean_b : 1.f;
 #pragma unroll
     for (int i = 0; i < NEE; ++i) {
       const int e = lane + 64 * i;
