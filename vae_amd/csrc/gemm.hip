@@ -917,6 +917,9 @@ __device__ __forceinline__ void split_pair_f16(float a0, float a1, float s0, flo
 #ifndef VAE_STAT_INTERLEAVE   // decoder forward: statistics and plain column tiles alternate in launch order
 #define VAE_STAT_INTERLEAVE 1
 #endif
+#ifndef VAE_ROWSC_BATCH32
+#define VAE_ROWSC_BATCH32 1
+#endif
 #ifndef VAE_TN_XONE   // one-term count operand in the TN weight gradient too (128 x 128 tiles)
 #define VAE_TN_XONE 1
 #endif
@@ -1109,6 +1112,15 @@ __global__ __launch_bounds__(256, ((VAE_X3_PIPE && NP <= 2 && BM == 128 && BN ==
         if (m < g.M) {
           const float* q = m < g.rmax_split ? g.rmax0 + m : g.rmax1 + (m - g.rmax_split);
           int c = 0;
+#if VAE_ROWSC_BATCH32
+          for (; c + 32 <= g.rmax_chunks; c += 32) {   // (B = 512: the backward leaves exactly 32 chunks -- one round trip)
+            float t[32];
+#pragma unroll
+            for (int u = 0; u < 32; ++u) t[u] = q[(int64_t)(c + u) * g.rmax_stride];
+#pragma unroll
+            for (int u = 0; u < 32; ++u) mx = fmaxf(mx, t[u]);
+          }
+#endif
           for (; c + 16 <= g.rmax_chunks; c += 16) {   // sixteen loads in flight, not a chain of round trips
             float t[16];
 #pragma unroll
